@@ -1,0 +1,52 @@
+"""Build recipe for libs2v_hip.so (hipcc, gfx950 only).  `python build.py` or `build_library()`."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libs2v_hip.so")
+SOURCES = ["api.hip", "gemm.hip", "attention.hip", "elementwise.hip", "vae.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_library(force=False, verbose=True):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "s2v_hip.h"))
+    objs = []
+    procs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        if not os.path.exists(sp):
+            continue
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        if force or _stale(obj, [sp] + headers):
+            cmd = [hipcc] + FLAGS + ["-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    for src, p in procs:
+        if p.wait() != 0:
+            raise RuntimeError(f"hipcc failed on {src}")
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build_library(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,635 @@
+// C ABI of libs2v_hip.so (see include/s2v_hip.h): context, weight ingest / re-packing, workspace, and the launch
+// sequences of the transformer forward, the block / attention seams and the fused denoise step.
+#define S2V_HOST
+#include "common.h"
+#include "kernels.h"
+#include "../../include/s2v_hip.h"
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+thread_local std::string g_s2v_err;
+int s2v_fail(const char* file, int line, const char* msg, int code) {
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s:%d: %s", file, line, msg);
+    g_s2v_err = buf;
+    return code;
+}
+
+static inline int64_t rup(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct Slot {
+    char* dst = nullptr;   // destination inside the arena
+    int64_t rows = 0, cols = 0, ld = 0;
+    bool loaded = false;
+};
+
+struct LayerW {
+    char *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    char *wqkv, *bqkv, *nq_w, *nq_b, *nk_w, *nk_b, *wo, *bo;
+    char *w1, *b1, *w2, *b2;
+};
+
+struct GraphKey {
+    void* latents; float* x0; const void* noise;
+    bool operator==(const GraphKey& o) const { return latents == o.latents && x0 == o.x0 && noise == o.noise; }
+};
+
+struct s2v_ctx {
+    s2v_model_config cfg;
+    int D = 0, L = 0, dtype = 0, esz = 0, temb = 0;
+    bool mfma = false;
+    bool finalized = false;
+    // weights
+    char* arena = nullptr;
+    int64_t arena_bytes = 0;
+    std::unordered_map<std::string, Slot> slots;
+    std::vector<LayerW> layers;
+    char *patch_w, *patch_b, *text_w, *text_b, *te1_w, *te1_b, *te2_w, *te2_b;
+    char *nf_w, *nf_b, *no_w, *no_b, *po_w, *po_b;
+    char *mod_w, *mod_b;
+    int64_t mod_rows = 0;
+    // geometry + workspace
+    int B = 0, T = 0, F = 0, H = 0, W = 0, R = 0, V = 0, Ntok = 0, ntok_pad = 0;
+    int64_t M = 0, Mpad = 0;
+    char* ws = nullptr;
+    int64_t ws_bytes = 0;
+    char *X, *Xn, *QKV, *Hb, *VT, *e0, *e1, *patches, *tailn, *proj, *mod, *tmp_te, *emb, *noise_pred;
+    float *rope_cos, *rope_sin;
+    char* pos_tab;
+    bool have_rope = false, have_pos = false, have_cond = false;
+    float* t_dev = nullptr;
+    SchedCoef* coef_dev = nullptr;
+    // pinned staging ring for per-step scalars
+    struct Stage { float t[4]; SchedCoef c; };
+    Stage* ring = nullptr;
+    int ring_pos = 0;
+    // graph
+    hipStream_t cap_stream = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    GraphKey gkey{nullptr, nullptr, nullptr};
+};
+
+static const int RING = 256;
+
+// ------------------------------------------------------------------------------------------------------
+extern "C" const char* s2v_last_error(void) { return g_s2v_err.c_str(); }
+extern "C" const char* s2v_version(void) { return "s2v_hip 0.1 (gfx950)"; }
+
+static Slot* add_slot(s2v_ctx* c, const std::string& name, char* dst, int64_t rows, int64_t cols, int64_t ld) {
+    Slot s;
+    s.dst = dst; s.rows = rows; s.cols = cols; s.ld = ld;
+    c->slots[name] = s;
+    return &c->slots[name];
+}
+
+extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
+    S2V_REQUIRE(cfg && out, "s2v_create: null argument");
+    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_create: unsupported dtype");
+    S2V_REQUIRE(cfg->patch_size == 2, "s2v_create: patch_size must be 2");
+    S2V_REQUIRE(cfg->num_layers > 0 && cfg->num_heads > 0, "s2v_create: bad model size");
+    S2V_REQUIRE(cfg->in_channels * 4 <= 4096 && cfg->out_channels > 0, "s2v_create: bad channel count");
+    s2v_ctx* c = new s2v_ctx();
+    c->cfg = *cfg;
+    c->D = cfg->num_heads * 64;
+    c->L = cfg->num_layers;
+    c->dtype = cfg->dtype;
+    c->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
+    c->temb = cfg->time_embed_dim;
+    c->mfma = (cfg->dtype == S2V_DTYPE_BF16) && !cfg->force_simple;
+    if (c->D > 4096) { delete c; return s2v_fail(__FILE__, __LINE__, "s2v_create: D > 4096 unsupported", -1); }
+    if (c->temb % 8 != 0 || c->D % 8 != 0) { delete c; return s2v_fail(__FILE__, __LINE__, "bad dims", -1); }
+
+    const int64_t D = c->D, E = c->esz, L = c->L, TE = c->temb;
+    const int64_t Kp = cfg->in_channels * 4, Cout = cfg->out_channels * 4, TX = cfg->text_embed_dim;
+    // two passes: size, then carve
+    int64_t off = 0;
+    auto carve = [&](int64_t elems) { int64_t o = off; off += rup(elems * E, 256); return o; };
+    struct Offs { int64_t ln1_w, ln1_b, ln2_w, ln2_b, wqkv, bqkv, nq_w, nq_b, nk_w, nk_b, wo, bo, w1, b1, w2, b2; };
+    std::vector<Offs> lo(L);
+    const int64_t Dp = rup(D, 128);
+    for (int l = 0; l < L; ++l) {
+        Offs& o = lo[l];
+        o.ln1_w = carve(D); o.ln1_b = carve(D); o.ln2_w = carve(D); o.ln2_b = carve(D);
+        o.wqkv = carve(rup(3 * D, 128) * D); o.bqkv = carve(3 * D);
+        o.nq_w = carve(64); o.nq_b = carve(64); o.nk_w = carve(64); o.nk_b = carve(64);
+        o.wo = carve(Dp * D); o.bo = carve(D);
+        o.w1 = carve(rup(4 * D, 128) * D); o.b1 = carve(4 * D);
+        o.w2 = carve(Dp * 4 * D); o.b2 = carve(D);
+    }
+    const int64_t o_patch_w = carve(Dp * Kp), o_patch_b = carve(D);
+    const int64_t o_text_w = carve(Dp * TX), o_text_b = carve(D);
+    const int64_t o_te1_w = carve(TE * D), o_te1_b = carve(TE), o_te2_w = carve(TE * TE), o_te2_b = carve(TE);
+    const int64_t o_nf_w = carve(D), o_nf_b = carve(D), o_no_w = carve(D), o_no_b = carve(D);
+    const int64_t o_po_w = carve(rup(Cout, 128) * D), o_po_b = carve(Cout);
+    c->mod_rows = 2 * L * 6 * D + 2 * D;
+    const int64_t o_mod_w = carve(c->mod_rows * TE), o_mod_b = carve(c->mod_rows);
+    c->arena_bytes = off;
+    hipError_t e = hipMalloc((void**)&c->arena, c->arena_bytes);
+    if (e != hipSuccess) { delete c; return s2v_fail(__FILE__, __LINE__, hipGetErrorString(e), -2); }
+    e = hipMemset(c->arena, 0, c->arena_bytes);
+    if (e != hipSuccess) { hipFree(c->arena); delete c; return s2v_fail(__FILE__, __LINE__, hipGetErrorString(e), -2); }
+    char* A = c->arena;
+    c->layers.resize(L);
+    char nm[160];
+    for (int l = 0; l < L; ++l) {
+        const Offs& o = lo[l];
+        LayerW& w = c->layers[l];
+        w.ln1_w = A + o.ln1_w; w.ln1_b = A + o.ln1_b; w.ln2_w = A + o.ln2_w; w.ln2_b = A + o.ln2_b;
+        w.wqkv = A + o.wqkv; w.bqkv = A + o.bqkv; w.nq_w = A + o.nq_w; w.nq_b = A + o.nq_b;
+        w.nk_w = A + o.nk_w; w.nk_b = A + o.nk_b; w.wo = A + o.wo; w.bo = A + o.bo;
+        w.w1 = A + o.w1; w.b1 = A + o.b1; w.w2 = A + o.w2; w.b2 = A + o.b2;
+#define NM(fmt) (snprintf(nm, sizeof(nm), "transformer_blocks.%d." fmt, l), std::string(nm))
+        add_slot(c, NM("norm1.norm.weight"), w.ln1_w, 1, D, D);
+        add_slot(c, NM("norm1.norm.bias"), w.ln1_b, 1, D, D);
+        add_slot(c, NM("norm2.norm.weight"), w.ln2_w, 1, D, D);
+        add_slot(c, NM("norm2.norm.bias"), w.ln2_b, 1, D, D);
+        add_slot(c, NM("attn1.to_q.weight"), w.wqkv, D, D, D);
+        add_slot(c, NM("attn1.to_k.weight"), w.wqkv + D * D * E, D, D, D);
+        add_slot(c, NM("attn1.to_v.weight"), w.wqkv + 2 * D * D * E, D, D, D);
+        add_slot(c, NM("attn1.to_q.bias"), w.bqkv, 1, D, D);
+        add_slot(c, NM("attn1.to_k.bias"), w.bqkv + D * E, 1, D, D);
+        add_slot(c, NM("attn1.to_v.bias"), w.bqkv + 2 * D * E, 1, D, D);
+        add_slot(c, NM("attn1.norm_q.weight"), w.nq_w, 1, 64, 64);
+        add_slot(c, NM("attn1.norm_q.bias"), w.nq_b, 1, 64, 64);
+        add_slot(c, NM("attn1.norm_k.weight"), w.nk_w, 1, 64, 64);
+        add_slot(c, NM("attn1.norm_k.bias"), w.nk_b, 1, 64, 64);
+        add_slot(c, NM("attn1.to_out.0.weight"), w.wo, D, D, D);
+        add_slot(c, NM("attn1.to_out.0.bias"), w.bo, 1, D, D);
+        add_slot(c, NM("ff.net.0.proj.weight"), w.w1, 4 * D, D, D);
+        add_slot(c, NM("ff.net.0.proj.bias"), w.b1, 1, 4 * D, 4 * D);
+        add_slot(c, NM("ff.net.2.weight"), w.w2, D, 4 * D, 4 * D);
+        add_slot(c, NM("ff.net.2.bias"), w.b2, 1, D, D);
+        add_slot(c, NM("norm1.linear.weight"), A + o_mod_w + (int64_t)(2 * l) * 6 * D * TE * E, 6 * D, TE, TE);
+        add_slot(c, NM("norm1.linear.bias"), A + o_mod_b + (int64_t)(2 * l) * 6 * D * E, 1, 6 * D, 6 * D);
+        add_slot(c, NM("norm2.linear.weight"), A + o_mod_w + (int64_t)(2 * l + 1) * 6 * D * TE * E, 6 * D, TE, TE);
+        add_slot(c, NM("norm2.linear.bias"), A + o_mod_b + (int64_t)(2 * l + 1) * 6 * D * E, 1, 6 * D, 6 * D);
+#undef NM
+    }
+    c->patch_w = A + o_patch_w; c->patch_b = A + o_patch_b; c->text_w = A + o_text_w; c->text_b = A + o_text_b;
+    c->te1_w = A + o_te1_w; c->te1_b = A + o_te1_b; c->te2_w = A + o_te2_w; c->te2_b = A + o_te2_b;
+    c->nf_w = A + o_nf_w; c->nf_b = A + o_nf_b; c->no_w = A + o_no_w; c->no_b = A + o_no_b;
+    c->po_w = A + o_po_w; c->po_b = A + o_po_b; c->mod_w = A + o_mod_w; c->mod_b = A + o_mod_b;
+    add_slot(c, "patch_embed.proj.weight", c->patch_w, D, Kp, Kp);
+    add_slot(c, "patch_embed.proj.bias", c->patch_b, 1, D, D);
+    add_slot(c, "patch_embed.text_proj.weight", c->text_w, D, TX, TX);
+    add_slot(c, "patch_embed.text_proj.bias", c->text_b, 1, D, D);
+    add_slot(c, "time_embedding.linear_1.weight", c->te1_w, TE, D, D);
+    add_slot(c, "time_embedding.linear_1.bias", c->te1_b, 1, TE, TE);
+    add_slot(c, "time_embedding.linear_2.weight", c->te2_w, TE, TE, TE);
+    add_slot(c, "time_embedding.linear_2.bias", c->te2_b, 1, TE, TE);
+    add_slot(c, "norm_final.weight", c->nf_w, 1, D, D);
+    add_slot(c, "norm_final.bias", c->nf_b, 1, D, D);
+    add_slot(c, "norm_out.norm.weight", c->no_w, 1, D, D);
+    add_slot(c, "norm_out.norm.bias", c->no_b, 1, D, D);
+    add_slot(c, "norm_out.linear.weight", c->mod_w + (int64_t)2 * L * 6 * D * TE * E, 2 * D, TE, TE);
+    add_slot(c, "norm_out.linear.bias", c->mod_b + (int64_t)2 * L * 6 * D * E, 1, 2 * D, 2 * D);
+    add_slot(c, "proj_out.weight", c->po_w, Cout, D, D);
+    add_slot(c, "proj_out.bias", c->po_b, 1, Cout, Cout);
+
+    hipMalloc((void**)&c->t_dev, 4 * sizeof(float));
+    hipMalloc((void**)&c->coef_dev, sizeof(SchedCoef));
+    hipHostMalloc((void**)&c->ring, sizeof(s2v_ctx::Stage) * RING);
+    hipStreamCreateWithFlags(&c->cap_stream, hipStreamNonBlocking);
+    if (!c->t_dev || !c->coef_dev || !c->ring || !c->cap_stream) {
+        s2v_destroy(c);
+        return s2v_fail(__FILE__, __LINE__, "s2v_create: allocation failed", -2);
+    }
+    *out = c;
+    return 0;
+}
+
+extern "C" void s2v_destroy(s2v_ctx* c) {
+    if (!c) return;
+    if (c->gexec) hipGraphExecDestroy(c->gexec);
+    if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+    if (c->ring) hipHostFree(c->ring);
+    if (c->coef_dev) hipFree(c->coef_dev);
+    if (c->t_dev) hipFree(c->t_dev);
+    if (c->ws) hipFree(c->ws);
+    if (c->arena) hipFree(c->arena);
+    delete c;
+}
+
+extern "C" int s2v_load_weight(s2v_ctx* c, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
+                               int32_t src_dtype, s2v_stream stream) {
+    S2V_REQUIRE(c && name && dev_ptr && shape, "s2v_load_weight: null argument");
+    S2V_REQUIRE(!c->finalized, "s2v_load_weight: weights already finalized");
+    S2V_REQUIRE(src_dtype == S2V_DTYPE_F32 || src_dtype == S2V_DTYPE_BF16, "s2v_load_weight: unsupported source dtype");
+    auto it = c->slots.find(name);
+    if (it == c->slots.end()) {
+        std::string m = std::string("s2v_load_weight: unknown tensor name: ") + name;
+        return s2v_fail(__FILE__, __LINE__, m.c_str(), -3);
+    }
+    Slot& s = it->second;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    if (n != s.rows * s.cols || (ndim >= 2 && shape[0] != s.rows)) {
+        std::string m = std::string("s2v_load_weight: shape mismatch for ") + name;
+        return s2v_fail(__FILE__, __LINE__, m.c_str(), -3);
+    }
+    S2V_TRY(launch_convert2d(dev_ptr, src_dtype, s.cols, s.dst, c->dtype, s.ld, s.rows, s.cols, (hipStream_t)stream));
+    s.loaded = true;
+    return 0;
+}
+
+extern "C" int s2v_merge_lora(s2v_ctx* c, const char* name, const float* A, const float* B, int32_t rank, float scale,
+                              s2v_stream stream) {
+    S2V_REQUIRE(c && name && A && B && rank > 0, "s2v_merge_lora: bad argument");
+    S2V_REQUIRE(!c->finalized, "s2v_merge_lora: weights already finalized");
+    auto it = c->slots.find(name);
+    S2V_REQUIRE(it != c->slots.end(), "s2v_merge_lora: unknown tensor name");
+    Slot& s = it->second;
+    S2V_REQUIRE(s.loaded && s.rows > 1, "s2v_merge_lora: base weight must be a loaded matrix");
+    hipStream_t st = (hipStream_t)stream;
+    float* tmp = nullptr;
+    S2V_CHECK_HIP(hipMalloc((void**)&tmp, sizeof(float) * s.rows * s.cols));
+    int r = launch_convert2d(s.dst, c->dtype, s.ld, tmp, S2V_F32, s.cols, s.rows, s.cols, st);
+    // tmp[out][in] += scale * sum_k B[out][k] * A[k][in]
+    if (!r) r = launch_gemm_strided_f32(B, rank, 1, A, 1, s.cols, tmp, s.cols, (int)s.rows, (int)s.cols, rank, scale, st);
+    if (!r) r = launch_convert2d(tmp, S2V_F32, s.cols, s.dst, c->dtype, s.ld, s.rows, s.cols, st);
+    hipStreamSynchronize(st);
+    hipFree(tmp);
+    return r;
+}
+
+extern "C" int s2v_finalize_weights(s2v_ctx* c, s2v_stream stream) {
+    S2V_REQUIRE(c, "s2v_finalize_weights: null context");
+    for (auto& kv : c->slots) {
+        if (!kv.second.loaded) {
+            std::string m = std::string("s2v_finalize_weights: tensor was never loaded: ") + kv.first;
+            return s2v_fail(__FILE__, __LINE__, m.c_str(), -3);
+        }
+    }
+    c->finalized = true;
+    return 0;
+}
+
+extern "C" int s2v_weight_arena(s2v_ctx* c, void** dev_ptr, int64_t* bytes) {
+    S2V_REQUIRE(c && dev_ptr && bytes, "s2v_weight_arena: null argument");
+    *dev_ptr = c->arena;
+    *bytes = c->arena_bytes;
+    return 0;
+}
+// a replica that received the arena by broadcast marks itself loaded
+extern "C" int s2v_mark_weights_loaded(s2v_ctx* c) {
+    S2V_REQUIRE(c, "null context");
+    for (auto& kv : c->slots) kv.second.loaded = true;
+    c->finalized = true;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int32_t H, int32_t W) {
+    S2V_REQUIRE(c, "null context");
+    S2V_REQUIRE(B >= 1 && B <= 4, "s2v_set_geometry: batch must be 1..4");
+    S2V_REQUIRE(T >= 0 && F >= 1 && H >= 2 && W >= 2 && H % 2 == 0 && W % 2 == 0, "s2v_set_geometry: bad geometry");
+    if (c->ws && B == c->B && T == c->T && F == c->F && H == c->H && W == c->W) return 0;
+    S2V_CHECK_HIP(hipDeviceSynchronize());
+    if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    if (c->ws) { hipFree(c->ws); c->ws = nullptr; }
+    c->B = B; c->T = T; c->F = F; c->H = H; c->W = W;
+    c->R = (H / 2) * (W / 2);
+    c->V = F * c->R;
+    c->Ntok = T + c->R + c->V;
+    c->ntok_pad = (int)rup(c->Ntok, 64);
+    c->M = (int64_t)B * c->Ntok;
+    c->Mpad = rup(c->M, 128) + 128;
+    c->have_rope = c->have_pos = c->have_cond = false;
+    const int64_t D = c->D, E = c->esz;
+    const int64_t Cin4 = c->cfg.in_channels * 4, Cout4 = c->cfg.out_channels * 4;
+    const int64_t BVp = rup((int64_t)B * c->V, 128) + 128;
+    int64_t off = 0;
+    auto carve = [&](int64_t bytes) { int64_t o = off; off += rup(bytes, 256); return o; };
+    const int64_t oX = carve(c->Mpad * D * E), oXn = carve(c->Mpad * D * E), oQKV = carve(c->Mpad * 3 * D * E);
+    const int64_t oH = carve(c->Mpad * 4 * D * E);
+    const int64_t oVT = carve((int64_t)B * c->cfg.num_heads * 64 * c->ntok_pad * 2);
+    const int64_t oe0 = carve(rup((int64_t)B * T + 128, 128) * D * E), oe1 = carve(rup(c->R + 128, 128) * D * E);
+    const int64_t opat = carve(BVp * Cin4 * E), otail = carve(BVp * D * E), oproj = carve(BVp * Cout4 * E);
+    const int64_t omod = carve((int64_t)B * c->mod_rows * E);
+    const int64_t ote = carve(((int64_t)B * D + (int64_t)B * c->temb) * E), oemb = carve((int64_t)B * c->temb * E);
+    const int64_t onp = carve((int64_t)B * F * c->cfg.out_channels * H * W * E);
+    const int64_t ocos = carve((int64_t)(c->R + c->V) * 64 * 4), osin = carve((int64_t)(c->R + c->V) * 64 * 4);
+    const int64_t opos = carve((int64_t)c->V * D * E);
+    c->ws_bytes = off;
+    S2V_CHECK_HIP(hipMalloc((void**)&c->ws, c->ws_bytes));
+    S2V_CHECK_HIP(hipMemset(c->ws, 0, c->ws_bytes));
+    char* w = c->ws;
+    c->X = w + oX; c->Xn = w + oXn; c->QKV = w + oQKV; c->Hb = w + oH; c->VT = w + oVT; c->e0 = w + oe0; c->e1 = w + oe1;
+    c->patches = w + opat; c->tailn = w + otail; c->proj = w + oproj; c->mod = w + omod; c->tmp_te = w + ote;
+    c->emb = w + oemb; c->noise_pred = w + onp; c->rope_cos = (float*)(w + ocos); c->rope_sin = (float*)(w + osin);
+    c->pos_tab = w + opos;
+    return 0;
+}
+
+extern "C" int s2v_set_rope(s2v_ctx* c, const float* cos_dev, const float* sin_dev, s2v_stream stream) {
+    S2V_REQUIRE(c && c->ws, "s2v_set_rope: call s2v_set_geometry first");
+    if (!cos_dev || !sin_dev) { c->have_rope = false; return 0; }
+    const size_t bytes = (size_t)(c->R + c->V) * 64 * 4;
+    S2V_CHECK_HIP(hipMemcpyAsync(c->rope_cos, cos_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    S2V_CHECK_HIP(hipMemcpyAsync(c->rope_sin, sin_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    c->have_rope = true;
+    return 0;
+}
+
+extern "C" int s2v_set_pos_embed(s2v_ctx* c, const void* table_dev, s2v_stream stream) {
+    S2V_REQUIRE(c && c->ws, "s2v_set_pos_embed: call s2v_set_geometry first");
+    if (!table_dev) { c->have_pos = false; return 0; }
+    S2V_CHECK_HIP(hipMemcpyAsync(c->pos_tab, table_dev, (size_t)c->V * c->D * c->esz, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+    c->have_pos = true;
+    return 0;
+}
+
+static int linear(s2v_ctx* c, const GemmArgs& g, int epi, hipStream_t st) {
+    if (c->mfma && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0) return launch_gemm_bf16(g, epi, st);
+    return launch_gemm_simple(g, epi, c->dtype, st);
+}
+
+extern "C" int s2v_set_conditioning(s2v_ctx* c, const void* text_dev, const void* ref_latent_dev, s2v_stream stream) {
+    S2V_REQUIRE(c && c->ws && c->finalized, "s2v_set_conditioning: geometry and weights must be set first");
+    S2V_REQUIRE(text_dev && ref_latent_dev, "s2v_set_conditioning: null input");
+    hipStream_t st = (hipStream_t)stream;
+    const int D = c->D;
+    // text_proj (cogvideox_transformer_3d.py:494).  The MFMA kernel stages 128-row tiles, so the operand is first
+    // copied into the (padded, zero-initialised) Hb scratch.
+    const int TX = c->cfg.text_embed_dim;
+    if (c->T > 0) {
+        S2V_TRY(launch_convert2d(text_dev, c->dtype, TX, c->Hb, c->dtype, TX, (int64_t)c->B * c->T, TX, st));
+        GemmArgs g{};
+        g.A = c->Hb; g.lda = TX; g.W = c->text_w; g.ldw = TX; g.bias = c->text_b;
+        g.C = c->e0; g.ldc = D; g.M = c->B * c->T; g.N = D; g.K = TX;
+        S2V_TRY(linear(c, g, EPI_BIAS, st));
+    }
+    // reference image latent -> patch tokens (cogvideox_transformer_3d.py:496-501); identical for every sample
+    const int K = c->cfg.in_channels * 4;
+    S2V_TRY(launch_patchify(ref_latent_dev, 0, 1, 1, c->cfg.in_channels, c->H, c->W, c->patches, c->dtype, st));
+    GemmArgs g{};
+    g.A = c->patches; g.lda = K; g.W = c->patch_w; g.ldw = K; g.bias = c->patch_b;
+    g.C = c->e1; g.ldc = D; g.M = c->R; g.N = D; g.K = K;
+    S2V_TRY(linear(c, g, EPI_BIAS, st));
+    c->have_cond = true;
+    return 0;
+}
+
+// ---- one transformer block on the packed residual buffer X ------------------------------------------------
+static int run_attention(s2v_ctx* c, int l, hipStream_t st) {
+    // Xn -> QKV -> (qk-norm, rope, V^T) -> attention -> Xn (reused as the attention output buffer)
+    const LayerW& w = c->layers[l];
+    const int D = c->D;
+    GemmArgs g{};
+    g.A = c->Xn; g.lda = D; g.W = w.wqkv; g.ldw = D; g.bias = w.bqkv;
+    g.C = c->QKV; g.ldc = 3 * D; g.M = (int)c->M; g.N = 3 * D; g.K = D;
+    S2V_TRY(linear(c, g, EPI_BIAS, st));
+    QkNormRopeArgs q{};
+    q.qkv = c->QKV; q.ld_qkv = 3 * D; q.B = c->B; q.H = c->cfg.num_heads; q.Ntok = c->Ntok; q.text_len = c->T;
+    q.nq_w = w.nq_w; q.nq_b = w.nq_b; q.nk_w = w.nk_w; q.nk_b = w.nk_b; q.eps = 1e-6f;
+    q.cos = c->have_rope ? c->rope_cos : nullptr; q.sin = c->have_rope ? c->rope_sin : nullptr;
+    q.vt = c->mfma ? c->VT : nullptr; q.ntok_pad = c->ntok_pad;
+    S2V_TRY(launch_qk_norm_rope(q, c->dtype, st));
+    AttnArgs a{};
+    a.qkv = c->QKV; a.ld_qkv = 3 * D; a.vt = c->VT; a.ntok_pad = c->ntok_pad; a.out = c->Xn; a.ld_out = D;
+    a.B = c->B; a.H = c->cfg.num_heads; a.Ntok = c->Ntok; a.scale = 0.125f;
+    if (c->mfma) S2V_TRY(launch_attn_bf16(a, st));
+    else S2V_TRY(launch_attn_simple(a, c->dtype, st));
+    return 0;
+}
+
+static int run_block(s2v_ctx* c, int l, const char* mod_base /* [B][mod_stride] rows of this layer's norm1 */,
+                     int64_t mod_stride, hipStream_t st) {
+    const LayerW& w = c->layers[l];
+    const int D = c->D;
+    const int64_t E = c->esz;
+    for (int half = 0; half < 2; ++half) {
+        const char* mb = mod_base + (int64_t)half * 6 * D * E;
+        LnModArgs n{};
+        n.x = c->X; n.ldx = D; n.y = c->Xn; n.ldy = D;
+        n.w = half ? w.ln2_w : w.ln1_w; n.b = half ? w.ln2_b : w.ln1_b; n.eps = c->cfg.norm_eps;
+        n.shift_vid = mb; n.scale_vid = mb + D * E; n.shift_txt = mb + 3 * D * E; n.scale_txt = mb + 4 * D * E;
+        n.mod_stride = (int)mod_stride; n.B = c->B; n.Ntok = c->Ntok; n.text_len = c->T; n.D = D;
+        S2V_TRY(launch_ln_modulate(n, c->dtype, st));
+        GemmArgs g{};
+        g.X = c->X; g.ldx = D; g.gate_vid = mb + 2 * D * E; g.gate_txt = mb + 5 * D * E; g.gate_stride = (int)mod_stride;
+        g.tok_per_batch = c->Ntok; g.text_len = c->T; g.M = (int)c->M; g.N = D;
+        if (half == 0) {
+            S2V_TRY(run_attention(c, l, st));
+            g.A = c->Xn; g.lda = D; g.W = w.wo; g.ldw = D; g.bias = w.bo; g.K = D;
+            S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
+        } else {
+            GemmArgs f{};
+            f.A = c->Xn; f.lda = D; f.W = w.w1; f.ldw = D; f.bias = w.b1; f.C = c->Hb; f.ldc = 4 * D;
+            f.M = (int)c->M; f.N = 4 * D; f.K = D;
+            S2V_TRY(linear(c, f, EPI_BIAS_GELU, st));
+            g.A = c->Hb; g.lda = 4 * D; g.W = w.w2; g.ldw = 4 * D; g.bias = w.b2; g.K = 4 * D;
+            S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
+        }
+    }
+    return 0;
+}
+
+static int forward_impl(s2v_ctx* c, const void* latents, int64_t lat_bstride, const float* t_dev, void* out,
+                        hipStream_t st) {
+    S2V_REQUIRE(c->ws && c->finalized && c->have_cond, "transformer_forward: geometry, weights and conditioning required");
+    S2V_REQUIRE(!c->cfg.use_rope || c->have_rope, "transformer_forward: RoPE tables missing (s2v_set_rope)");
+    S2V_REQUIRE(c->cfg.use_rope || c->have_pos, "transformer_forward: sincos table missing (s2v_set_pos_embed)");
+    const int D = c->D, B = c->B;
+    const int64_t E = c->esz;
+    // 1. timestep embedding + every AdaLN modulation of the step in one batched GEMV (temb is block-invariant)
+    S2V_TRY(launch_time_embed(t_dev, B, D, c->te1_w, c->te1_b, c->te2_w, c->te2_b, c->temb, c->tmp_te, c->emb, c->dtype, st));
+    S2V_TRY(launch_mod_gemv(c->emb, B, c->temb, c->mod_w, c->mod_b, c->mod_rows, c->mod, c->dtype, st));
+    // 2. residual streams: [text | ref | video] per sample
+    const int K = c->cfg.in_channels * 4;
+    S2V_TRY(launch_patchify(latents, lat_bstride, B, c->F, c->cfg.in_channels, c->H, c->W, c->patches, c->dtype, st));
+    for (int b = 0; b < B; ++b) {
+        char* xb = c->X + (int64_t)b * c->Ntok * D * E;
+        S2V_TRY(launch_copy_rows(c->e0 + (int64_t)b * c->T * D * E, D, nullptr, 0, xb, D, c->T, D, c->dtype, st));
+        S2V_TRY(launch_copy_rows(c->e1, D, nullptr, 0, xb + (int64_t)c->T * D * E, D, c->R, D, c->dtype, st));
+        char* xv = xb + (int64_t)(c->T + c->R) * D * E;
+        GemmArgs g{};
+        g.A = c->patches + (int64_t)b * c->V * K * E; g.lda = K; g.W = c->patch_w; g.ldw = K; g.bias = c->patch_b;
+        g.C = xv; g.ldc = D; g.M = c->V; g.N = D; g.K = K;
+        S2V_TRY(linear(c, g, EPI_BIAS, st));
+        if (!c->cfg.use_rope) S2V_TRY(launch_copy_rows(xv, D, c->pos_tab, D, xv, D, c->V, D, c->dtype, st));
+    }
+    // 3. blocks
+    for (int l = 0; l < c->L; ++l)
+        S2V_TRY(run_block(c, l, c->mod + (int64_t)(2 * l) * 6 * D * E, c->mod_rows, st));
+    // 4. tail
+    const char* mo = c->mod + (int64_t)2 * c->L * 6 * D * E;
+    TailNormArgs t{};
+    t.x = c->X; t.ldx = D; t.y = c->tailn; t.ldy = D; t.w1 = c->nf_w; t.b1 = c->nf_b; t.w2 = c->no_w; t.b2 = c->no_b;
+    t.eps = c->cfg.norm_eps; t.shift = mo; t.scale = mo + D * E; t.mod_stride = (int)c->mod_rows;
+    t.B = B; t.Ntok = c->Ntok; t.row0 = c->T + c->R; t.V = c->V; t.D = D;
+    S2V_TRY(launch_tail_norm(t, c->dtype, st));
+    const int Co = c->cfg.out_channels * 4;
+    GemmArgs g{};
+    g.A = c->tailn; g.lda = D; g.W = c->po_w; g.ldw = D; g.bias = c->po_b; g.C = c->proj; g.ldc = Co;
+    g.M = B * c->V; g.N = Co; g.K = D;
+    S2V_TRY(linear(c, g, EPI_BIAS, st));
+    S2V_TRY(launch_unpatchify(c->proj, Co, c->V, out, B, c->F, c->cfg.out_channels, c->H, c->W, c->dtype, st));
+    return 0;
+}
+
+extern "C" int s2v_transformer_forward(s2v_ctx* c, const void* latents, int64_t lat_bstride, const float* timesteps_dev,
+                                       void* out, s2v_stream stream) {
+    S2V_REQUIRE(c && latents && timesteps_dev && out, "s2v_transformer_forward: null argument");
+    return forward_impl(c, latents, lat_bstride, timesteps_dev, out, (hipStream_t)stream);
+}
+
+extern "C" int s2v_block_forward(s2v_ctx* c, int32_t layer, const void* hidden, const void* enc0, const void* enc1,
+                                 const void* temb, void* out_hidden, void* out_enc0, void* out_enc1, s2v_stream stream) {
+    S2V_REQUIRE(c && c->ws && c->finalized, "s2v_block_forward: geometry and weights required");
+    S2V_REQUIRE(layer >= 0 && layer < c->L, "s2v_block_forward: bad layer");
+    S2V_REQUIRE(hidden && enc1 && temb && out_hidden && out_enc1, "s2v_block_forward: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int D = c->D, B = c->B;
+    const int64_t E = c->esz;
+    // this layer's two modulation linears are contiguous in the stack: rows [(2l)*6D, (2l+2)*6D)
+    const int64_t r0 = (int64_t)(2 * layer) * 6 * D;
+    char* modl = c->mod;  // [B][12D]
+    S2V_TRY(launch_mod_gemv(temb, B, c->temb, c->mod_w + r0 * c->temb * E, c->mod_b + r0 * E, 12 * D, modl, c->dtype, st));
+    for (int b = 0; b < B; ++b) {
+        char* xb = c->X + (int64_t)b * c->Ntok * D * E;
+        if (c->T) S2V_TRY(launch_copy_rows((const char*)enc0 + (int64_t)b * c->T * D * E, D, nullptr, 0, xb, D, c->T, D, c->dtype, st));
+        S2V_TRY(launch_copy_rows((const char*)enc1 + (int64_t)b * c->R * D * E, D, nullptr, 0, xb + (int64_t)c->T * D * E, D, c->R, D, c->dtype, st));
+        S2V_TRY(launch_copy_rows((const char*)hidden + (int64_t)b * c->V * D * E, D, nullptr, 0, xb + (int64_t)(c->T + c->R) * D * E, D, c->V, D, c->dtype, st));
+    }
+    S2V_TRY(run_block(c, layer, modl, 12 * D, st));
+    for (int b = 0; b < B; ++b) {
+        const char* xb = c->X + (int64_t)b * c->Ntok * D * E;
+        if (c->T) S2V_TRY(launch_copy_rows(xb, D, nullptr, 0, (char*)out_enc0 + (int64_t)b * c->T * D * E, D, c->T, D, c->dtype, st));
+        S2V_TRY(launch_copy_rows(xb + (int64_t)c->T * D * E, D, nullptr, 0, (char*)out_enc1 + (int64_t)b * c->R * D * E, D, c->R, D, c->dtype, st));
+        S2V_TRY(launch_copy_rows(xb + (int64_t)(c->T + c->R) * D * E, D, nullptr, 0, (char*)out_hidden + (int64_t)b * c->V * D * E, D, c->V, D, c->dtype, st));
+    }
+    return 0;
+}
+
+extern "C" int s2v_attn_forward(s2v_ctx* c, int32_t layer, const void* hidden, const void* encoder, void* out_hidden,
+                                void* out_encoder, s2v_stream stream) {
+    S2V_REQUIRE(c && c->ws && c->finalized, "s2v_attn_forward: geometry and weights required");
+    S2V_REQUIRE(layer >= 0 && layer < c->L, "s2v_attn_forward: bad layer");
+    S2V_REQUIRE(hidden && encoder && out_hidden && out_encoder, "s2v_attn_forward: null argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int D = c->D, B = c->B, TR = c->T + c->R;
+    const int64_t E = c->esz;
+    for (int b = 0; b < B; ++b) {
+        char* xb = c->Xn + (int64_t)b * c->Ntok * D * E;
+        S2V_TRY(launch_copy_rows((const char*)encoder + (int64_t)b * TR * D * E, D, nullptr, 0, xb, D, TR, D, c->dtype, st));
+        S2V_TRY(launch_copy_rows((const char*)hidden + (int64_t)b * c->V * D * E, D, nullptr, 0, xb + (int64_t)TR * D * E, D, c->V, D, c->dtype, st));
+    }
+    S2V_TRY(run_attention(c, layer, st));
+    const LayerW& w = c->layers[layer];
+    GemmArgs g{};
+    g.A = c->Xn; g.lda = D; g.W = w.wo; g.ldw = D; g.bias = w.bo; g.C = c->Hb; g.ldc = D; g.M = (int)c->M; g.N = D; g.K = D;
+    S2V_TRY(linear(c, g, EPI_BIAS, st));
+    for (int b = 0; b < B; ++b) {
+        const char* xb = c->Hb + (int64_t)b * c->Ntok * D * E;
+        S2V_TRY(launch_copy_rows(xb, D, nullptr, 0, (char*)out_encoder + (int64_t)b * TR * D * E, D, TR, D, c->dtype, st));
+        S2V_TRY(launch_copy_rows(xb + (int64_t)TR * D * E, D, nullptr, 0, (char*)out_hidden + (int64_t)b * c->V * D * E, D, c->V, D, c->dtype, st));
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+static void fill_coef(SchedCoef& d, const s2v_sched_coef& s) {
+    d.kind = s.kind; d.guidance = s.guidance; d.c_x0_x = s.c_x0_x; d.c_x0_v = s.c_x0_v; d.a_t = s.a_t; d.b_t = s.b_t;
+    d.m1 = s.m1; d.m2 = s.m2; d.m3 = s.m3; d.m4 = s.m4; d.mn = s.mn; d.pad = 0.f;
+}
+
+extern "C" int s2v_sched_step(s2v_ctx* c, const s2v_sched_coef* coef_host, const void* noise_pred, int32_t cfg,
+                              const void* latents_in, void* latents_out, float* x0_hist, const void* noise, int64_t n,
+                              s2v_stream stream) {
+    S2V_REQUIRE(c && coef_host && noise_pred && latents_in && latents_out, "s2v_sched_step: null argument");
+    S2V_REQUIRE(coef_host->kind == 0 || noise, "s2v_sched_step: DPM step needs a noise tensor");
+    S2V_REQUIRE(coef_host->kind != 2 || x0_hist, "s2v_sched_step: DPM multistep needs x0_hist");
+    hipStream_t st = (hipStream_t)stream;
+    s2v_ctx::Stage& sg = c->ring[c->ring_pos];
+    c->ring_pos = (c->ring_pos + 1) % RING;
+    fill_coef(sg.c, *coef_host);
+    S2V_CHECK_HIP(hipMemcpyAsync(c->coef_dev, &sg.c, sizeof(SchedCoef), hipMemcpyHostToDevice, st));
+    SchedArgs a{};
+    a.noise_pred = noise_pred; a.latents_in = latents_in; a.latents_out = latents_out; a.x0_hist = x0_hist;
+    a.noise = noise; a.n = n; a.cfg = cfg; a.coef = c->coef_dev;
+    return launch_sched_step(a, c->dtype, st);
+}
+
+static int step_launches(s2v_ctx* c, void* latents, float* x0_hist, const void* noise, hipStream_t st) {
+    S2V_TRY(forward_impl(c, latents, 0, c->t_dev, c->noise_pred, st));
+    SchedArgs a{};
+    a.noise_pred = c->noise_pred; a.latents_in = latents; a.latents_out = latents; a.x0_hist = x0_hist; a.noise = noise;
+    a.n = (int64_t)c->F * c->cfg.out_channels * c->H * c->W; a.cfg = c->B == 2 ? 1 : 0; a.coef = c->coef_dev;
+    return launch_sched_step(a, c->dtype, st);
+}
+
+extern "C" int s2v_denoise_step(s2v_ctx* c, void* latents, float timestep, const s2v_sched_coef* coef_host,
+                                float* x0_hist, const void* noise, int32_t use_graph, s2v_stream stream) {
+    S2V_REQUIRE(c && latents && coef_host, "s2v_denoise_step: null argument");
+    S2V_REQUIRE(c->ws && (c->B == 1 || c->B == 2), "s2v_denoise_step: geometry with B = 1 or 2 (CFG pair) required");
+    S2V_REQUIRE(c->cfg.in_channels == c->cfg.out_channels, "s2v_denoise_step: in/out channels must match");
+    S2V_REQUIRE(coef_host->kind == 0 || (noise && x0_hist), "s2v_denoise_step: DPM needs noise and x0_hist");
+    hipStream_t st = (hipStream_t)stream;
+    s2v_ctx::Stage& sg = c->ring[c->ring_pos];
+    c->ring_pos = (c->ring_pos + 1) % RING;
+    for (int i = 0; i < 4; ++i) sg.t[i] = timestep;
+    fill_coef(sg.c, *coef_host);
+    S2V_CHECK_HIP(hipMemcpyAsync(c->t_dev, sg.t, sizeof(float) * 4, hipMemcpyHostToDevice, st));
+    S2V_CHECK_HIP(hipMemcpyAsync(c->coef_dev, &sg.c, sizeof(SchedCoef), hipMemcpyHostToDevice, st));
+    if (!use_graph) return step_launches(c, latents, x0_hist, noise, st);
+    GraphKey key{latents, x0_hist, noise};
+    if (!c->gexec || !(c->gkey == key)) {
+        if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        hipGraph_t graph = nullptr;
+        S2V_CHECK_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+        int r = step_launches(c, latents, x0_hist, noise, c->cap_stream);
+        hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
+        if (r != 0) { if (graph) hipGraphDestroy(graph); return r; }
+        S2V_CHECK_HIP(e);
+        e = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        S2V_CHECK_HIP(e);
+        c->gkey = key;
+    }
+    S2V_CHECK_HIP(hipGraphLaunch(c->gexec, st));
+    return 0;
+}
+
+extern "C" int s2v_last_noise_pred(s2v_ctx* c, void** dev_ptr) {
+    S2V_REQUIRE(c && c->ws && dev_ptr, "s2v_last_noise_pred: no workspace");
+    *dev_ptr = c->noise_pred;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+extern "C" int s2v_op_linear(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
+                             int32_t epilogue, int32_t dtype, int32_t impl, s2v_stream stream) {
+    S2V_REQUIRE(A && W && C, "s2v_op_linear: null argument");
+    S2V_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU, "s2v_op_linear: epilogue must be 0 or 1");
+    GemmArgs g{};
+    g.A = A; g.lda = K; g.W = W; g.ldw = K; g.bias = bias; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    if (impl == 0) {
+        S2V_REQUIRE(dtype == S2V_DTYPE_BF16, "s2v_op_linear: the MFMA kernel is bf16 only");
+        S2V_REQUIRE(M % 128 == 0 && N % 128 == 0, "s2v_op_linear: impl 0 needs M and N padded to 128 by the caller");
+        return launch_gemm_bf16(g, epilogue, (hipStream_t)stream);
+    }
+    return launch_gemm_simple(g, epilogue, dtype, (hipStream_t)stream);
+}
+
+extern "C" int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok,
+                                int32_t dtype, int32_t impl, s2v_stream stream) {
+    S2V_REQUIRE(qkv && out, "s2v_op_attention: null argument");
+    const int D = H * 64;
+    AttnArgs a{};
+    a.qkv = qkv; a.ld_qkv = 3 * D; a.out = out; a.ld_out = D; a.B = B; a.H = H; a.Ntok = Ntok; a.scale = 0.125f;
+    a.ntok_pad = (int)rup(Ntok, 64);
+    hipStream_t st = (hipStream_t)stream;
+    if (impl == 0) {
+        S2V_REQUIRE(dtype == S2V_DTYPE_BF16 && vt_scratch, "s2v_op_attention: impl 0 is bf16 and needs vt_scratch");
+        a.vt = vt_scratch;
+        S2V_TRY(launch_v_transpose(qkv, 3 * D, B, H, Ntok, vt_scratch, a.ntok_pad, st));
+        return launch_attn_bf16(a, st);
+    }
+    return launch_attn_simple(a, dtype, st);
+}

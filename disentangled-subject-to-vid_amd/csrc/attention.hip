@@ -1,0 +1,226 @@
+// Joint [text | ref-image | video] self-attention, head_dim 64, no mask
+// (replaces F.scaled_dot_product_attention at attention_processor.py:2083-2087).
+//
+//  attn_bf16_k : flash-attention forward on v_mfma_f32_32x32x16_bf16.
+//     block = 4 waves x 32 query rows; KV tile = 64 keys; K tile [64 kv][64 d] and V^T tile [64 d][64 kv] are
+//     staged with global_load_lds into double-buffered, XOR-swizzled LDS (same image as gemm.hip).
+//     QK^T is issued swapped (S^T = K . Q^T) so every lane owns ONE query row: row max / row sum / rescale are
+//     lane-local (one cross-half exchange per tile).  P^T feeds the PV MFMA straight from the S^T accumulator
+//     registers: the MFMA k-slot <-> key assignment is free, so V^T is stored in HBM with the keys of every
+//     16-group permuted [0-3, 8-11, 4-7, 12-15] (done by qk_norm_rope) and no lane exchange is needed.
+//     O^T = V^T . P^T accumulates with the query again on the lane axis.
+//  attn_simple_k<T> : one wave per query row, fp32 math, any dtype (CPU-reference-parity mode / cross-check).
+#define S2V_HOST
+#include "common.h"
+#include "kernels.h"
+
+#define KV_TILE 64
+#define Q_BLOCK 128
+#define ATT_TILE_BYTES (64 * 64 * 2)  // 8 KiB
+
+__device__ __forceinline__ void stage64(const bf16_t* __restrict__ g, size_t ld, char* lds, int tid) {
+    // 64 rows x 128 B; 512 chunks of 16 B; 2 rounds of 256 threads
+    const int wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int gi = i * 256 + tid;
+        const int row = gi >> 3;
+        const int cp = gi & 7;
+        const int c = cp ^ ((row >> 1) & 7);
+        const bf16_t* src = g + (size_t)row * ld + c * 8;
+        char* dst = lds + (i * 256 + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
+__device__ __forceinline__ bf16x8 frag64(const char* tile, int row, int cl) {
+    return *(const bf16x8*)(tile + row * 128 + ((cl ^ ((row >> 1) & 7)) << 4));
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K tile | VT tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, hi = lane >> 5;
+
+    // XCD-aware order: all q-blocks of one (b,h) run on one XCD so its K/V stay in that XCD's L2
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    const int bh = wg / nqb, qb = wg - bh * nqb;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int D = a.H * 64;
+
+    const bf16_t* qkv = (const bf16_t*)a.qkv + (size_t)b * a.Ntok * a.ld_qkv;
+    const bf16_t* Kg = qkv + D + h * 64;
+    const bf16_t* VTg = (const bf16_t*)a.vt + (size_t)(b * a.H + h) * 64 * a.ntok_pad;
+
+    // Q fragments (B operand of S^T = K.Q^T): lane (q = fr, hi) holds Q[q][16kk + 8hi .. +8]
+    const int q_row = qb * Q_BLOCK + wave * 32 + fr;
+    const int q_ld = min(q_row, a.Ntok - 1);
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+        qf[kk] = *(const bf16x8*)(qkv + (size_t)q_ld * a.ld_qkv + h * 64 + kk * 16 + hi * 8);
+
+    f32x16 ot[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ot[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = a.scale * 1.4426950408889634f;
+
+    const int nt = (a.Ntok + KV_TILE - 1) / KV_TILE;
+    stage64(Kg, a.ld_qkv, smem, tid);
+    stage64(VTg, a.ntok_pad, smem + ATT_TILE_BYTES, tid);
+    __syncthreads();
+
+    for (int t = 0; t < nt; ++t) {
+        const int cur = t & 1;
+        const int kv0 = t * KV_TILE;
+        if (t + 1 < nt) {
+            char* nb = smem + (cur ^ 1) * 2 * ATT_TILE_BYTES;
+            stage64(Kg + (size_t)(kv0 + KV_TILE) * a.ld_qkv, a.ld_qkv, nb, tid);
+            stage64(VTg + kv0 + KV_TILE, a.ntok_pad, nb + ATT_TILE_BYTES, tid);
+        }
+        const char* tK = smem + cur * 2 * ATT_TILE_BYTES;
+        const char* tV = tK + ATT_TILE_BYTES;
+
+        // S^T[kv][q] for two 32-key blocks
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[kb][e] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                bf16x8 kf = frag64(tK, kb * 32 + fr, kk * 2 + hi);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kb], 0, 0, 0);
+            }
+        }
+        if (kv0 + KV_TILE > a.Ntok) {  // tail tile: mask keys >= Ntok
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kv = kv0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    if (kv >= a.Ntok) st[kb][e] = -INFINITY;
+                }
+        }
+        float mx = st[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[kb][e]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        const float mc = m_new * c;
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float p = __builtin_amdgcn_exp2f(st[kb][e] * c - mc);
+                st[kb][e] = p;
+                psum += p;
+            }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
+
+        // O^T[d][q] += V^T[d][kv] . P^T[kv][q]; k-step s covers keys 16s..16s+15 of the tile
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int kb = s >> 1, r0 = (s & 1) * 8;
+            bf16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (__bf16)st[kb][r0 + e];
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                bf16x8 vf = frag64(tV, db * 32 + fr, s * 2 + hi);
+                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[db], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < a.Ntok) {
+        bf16_t* o = (bf16_t*)a.out + (size_t)(b * a.Ntok + q_row) * a.ld_out + h * 64;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = db * 32 + 8 * rq + 4 * hi;
+                u32x2 p;
+                p.x = pack2bf(ot[db][rq * 4 + 0] * inv, ot[db][rq * 4 + 1] * inv);
+                p.y = pack2bf(ot[db][rq * 4 + 2] * inv, ot[db][rq * 4 + 3] * inv);
+                *(u32x2*)(o + d) = p;
+            }
+    }
+}
+
+int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
+    S2V_REQUIRE(a.vt != nullptr, "attn_bf16: V^T buffer missing");
+    S2V_REQUIRE(a.ld_qkv % 8 == 0 && a.ntok_pad % 64 == 0, "attn_bf16: bad leading dims");
+    S2V_REQUIRE(a.ntok_pad >= ((a.Ntok + 63) / 64) * 64, "attn_bf16: ntok_pad too small");
+    const int nqb = (a.Ntok + Q_BLOCK - 1) / Q_BLOCK;
+    const int grid = nqb * a.B * a.H;
+    hipLaunchKernelGGL(attn_bf16_k, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_simple_k(const AttnArgs a) {
+    __shared__ float sq[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+    const int D = a.H * 64;
+    const bool active = q < a.Ntok;
+    const T* base = (const T*)a.qkv + (size_t)b * a.Ntok * a.ld_qkv;
+    const int ql = active ? q : a.Ntok - 1;
+    sq[wave][lane] = ET<T>::ld(base + (size_t)ql * a.ld_qkv + h * 64 + lane) * a.scale;
+    __syncthreads();
+    float m = -INFINITY, l = 0.f, o = 0.f;
+    for (int kv0 = 0; kv0 < a.Ntok; kv0 += 64) {
+        const int kv = kv0 + lane;
+        float s = -INFINITY;
+        if (kv < a.Ntok) {
+            const T* kp = base + (size_t)kv * a.ld_qkv + D + h * 64;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int d = 0; d < 64; ++d) acc = fmaf(sq[wave][d], ET<T>::ld(kp + d), acc);
+            s = acc;
+        }
+        const float mx = wave_max(s);
+        const float mn = fmaxf(m, mx);
+        const float alpha = expf(m - mn);
+        const float p = expf(s - mn);
+        l = l * alpha + wave_sum(p);
+        o *= alpha;
+        m = mn;
+        const int nv = min(64, a.Ntok - kv0);
+        for (int j = 0; j < nv; ++j) {
+            const float pj = __shfl(p, j, 64);
+            o = fmaf(pj, ET<T>::ld(base + (size_t)(kv0 + j) * a.ld_qkv + 2 * D + h * 64 + lane), o);
+        }
+    }
+    if (active) ET<T>::st((T*)a.out + (size_t)(b * a.Ntok + q) * a.ld_out + h * 64 + lane, o / l);
+}
+
+int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st) {
+    dim3 grid((a.Ntok + 3) / 4, a.H, a.B);
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(attn_simple_k<bf16_t>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(attn_simple_k<float>, grid, dim3(256), 0, st, a);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}

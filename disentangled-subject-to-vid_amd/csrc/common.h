@@ -1,0 +1,75 @@
+// Shared device/host helpers for the s2v HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define S2V_WAVE 64
+
+// ---- scalar conversions -------------------------------------------------
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned int)h) << 16); }
+// round-to-nearest-even, lowers to v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+__device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
+    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+}
+
+// Element-type traits: T is the model's storage dtype (float or bf16_t).
+template <typename T> struct ET;
+template <> struct ET<float> {
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+    static __device__ __forceinline__ float rnd(float v) { return v; }
+};
+template <> struct ET<bf16_t> {
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+    // value after a round trip through the storage type (mimics the reference's per-op bf16 rounding)
+    static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+    // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3)))  -- torch F.gelu(approximate="tanh")
+    const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+    float u = k0 * (x + k1 * x * x * x);
+    return 0.5f * x * (1.0f + tanhf(u));
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
+// ---- host side ------------------------------------------------------------
+#ifdef S2V_HOST
+#include <string>
+extern thread_local std::string g_s2v_err;
+int s2v_fail(const char* file, int line, const char* msg, int code);
+#define S2V_CHECK_HIP(expr)                                                          \
+    do {                                                                             \
+        hipError_t _e = (expr);                                                      \
+        if (_e != hipSuccess) return s2v_fail(__FILE__, __LINE__, hipGetErrorString(_e), -2); \
+    } while (0)
+#define S2V_REQUIRE(cond, msg)                                                       \
+    do {                                                                             \
+        if (!(cond)) return s2v_fail(__FILE__, __LINE__, msg, -1);                   \
+    } while (0)
+#define S2V_TRY(expr)                                                                \
+    do {                                                                             \
+        int _r = (expr);                                                             \
+        if (_r != 0) return _r;                                                      \
+    } while (0)
+#endif

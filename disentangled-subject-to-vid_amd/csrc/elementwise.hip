@@ -1,0 +1,525 @@
+// HBM-bound kernels of the denoise step: AdaLN-Zero modulate, per-head QK LayerNorm + RoPE, V^T production,
+// timestep / modulation GEMVs, patchify / unpatchify, tail norms, CFG + scheduler step.
+// Every kernel is templated on the storage type T (float for the fp32 CPU-parity mode, bf16 otherwise); math is
+// fp32 and results pass through ET<T>::rnd at the points where the reference materialises a tensor in the model
+// dtype, so the bf16 path rounds where the reference's bf16 CPU run rounds.
+#define S2V_HOST
+#include "common.h"
+#include "kernels.h"
+
+// 16-byte vector of T
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void ld(const float* p, float* v) {
+        f32x4 t = *(const f32x4*)p;
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float* v) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* v) {
+        u32x4 t = *(const u32x4*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(t[i] << 16);
+            v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* v) {
+        u32x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+        *(u32x4*)p = t;
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// Row LayerNorm helpers: one wave per row, row cached in registers (D <= 4096, D % (16/sizeof(T)) == 0)
+#define LN_MAX_FLOATS 64
+template <typename T>
+__device__ __forceinline__ void row_load(const T* x, int D, int lane, float* v, int& nch) {
+    constexpr int VN = Vec16<T>::N;
+    const int chunks = D / VN;
+    nch = 0;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_FLOATS / VN; ++i) {
+        const int c = lane + 64 * i;
+        if (c < chunks) {
+            Vec16<T>::ld(x + c * VN, v + i * VN);
+            nch = i + 1;
+        } else {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[i * VN + e] = 0.f;
+        }
+    }
+}
+// normalise the register-resident row in place: v = rnd((v-mean)*rstd*w + b)
+template <typename T>
+__device__ __forceinline__ void row_layernorm(float* v, int D, int lane, const T* w, const T* b, float eps) {
+    constexpr int VN = Vec16<T>::N;
+    const int chunks = D / VN;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_FLOATS; ++i) s += v[i];
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_FLOATS / VN; ++i) {
+        const int c = lane + 64 * i;
+        if (c < chunks) {
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                const float d = v[i * VN + e] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float var = wave_sum(q) / (float)D;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAX_FLOATS / VN; ++i) {
+        const int c = lane + 64 * i;
+        if (c < chunks) {
+            float wv[VN], bv[VN];
+            Vec16<T>::ld(w + c * VN, wv);
+            Vec16<T>::ld(b + c * VN, bv);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) v[i * VN + e] = ET<T>::rnd((v[i * VN + e] - mean) * rstd * wv[e] + bv[e]);
+        }
+    }
+}
+// v = rnd(rnd(v * rnd(1+scale)) + shift), then store
+template <typename T>
+__device__ __forceinline__ void row_modulate_store(float* v, int D, int lane, const T* shift, const T* scale, T* y) {
+    constexpr int VN = Vec16<T>::N;
+    const int chunks = D / VN;
+#pragma unroll
+    for (int i = 0; i < LN_MAX_FLOATS / VN; ++i) {
+        const int c = lane + 64 * i;
+        if (c < chunks) {
+            float sc[VN], sh[VN], o[VN];
+            Vec16<T>::ld(scale + c * VN, sc);
+            Vec16<T>::ld(shift + c * VN, sh);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                const float s1 = ET<T>::rnd(1.0f + sc[e]);
+                const float p = ET<T>::rnd(v[i * VN + e] * s1);
+                o[e] = p + sh[e];
+            }
+            Vec16<T>::st(y + c * VN, o);
+        }
+    }
+}
+
+// CogVideoXLayerNormZero.forward (normalization.py:467-484): LN(x)*(1+scale)+shift, three token ranges
+template <typename T>
+__global__ __launch_bounds__(256) void ln_modulate_k(const LnModArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.B * a.Ntok) return;
+    const int b = row / a.Ntok, r = row - b * a.Ntok;
+    float v[LN_MAX_FLOATS];
+    int nch;
+    row_load<T>((const T*)a.x + (size_t)row * a.ldx, a.D, lane, v, nch);
+    row_layernorm<T>(v, a.D, lane, (const T*)a.w, (const T*)a.b, a.eps);
+    const bool txt = r < a.text_len;
+    const T* shift = (const T*)(txt ? a.shift_txt : a.shift_vid) + (size_t)b * a.mod_stride;
+    const T* scale = (const T*)(txt ? a.scale_txt : a.scale_vid) + (size_t)b * a.mod_stride;
+    row_modulate_store<T>(v, a.D, lane, shift, scale, (T*)a.y + (size_t)row * a.ldy);
+}
+int launch_ln_modulate(const LnModArgs& a, int dtype, hipStream_t st) {
+    S2V_REQUIRE(a.D <= 4096 && a.D % 8 == 0, "ln_modulate: D must be <= 4096 and a multiple of 8");
+    const int rows = a.B * a.Ntok;
+    dim3 grid((rows + 3) / 4);
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(ln_modulate_k<bf16_t>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(ln_modulate_k<float>, grid, dim3(256), 0, st, a);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// norm_final -> norm_out (AdaLayerNorm, shift first) on the video rows (cogvideox_transformer_3d.py:536-542)
+template <typename T>
+__global__ __launch_bounds__(256) void tail_norm_k(const TailNormArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (idx >= a.B * a.V) return;
+    const int b = idx / a.V, vr = idx - b * a.V;
+    const size_t xrow = (size_t)b * a.Ntok + a.row0 + vr;
+    float v[LN_MAX_FLOATS];
+    int nch;
+    row_load<T>((const T*)a.x + xrow * a.ldx, a.D, lane, v, nch);
+    row_layernorm<T>(v, a.D, lane, (const T*)a.w1, (const T*)a.b1, a.eps);
+    row_layernorm<T>(v, a.D, lane, (const T*)a.w2, (const T*)a.b2, a.eps);
+    const T* shift = (const T*)a.shift + (size_t)b * a.mod_stride;
+    const T* scale = (const T*)a.scale + (size_t)b * a.mod_stride;
+    row_modulate_store<T>(v, a.D, lane, shift, scale, (T*)a.y + (size_t)idx * a.ldy);
+}
+int launch_tail_norm(const TailNormArgs& a, int dtype, hipStream_t st) {
+    S2V_REQUIRE(a.D <= 4096 && a.D % 8 == 0, "tail_norm: D must be <= 4096 and a multiple of 8");
+    dim3 grid((a.B * a.V + 3) / 4);
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(tail_norm_k<bf16_t>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(tail_norm_k<float>, grid, dim3(256), 0, st, a);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// per-head LN(64) on q and k + RoPE (attention_processor.py:2060-2080, embeddings.py:759-778).
+// 8 lanes per 64-wide head vector (8 contiguous elements per lane); one thread-task = (row, q|k, head, octet)
+template <typename T>
+__global__ __launch_bounds__(256) void qk_norm_rope_k(const QkNormRopeArgs a) {
+    const int D = a.H * 64;
+    const size_t tasks_per_row = (size_t)2 * a.H * 8;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t row = gid / tasks_per_row;
+    if (row >= (size_t)a.B * a.Ntok) return;  // whole 8-lane groups exit together (tasks_per_row % 8 == 0)
+    const int t = (int)(gid - row * tasks_per_row);
+    const int which = t / (a.H * 8);  // 0 = q, 1 = k
+    const int hh = (t >> 3) % a.H;
+    const int oct = t & 7;
+    T* p = (T*)a.qkv + row * a.ld_qkv + which * D + hh * 64 + oct * 8;
+    float v[8];
+    if constexpr (sizeof(T) == 2) {
+        Vec16<T>::ld(p, v);
+    } else {
+        Vec16<T>::ld(p, v);
+        Vec16<T>::ld(p + 4, v + 4);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s += v[e];
+    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+    const float mean = s * (1.0f / 64.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; q += d * d; }
+    q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + a.eps);
+    const T* w = (const T*)(which ? a.nk_w : a.nq_w) + oct * 8;
+    const T* bb = (const T*)(which ? a.nk_b : a.nq_b) + oct * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ET<T>::rnd((v[e] - mean) * rstd * ET<T>::ld(w + e) + ET<T>::ld(bb + e));
+    const int r = (int)(row % a.Ntok);
+    if (a.cos != nullptr && r >= a.text_len) {
+        const float* cs = a.cos + (size_t)(r - a.text_len) * 64 + oct * 8;
+        const float* sn = a.sin + (size_t)(r - a.text_len) * 64 + oct * 8;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const float x0 = v[e], x1 = v[e + 1];
+            v[e] = ET<T>::rnd(x0 * cs[e] + (-x1) * sn[e]);
+            v[e + 1] = ET<T>::rnd(x1 * cs[e + 1] + x0 * sn[e + 1]);
+        }
+    }
+    if constexpr (sizeof(T) == 2) {
+        Vec16<T>::st(p, v);
+    } else {
+        Vec16<T>::st(p, v);
+        Vec16<T>::st(p + 4, v + 4);
+    }
+}
+
+// V [B*Ntok, .] (cols 2D + h*64 + d) -> V^T [B][H][64][ntok_pad]; inside every aligned 16-token group the
+// tokens are stored in the order [0-3, 8-11, 4-7, 12-15] (bits 2 and 3 of the token index swapped) which is the
+// k-slot order the PV MFMA of attn_bf16_k consumes.  64 tokens x 64 dims per block through LDS.
+__global__ __launch_bounds__(256) void v_transpose_k(const bf16_t* qkv, int ld_qkv, int B, int H, int Ntok, bf16_t* vt,
+                                                     int ntok_pad) {
+    __shared__ bf16_t tile[64][64 + 2];
+    const int n0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64;
+    const int tid = threadIdx.x;
+    // load: 64 rows x 128 B, 8 lanes x 16 B per row
+    for (int i = tid; i < 64 * 8; i += 256) {
+        const int rr = i >> 3, cc = (i & 7) * 8;
+        const int n = n0 + rr;
+        u32x4 val = {0, 0, 0, 0};
+        if (n < Ntok) val = *(const u32x4*)(qkv + (size_t)(b * Ntok + n) * ld_qkv + 2 * D + h * 64 + cc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            tile[rr][cc + 2 * e] = (bf16_t)(val[e] & 0xffff);
+            tile[rr][cc + 2 * e + 1] = (bf16_t)(val[e] >> 16);
+        }
+    }
+    __syncthreads();
+    bf16_t* dst = vt + (size_t)(b * H + h) * 64 * ntok_pad;
+    for (int i = tid; i < 64 * 64; i += 256) {
+        const int d = i >> 6, pos = i & 63;
+        const int tok = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);  // token stored at this position
+        if (n0 + tok < Ntok) dst[(size_t)d * ntok_pad + n0 + pos] = tile[tok][d];
+        else if (n0 + pos < ntok_pad) dst[(size_t)d * ntok_pad + n0 + pos] = 0;
+    }
+}
+
+int launch_qk_norm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t st) {
+    const size_t total = (size_t)a.B * a.Ntok * 2 * a.H * 8;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(qk_norm_rope_k<bf16_t>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(qk_norm_rope_k<float>, grid, dim3(256), 0, st, a);
+    S2V_CHECK_HIP(hipGetLastError());
+    if (a.vt != nullptr) {
+        S2V_REQUIRE(dtype == S2V_BF16, "V^T is only produced on the bf16 path");
+        S2V_TRY(launch_v_transpose(a.qkv, a.ld_qkv, a.B, a.H, a.Ntok, a.vt, a.ntok_pad, st));
+    }
+    return 0;
+}
+int launch_v_transpose(const void* qkv, int ld_qkv, int B, int H, int Ntok, void* vt, int ntok_pad, hipStream_t st) {
+    dim3 g2((Ntok + 63) / 64, H, B);
+    hipLaunchKernelGGL(v_transpose_k, g2, dim3(256), 0, st, (const bf16_t*)qkv, ld_qkv, B, H, Ntok, (bf16_t*)vt, ntok_pad);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// timestep sinusoid [cos | sin] (flip_sin_to_cos=True, shift 0), fp32 math then cast (embeddings.py:56-73)
+template <typename T>
+__global__ void timestep_sincos_k(const float* t, int B, int D, T* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * D) return;
+    const int b = i / D, j = i - b * D;
+    const int half = D / 2;
+    const int f = j < half ? j : j - half;
+    const float expo = -logf(10000.0f) * (float)f / (float)half;
+    const float arg = t[b] * expf(expo);
+    ET<T>::st(out + i, j < half ? cosf(arg) : sinf(arg));
+}
+
+// out[b][row] = rnd(sum_k f(in[b][k]) * W[row][k] + bias[row]); f = rnd(silu(.)) when PRE_SILU. One wave per row.
+template <typename T, bool PRE_SILU>
+__global__ __launch_bounds__(256) void gemv_rows_k(const T* in, int B, int K, const T* W, const T* bias, int64_t rows,
+                                                   T* out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    constexpr int VN = Vec16<T>::N;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const T* w = W + row * K;
+    for (int k = lane * VN; k < K; k += 64 * VN) {
+        float wv[VN];
+        Vec16<T>::ld(w + k, wv);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b < B) {
+                float xv[VN];
+                Vec16<T>::ld(in + (size_t)b * K + k, xv);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
+                    float x = xv[e];
+                    if (PRE_SILU) x = ET<T>::rnd(silu_f(x));
+                    acc[b] = fmaf(x, wv[e], acc[b]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        if (b < B) {
+            const float s = wave_sum(acc[b]);
+            if (lane == 0) ET<T>::st(out + (size_t)b * rows + row, s + (bias ? ET<T>::ld(bias + row) : 0.f));
+        }
+    }
+}
+template <typename T>
+static int gemv_rows(const void* in, int B, int K, const void* W, const void* bias, int64_t rows, void* out,
+                     bool pre_silu, hipStream_t st) {
+    S2V_REQUIRE(B <= 4, "gemv_rows: batch must be <= 4");
+    S2V_REQUIRE(K % Vec16<T>::N == 0, "gemv_rows: K must be a multiple of the 16-byte vector width");
+    dim3 grid((unsigned)((rows + 3) / 4));
+    if (pre_silu)
+        hipLaunchKernelGGL((gemv_rows_k<T, true>), grid, dim3(256), 0, st, (const T*)in, B, K, (const T*)W,
+                           (const T*)bias, rows, (T*)out);
+    else
+        hipLaunchKernelGGL((gemv_rows_k<T, false>), grid, dim3(256), 0, st, (const T*)in, B, K, (const T*)W,
+                           (const T*)bias, rows, (T*)out);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_time_embed(const float* t_dev, int B, int D, const void* w1, const void* b1, const void* w2, const void* b2,
+                      int temb_dim, void* tmp, void* emb_out, int dtype, hipStream_t st) {
+    // tmp holds [B, D] sinusoid followed by [B, temb] hidden
+    const int n = B * D;
+    if (dtype == S2V_BF16) {
+        bf16_t* sc = (bf16_t*)tmp;
+        bf16_t* h1 = sc + n;
+        hipLaunchKernelGGL(timestep_sincos_k<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, st, t_dev, B, D, sc);
+        S2V_CHECK_HIP(hipGetLastError());
+        S2V_TRY(gemv_rows<bf16_t>(sc, B, D, w1, b1, temb_dim, h1, false, st));
+        S2V_TRY(gemv_rows<bf16_t>(h1, B, temb_dim, w2, b2, temb_dim, emb_out, true, st));
+    } else {
+        float* sc = (float*)tmp;
+        float* h1 = sc + n;
+        hipLaunchKernelGGL(timestep_sincos_k<float>, dim3((n + 255) / 256), dim3(256), 0, st, t_dev, B, D, sc);
+        S2V_CHECK_HIP(hipGetLastError());
+        S2V_TRY(gemv_rows<float>(sc, B, D, w1, b1, temb_dim, h1, false, st));
+        S2V_TRY(gemv_rows<float>(h1, B, temb_dim, w2, b2, temb_dim, emb_out, true, st));
+    }
+    return 0;
+}
+
+int launch_mod_gemv(const void* emb, int B, int temb_dim, const void* W, const void* bias, int64_t rows_total,
+                    void* out, int dtype, hipStream_t st) {
+    return dtype == S2V_BF16 ? gemv_rows<bf16_t>(emb, B, temb_dim, W, bias, rows_total, out, true, st)
+                             : gemv_rows<float>(emb, B, temb_dim, W, bias, rows_total, out, true, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void patchify_k(const T* lat, int64_t lat_bstride, int Bn, int F, int C, int H, int W, T* out) {
+    // out[(((b*F + f)*hp + y)*wp + x)][c*4 + py*2 + px] = lat[b][f][c][2y+py][2x+px]
+    // (the im2col operand of the 2x2 stride-2 patch conv, embeddings.py:414-419)
+    const int hp = H / 2, wp = W / 2, K = C * 4;
+    const int64_t total = (int64_t)Bn * F * hp * wp * K;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % K);
+    const int64_t tok = i / K;
+    const int x = (int)(tok % wp);
+    const int y = (int)((tok / wp) % hp);
+    const int f = (int)((tok / ((int64_t)wp * hp)) % F);
+    const int64_t b = tok / ((int64_t)wp * hp * F);
+    const int c = k >> 2, py = (k >> 1) & 1, px = k & 1;
+    out[i] = lat[b * lat_bstride + (((int64_t)f * C + c) * H + 2 * y + py) * W + 2 * x + px];
+}
+int launch_patchify(const void* lat, int64_t lat_bstride, int Bn, int F, int C, int H, int W, void* out, int dtype,
+                    hipStream_t st) {
+    const int64_t total = (int64_t)Bn * F * (H / 2) * (W / 2) * C * 4;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(patchify_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)lat, lat_bstride, Bn, F, C, H, W,
+                           (bf16_t*)out);
+    else
+        hipLaunchKernelGGL(patchify_k<float>, grid, dim3(256), 0, st, (const float*)lat, lat_bstride, Bn, F, C, H, W,
+                           (float*)out);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+__global__ void unpatchify_k(const T* y, int ldy, int64_t y_bstride, T* out, int B, int F, int C, int H, int W) {
+    // out[b][f][c][yy][xx] = y[b*y_bstride + (f*hp + yy/2)*wp + xx/2][c*4 + (yy&1)*2 + (xx&1)]
+    // (cogvideox_transformer_3d.py:549-551)
+    const int hp = H / 2, wp = W / 2;
+    const int64_t total = (int64_t)B * F * C * H * W;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int xx = (int)(i % W);
+    const int yy = (int)((i / W) % H);
+    const int c = (int)((i / ((int64_t)W * H)) % C);
+    const int f = (int)((i / ((int64_t)W * H * C)) % F);
+    const int b = (int)(i / ((int64_t)W * H * C * F));
+    const int64_t row = (int64_t)b * y_bstride + ((int64_t)f * hp + yy / 2) * wp + xx / 2;
+    out[i] = y[row * ldy + c * 4 + (yy & 1) * 2 + (xx & 1)];
+}
+int launch_unpatchify(const void* y, int ldy, int64_t y_bstride, void* out, int B, int F, int C, int H, int W, int dtype,
+                      hipStream_t st) {
+    const int64_t total = (int64_t)B * F * C * H * W;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(unpatchify_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)y, ldy, y_bstride, (bf16_t*)out,
+                           B, F, C, H, W);
+    else
+        hipLaunchKernelGGL(unpatchify_k<float>, grid, dim3(256), 0, st, (const float*)y, ldy, y_bstride, (float*)out, B,
+                           F, C, H, W);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+__global__ void copy_rows_k(const T* src, int lds_, const T* add, int ldadd, T* dst, int ldd, int rows, int D) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * D) return;
+    const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
+    float v = ET<T>::ld(src + (size_t)r * lds_ + c);
+    if (add) v += ET<T>::ld(add + (size_t)r * ldadd + c);
+    ET<T>::st(dst + (size_t)r * ldd + c, v);
+}
+int launch_copy_rows(const void* src, int lds_, const void* add, int ldadd, void* dst, int ldd, int rows, int D,
+                     int dtype, hipStream_t st) {
+    const int64_t total = (int64_t)rows * D;
+    if (total == 0) return 0;
+    dim3 grid((unsigned)((total + 255) / 256));
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(copy_rows_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, lds_, (const bf16_t*)add,
+                           ldadd, (bf16_t*)dst, ldd, rows, D);
+    else
+        hipLaunchKernelGGL(copy_rows_k<float>, grid, dim3(256), 0, st, (const float*)src, lds_, (const float*)add, ldadd,
+                           (float*)dst, ldd, rows, D);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// CFG + scheduler step (custom_cogvideox_pipe.py:266-296; scheduling_ddim_cogvideox.py:364-394;
+// scheduling_dpm_cogvideox.py:391-434).  Coefficients that multiply a model-dtype tensor (c_x0_x, a_t, m1, mn)
+// arrive already rounded to the model dtype by the host: torch rounds a 0-dim fp64 scalar to the tensor dtype
+// before the multiply (pinned by tests/golden/sched_*.npz).  __f*_rn keep the reference's separate roundings
+// (no fma contraction), so the fp32 arithmetic is bit-identical to the CPU reference.
+template <typename T>
+__global__ void sched_step_k(const SchedArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const SchedCoef k = *a.coef;
+    const T* np = (const T*)a.noise_pred;
+    float v;
+    if (a.cfg) {
+        const float u = ET<T>::ld(np + i), c = ET<T>::ld(np + a.n + i);
+        v = __fadd_rn(u, __fmul_rn(k.guidance, __fsub_rn(c, u)));
+    } else {
+        v = ET<T>::ld(np + i);
+    }
+    const float x = ET<T>::ld((const T*)a.latents_in + i);
+    const float x0 = __fsub_rn(ET<T>::rnd(__fmul_rn(x, k.c_x0_x)), __fmul_rn(k.c_x0_v, v));
+    float prev;
+    if (k.kind == 0) {
+        prev = __fadd_rn(ET<T>::rnd(__fmul_rn(k.a_t, x)), __fmul_rn(k.b_t, x0));
+    } else {
+        float d = x0;
+        if (k.kind == 2) d = __fsub_rn(__fmul_rn(k.m3, x0), __fmul_rn(k.m4, a.x0_hist[i]));
+        const float nz = ET<T>::ld((const T*)a.noise + i);
+        prev = __fadd_rn(__fsub_rn(ET<T>::rnd(__fmul_rn(k.m1, x)), __fmul_rn(k.m2, d)), ET<T>::rnd(__fmul_rn(k.mn, nz)));
+    }
+    if (a.x0_hist) a.x0_hist[i] = x0;
+    ET<T>::st((T*)a.latents_out + i, prev);
+}
+int launch_sched_step(const SchedArgs& a, int dtype, hipStream_t st) {
+    dim3 grid((unsigned)((a.n + 255) / 256));
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(sched_step_k<bf16_t>, grid, dim3(256), 0, st, a);
+    else
+        hipLaunchKernelGGL(sched_step_k<float>, grid, dim3(256), 0, st, a);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ void convert2d_k(const TS* src, int64_t lds_, TD* dst, int64_t ldd, int64_t rows, int64_t cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols, c = i - r * cols;
+    ET<TD>::st(dst + r * ldd + c, ET<TS>::ld(src + r * lds_ + c));
+}
+int launch_convert2d(const void* src, int sdt, int64_t lds_, void* dst, int ddt, int64_t ldd, int64_t rows, int64_t cols,
+                     hipStream_t st) {
+    const int64_t total = rows * cols;
+    if (total == 0) return 0;
+    dim3 grid((unsigned)((total + 255) / 256));
+#define CV(TS, TD) hipLaunchKernelGGL((convert2d_k<TS, TD>), grid, dim3(256), 0, st, (const TS*)src, lds_, (TD*)dst, ldd, rows, cols)
+    if (sdt == S2V_F32 && ddt == S2V_F32) CV(float, float);
+    else if (sdt == S2V_F32 && ddt == S2V_BF16) CV(float, bf16_t);
+    else if (sdt == S2V_BF16 && ddt == S2V_F32) CV(bf16_t, float);
+    else CV(bf16_t, bf16_t);
+#undef CV
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_convert(const void* src, int sdt, void* dst, int ddt, int64_t n, hipStream_t st) {
+    return launch_convert2d(src, sdt, n, dst, ddt, n, 1, n, st);
+}

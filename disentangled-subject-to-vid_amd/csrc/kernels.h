@@ -1,0 +1,121 @@
+// Internal launcher declarations (host side). Every launcher enqueues on `st` and returns 0 / <0.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+enum { S2V_F32 = 0, S2V_BF16 = 1 };
+enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_GATE_RES = 2 };
+
+// C[m][n] = sum_k A[m][k] * W[n][k] (+ bias[n]) followed by an epilogue.
+//   EPI_BIAS          : C = rnd(acc + bias)
+//   EPI_BIAS_GELU     : C = rnd(gelu_tanh(rnd(acc + bias)))
+//   EPI_BIAS_GATE_RES : X[m][n] = rnd(X[m][n] + rnd(gate(m)[n] * rnd(acc + bias)))   (C unused)
+// gate(m): row m belongs to sample b = m / tok_per_batch; rows with (m % tok_per_batch) < text_len use
+// gate_txt[b], the others (reference-image + video tokens) gate_vid[b]
+// (reference: cogvideox_transformer_3d.py:165-167,182-184; normalization.py:484).
+struct GemmArgs {
+    const void* A; int lda;
+    const void* W; int ldw;   // W is [N_pad, K], nn.Linear layout
+    const void* bias;         // [N] or null
+    void* C; int ldc;
+    int M, N, K;
+    void* X; int ldx;
+    const void* gate_vid; const void* gate_txt; int gate_stride;
+    int tok_per_batch; int text_len;
+};
+
+int launch_gemm_bf16(const GemmArgs& a, int epi, hipStream_t st);              // MFMA path, bf16 only
+int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st);  // any dtype, any shape
+// generic strided fp32 GEMM used at load time (LoRA merge): C[m,n] += alpha * sum_k A[m*sam+k*sak]*B[n*sbn+k*sbk]
+int launch_gemm_strided_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
+                            float* C, int64_t ldc, int M, int N, int K, float alpha, hipStream_t st);
+
+// ---- attention ---------------------------------------------------------------
+// qkv: [B*Ntok (+pad), 3*D] rows = tokens; q at col h*64, k at col D+h*64, v at col 2D+h*64.
+// out: [B*Ntok, D] (col h*64+d).  softmax(q k^T / 8) v, no mask  (attention_processor.py:2083-2087)
+struct AttnArgs {
+    const void* qkv; int ld_qkv;
+    const void* vt;            // bf16 path only: V^T [B][H][64][ntok_pad] (kv-permuted inside 16-groups)
+    int ntok_pad;
+    void* out; int ld_out;
+    int B, H, Ntok;
+    float scale;               // 1/sqrt(64)
+};
+int launch_attn_bf16(const AttnArgs& a, hipStream_t st);
+int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st);
+
+// ---- elementwise / normalisation ------------------------------------------------
+// LayerNorm(eps, affine w,b) then (1+scale)*y+shift with per-row-range modulation sets.
+// rows: [B*Ntok, D]; text rows use (shift_txt, scale_txt), other rows (shift_vid, scale_vid); all [B][mod_stride].
+struct LnModArgs {
+    const void* x; int ldx; void* y; int ldy;
+    const void* w; const void* b; float eps;
+    const void* shift_vid; const void* scale_vid; const void* shift_txt; const void* scale_txt; int mod_stride;
+    int B, Ntok, text_len, D;
+};
+int launch_ln_modulate(const LnModArgs& a, int dtype, hipStream_t st);
+
+// per-head LayerNorm(64, eps 1e-6, affine) on q,k (in place in qkv) + interleaved-pair RoPE on rows >= text_len,
+// optional V^T production (bf16 path).  cos/sin: [Ntok - text_len, 64] fp32 (ref rows then video rows), null => no RoPE.
+struct QkNormRopeArgs {
+    void* qkv; int ld_qkv; int B, H, Ntok, text_len;
+    const void* nq_w; const void* nq_b; const void* nk_w; const void* nk_b; float eps;
+    const float* cos; const float* sin;
+    void* vt; int ntok_pad;   // null => skip
+};
+int launch_qk_norm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t st);
+// bf16 V [B*Ntok, ld] (cols 2D + h*64 + d) -> V^T [B][H][64][ntok_pad] in the k-slot order attn_bf16 consumes
+int launch_v_transpose(const void* qkv, int ld_qkv, int B, int H, int Ntok, void* vt, int ntok_pad, hipStream_t st);
+
+// timestep sinusoid -> Linear -> SiLU -> Linear  (embeddings.py:27-78, 864-876)
+int launch_time_embed(const float* t_dev, int B, int D, const void* w1, const void* b1, const void* w2, const void* b2,
+                      int temb_dim, void* tmp /*[B,temb]*/, void* emb_out /*[B,temb]*/, int dtype, hipStream_t st);
+// out[j][b][:] = W_j . silu(emb[b]) + bias_j for a batch of stacked linears: W [rows_total, temb], bias [rows_total]
+int launch_mod_gemv(const void* emb, int B, int temb_dim, const void* W, const void* bias, int64_t rows_total,
+                    void* out /*[B][rows_total]*/, int dtype, hipStream_t st);
+
+// latents [Bn, F, C, H, W] -> patches [Bn*F*(H/2)*(W/2), C*4] with feature order (c, py, px);
+// lat_bstride = elements between samples (0 => every sample reads the same latent: the CFG pair)
+int launch_patchify(const void* lat, int64_t lat_bstride, int Bn, int F, int C, int H, int W, void* out, int dtype,
+                    hipStream_t st);
+// y [B*V, C*4] (feature c*4+py*2+px) -> out [B, F, C, H, W]; rows of y start at y_row0 with batch stride y_bstride rows
+int launch_unpatchify(const void* y, int ldy, int64_t y_bstride, void* out, int B, int F, int C, int H, int W, int dtype,
+                      hipStream_t st);
+// dst[r][:] = rnd(src[r][:] (+ add[r][:]))
+int launch_copy_rows(const void* src, int lds_, const void* add, int ldadd, void* dst, int ldd, int rows, int D,
+                     int dtype, hipStream_t st);
+// final: y = LN2(LN1(x)) * (1+scale[b]) + shift[b]   on video rows  (cogvideox_transformer_3d.py:536-542)
+struct TailNormArgs {
+    const void* x; int ldx; void* y; int ldy;
+    const void* w1; const void* b1; const void* w2; const void* b2; float eps;
+    const void* shift; const void* scale; int mod_stride;
+    int B, Ntok, row0, V, D;
+};
+int launch_tail_norm(const TailNormArgs& a, int dtype, hipStream_t st);
+
+// CFG + scheduler step (custom_cogvideox_pipe.py:266-296; scheduling_{ddim,dpm}_cogvideox.py)
+// Per-step scalars live in DEVICE memory so one captured hipGraph serves every step.
+//   x0 = rnd(c_x0_x * x) - c_x0_v * v
+//   kind 0 (DDIM)          : out = rnd(a_t * x) + b_t * x0
+//   kind 1 (DPM first/last): out = (rnd(m1 * x) - m2 * x0) + rnd(mn * noise)
+//   kind 2 (DPM multistep) : d = m3 * x0 - m4 * x0_old ; out = (rnd(m1 * x) - m2 * d) + rnd(mn * noise)
+struct SchedCoef {
+    int kind; float guidance;
+    float c_x0_x, c_x0_v, a_t, b_t, m1, m2, m3, m4, mn;
+    float pad;
+};
+struct SchedArgs {
+    const void* noise_pred;   // [2, n] model dtype (uncond, cond) or [1, n] when !cfg
+    const void* latents_in;   // [n] model dtype
+    void* latents_out;        // [n] model dtype (may alias latents_in)
+    float* x0_hist;           // [n] fp32: read as x0_old (kind 2), overwritten with this step's x0 (may be null for DDIM)
+    const void* noise;        // [n] model dtype, DPM only
+    int64_t n; int cfg;
+    const SchedCoef* coef;    // device pointer
+};
+int launch_sched_step(const SchedArgs& a, int dtype, hipStream_t st);
+// dst[i] = (Tdst) src[i]
+int launch_convert(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t st);
+// strided 2-D convert-copy: dst[r*ldd + c] = src[r*lds + c]
+int launch_convert2d(const void* src, int src_dtype, int64_t lds_, void* dst, int dst_dtype, int64_t ldd, int64_t rows,
+                     int64_t cols, hipStream_t st);

@@ -1,0 +1,138 @@
+/*
+ * s2v_hip.h -- C ABI of libs2v_hip.so: the MI355X (gfx950) implementation of the CogVideoX denoise hot path that
+ * carpedkm/disentangled-subject-to-vid drives from src/custom_cogvideox_pipe.py.
+ *
+ * The reference has no FFI: its plug-in seams are Python protocols.  Each entry point below
+ * names the reference interface it stands behind (paths relative to the reference checkout).  The ctypes binding a
+ * maintainer adds on the reference side is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every tensor argument is a DEVICE pointer to a dense row-major array of the model dtype (S2V_F32 / S2V_BF16)
+ *     unless stated otherwise; the caller owns it and keeps it alive until the stream has passed the call;
+ *   - weights are copied (and re-packed: fused QKV, stacked AdaLN linears, padded tiles) into context-owned buffers by
+ *     s2v_load_weight, the caller may free its copy afterwards;
+ *   - every compute entry point is asynchronous on the given hipStream_t;
+ *   - return value 0 = ok, < 0 = error; s2v_last_error() returns a thread-local message; no C++ exception crosses;
+ *   - one context must not be used from two host threads at once; distinct contexts (one per GPU) are independent.
+ */
+#ifndef S2V_HIP_H
+#define S2V_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct s2v_ctx s2v_ctx;
+typedef void* s2v_stream; /* hipStream_t */
+
+enum { S2V_DTYPE_F32 = 0, S2V_DTYPE_BF16 = 1 };
+
+/* CogVideoXTransformer3DModel.__init__ hyper-parameters
+ * (diffusers/src/diffusers/models/transformers/cogvideox_transformer_3d.py:253-280) */
+typedef struct s2v_model_config {
+    int32_t num_layers;       /* 30 (2B) / 42 (5B) */
+    int32_t num_heads;        /* 30 / 48; head_dim is fixed at 64 */
+    int32_t in_channels;      /* 16 */
+    int32_t out_channels;     /* 16 */
+    int32_t patch_size;       /* 2 */
+    int32_t time_embed_dim;   /* 512 */
+    int32_t text_embed_dim;   /* 4096 */
+    int32_t use_rope;         /* use_rotary_positional_embeddings: 0 (2B) / 1 (5B) */
+    int32_t dtype;            /* S2V_DTYPE_* : storage + rounding points of the model */
+    float norm_eps;           /* 1e-5 */
+    int32_t force_simple;     /* 1 = run the bf16 model on the generic (non-MFMA) kernels; cross-check only */
+    int32_t reserved[5];
+} s2v_model_config;
+
+const char* s2v_last_error(void);
+const char* s2v_version(void);
+
+int s2v_create(const s2v_model_config* cfg, s2v_ctx** out);
+void s2v_destroy(s2v_ctx* ctx);
+
+/* Load one state-dict tensor.  `name` is the reference's own key, e.g.
+ * "transformer_blocks.3.attn1.to_q.weight", "patch_embed.proj.weight" [D,16,2,2], "norm_out.linear.bias"
+ * (key list: SURVEY.md section 8b).  src_dtype may differ from the model dtype (converted on the fly).
+ * Replaces ModelMixin.from_pretrained/.to(device,dtype) for this model (src/inference.py:191-215). */
+int s2v_load_weight(s2v_ctx* ctx, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
+                    int32_t src_dtype, s2v_stream stream);
+/* W[name] += scale * B.A   (A:[r,in] B:[out,r], fp32 device tensors; Conv2d patch_embed.proj takes A as [r,in*k*k]).
+ * The merge the reference's PEFT LoRA is equivalent to (src/inference.py:218-229, alpha/r = 0.5).
+ * Must be called after s2v_load_weight(name) and before s2v_finalize_weights. */
+int s2v_merge_lora(s2v_ctx* ctx, const char* name, const float* A, const float* B, int32_t rank, float scale,
+                   s2v_stream stream);
+/* Checks that every tensor was loaded; after this call the weights are immutable. */
+int s2v_finalize_weights(s2v_ctx* ctx, s2v_stream stream);
+/* Total bytes of context-owned weights (for the broadcast) and access to the packed arena so that ONE
+ * collective can replicate a finalized model rank0 -> all. */
+int s2v_weight_arena(s2v_ctx* ctx, void** dev_ptr, int64_t* bytes);
+
+/* Token geometry of the next calls: batch B (2 = CFG pair), text tokens T, latent frames F and latent H x W
+ * (R = (H/2)(W/2) reference-image tokens, V = F*R video tokens, sequence order [text | ref | video]).
+ * Allocates the activation workspace (no allocation happens inside the compute calls). */
+int s2v_set_geometry(s2v_ctx* ctx, int32_t B, int32_t T, int32_t F, int32_t H, int32_t W);
+
+/* RoPE tables, fp32 [R + V, 64] (reference rows first): cos/sin as produced by
+ * get_3d_rotary_pos_embed (embeddings.py:505-570) and sliced in custom_cogvideox_pipe.py:223-235. */
+int s2v_set_rope(s2v_ctx* ctx, const float* cos_dev, const float* sin_dev, s2v_stream stream);
+/* 2B only: additive 3-D sincos table for the video tokens, model dtype [V, D] (embeddings.py:380-401,440-446). */
+int s2v_set_pos_embed(s2v_ctx* ctx, const void* table_dev, s2v_stream stream);
+
+/* Step-invariant conditioning: text [B,T,text_embed_dim] -> patch_embed.text_proj; ref image latent [1,1,C,H,W] ->
+ * patch_embed.proj, duplicated over the batch (cogvideox_transformer_3d.py:494-504). */
+int s2v_set_conditioning(s2v_ctx* ctx, const void* text_dev, const void* ref_latent_dev, s2v_stream stream);
+
+/* CogVideoXTransformer3DModel.forward (cogvideox_transformer_3d.py:450-560) with eval=True.
+ * latents [B,F,C,H,W] (lat_bstride = elements between samples, 0 = all samples share one latent), timesteps fp32
+ * DEVICE [B]; out [B,F,C,H,W]. */
+int s2v_transformer_forward(s2v_ctx* ctx, const void* latents, int64_t lat_bstride, const float* timesteps_dev,
+                            void* out, s2v_stream stream);
+
+/* CogVideoXBlock.forward (cogvideox_transformer_3d.py:122-186) for layer `layer`: three residual streams in/out,
+ * hidden [B,V,D], enc0 (text) [B,T,D], enc1 (ref) [B,R,D], temb [B,time_embed_dim]. */
+int s2v_block_forward(s2v_ctx* ctx, int32_t layer, const void* hidden, const void* enc0, const void* enc1,
+                      const void* temb, void* out_hidden, void* out_enc0, void* out_enc1, s2v_stream stream);
+
+/* CogVideoXAttnProcessor2_0.__call__ (attention_processor.py:2024-2097) with layer `layer`'s attn1 weights:
+ * hidden [B,V,D] and encoder [B,T+R,D] are the already-modulated inputs; outputs have the same shapes. */
+int s2v_attn_forward(s2v_ctx* ctx, int32_t layer, const void* hidden, const void* encoder, void* out_hidden,
+                     void* out_encoder, s2v_stream stream);
+
+/* Per-step scheduler scalars, computed on the host exactly as scheduling_ddim_cogvideox.py:364-394 /
+ * scheduling_dpm_cogvideox.py:306-434 do (fp64), then cast; see s2v schedulers.py. */
+typedef struct s2v_sched_coef {
+    int32_t kind;      /* 0 DDIM, 1 DPM first/last step, 2 DPM multistep */
+    float guidance;    /* classifier-free guidance scale of this step */
+    float c_x0_x, c_x0_v, a_t, b_t, m1, m2, m3, m4, mn;
+    float pad;
+} s2v_sched_coef;
+
+/* scheduler.step (+ optional CFG combine, custom_cogvideox_pipe.py:266-296):
+ * noise_pred [2,n] (cfg=1: uncond, cond) or [n]; latents in/out [n] model dtype (may alias); x0_hist fp32 [n]
+ * (DPM: read as old x0, then overwritten; may be NULL for DDIM); noise [n] model dtype (DPM only). */
+int s2v_sched_step(s2v_ctx* ctx, const s2v_sched_coef* coef_host, const void* noise_pred, int32_t cfg,
+                   const void* latents_in, void* latents_out, float* x0_hist, const void* noise, int64_t n,
+                   s2v_stream stream);
+
+/* One iteration of the denoise loop (custom_cogvideox_pipe.py:241-296): transformer on the CFG pair sharing
+ * `latents` [1,F,C,H,W], fp32 CFG, scheduler step, round to the model dtype; latents updated IN PLACE.
+ * use_graph != 0 captures the launch sequence into a hipGraph on first use and replays it afterwards
+ * (timestep and coefficients live in device memory, so one graph serves all steps). */
+int s2v_denoise_step(s2v_ctx* ctx, void* latents, float timestep, const s2v_sched_coef* coef_host, float* x0_hist,
+                     const void* noise, int32_t use_graph, s2v_stream stream);
+/* pointer to the [B,F,C,H,W] model output of the last s2v_denoise_step (context-owned, model dtype) */
+int s2v_last_noise_pred(s2v_ctx* ctx, void** dev_ptr);
+
+/* ---- operator-level entry points (used by the parity tests and micro-benchmarks) ------------------------- */
+/* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic */
+int s2v_op_linear(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
+                  int32_t epilogue, int32_t dtype, int32_t impl, s2v_stream stream);
+/* qkv [B*Ntok (+64 rows of slack), 3*H*64] -> out [B*Ntok, H*64]; impl 0 = MFMA flash kernel (needs vt scratch
+ * [B*H*64*ceil64(Ntok)] bf16, zero-filled by the caller), 1 = generic */
+int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype,
+                     int32_t impl, s2v_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

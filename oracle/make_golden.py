@@ -1,0 +1,299 @@
+"""Generates tests/golden/*.npz by IMPORTING the reference (read-only, by path) in the build container.
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+Never runs on the GPU box (the reference does not exist there); only its outputs -- inputs and expected outputs,
+weights of the tiny seeded modules included -- are committed.  Nothing from the reference is copied.
+"""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import torch
+
+REF = os.environ.get("S2V_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+
+
+def import_reference():
+    stub = tempfile.mkdtemp()
+    open(os.path.join(stub, "imageio.py"), "w").close()  # the fork imports imageio at module top (export_utils.py:11)
+    sys.path[:0] = [stub, os.path.join(REF, "diffusers", "src"), os.path.join(REF, "src")]
+    import transformers.utils as tu
+
+    tu.FLAX_WEIGHTS_NAME = getattr(tu, "FLAX_WEIGHTS_NAME", "flax_model.msgpack")
+    import diffusers  # noqa: F401
+
+
+def npsd(sd, prefix="w:"):
+    return {prefix + k: v.detach().float().numpy() for k, v in sd.items()}
+
+
+def randomize(module, gen, std=0.15):
+    """larger-variance weights, non-zero biases and LN affines so every term contributes."""
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if p.ndim >= 2:
+                p.copy_(torch.randn(p.shape, generator=gen) * (std if "linear" not in n else 0.05))
+            elif "norm" in n and n.endswith("weight"):
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+            else:
+                p.copy_(0.1 * torch.randn(p.shape, generator=gen))
+
+
+def bf16_np(t):
+    """bf16 tensor -> uint16 bit pattern (numpy has no bf16)."""
+    return t.detach().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+def gen_tables():
+    from diffusers.models.embeddings import get_3d_rotary_pos_embed, get_3d_sincos_pos_embed, get_timestep_embedding
+    from diffusers.pipelines.cogvideo.pipeline_cogvideox import get_resize_crop_region_for_grid
+    from diffusers import CogVideoXDDIMScheduler
+
+    out = {}
+    t = torch.tensor([999.0, 979.0, 500.0, 19.0, 0.0])
+    out["ts_t"] = t.numpy()
+    for dim in (128, 1920, 3072):
+        out[f"ts_{dim}"] = get_timestep_embedding(t, dim, flip_sin_to_cos=True, downscale_freq_shift=0).numpy()
+    for (h, w, frames) in ((256, 256, 3), (480, 720, 13), (720, 1280, 13)):
+        gh, gw = h // 16, w // 16
+        crops = get_resize_crop_region_for_grid((gh, gw), 720 // 16, 480 // 16)
+        cos, sin = get_3d_rotary_pos_embed(64, crops, (gh, gw), frames + 1)
+        out[f"rope_crops_{h}x{w}"] = np.array(crops, dtype=np.int64)
+        if cos.shape[0] <= 4096:
+            out[f"rope_cos_{h}x{w}"] = cos.numpy()
+            out[f"rope_sin_{h}x{w}"] = sin.numpy()
+        else:  # keep the fixture small: every 61st row + fp64 checksums of the whole table
+            out[f"rope_cos_{h}x{w}_rows61"] = cos[::61].numpy()
+            out[f"rope_sin_{h}x{w}_rows61"] = sin[::61].numpy()
+            out[f"rope_sum_{h}x{w}"] = np.array([cos.double().sum().item(), sin.double().sum().item(),
+                                                  (cos.double() * torch.arange(cos.shape[0])[:, None]).sum().item(),
+                                                  (sin.double() * torch.arange(sin.shape[0])[:, None]).sum().item()])
+    for (D, wp, hp, fr) in ((128, 4, 4, 2), (1920, 16, 16, 3), (192, 6, 4, 3)):
+        pe = get_3d_sincos_pos_embed(D, (wp, hp), fr, 1.875, 1.0)
+        pe = torch.from_numpy(pe).flatten(0, 1).float()
+        if D == 1920:
+            out[f"sincos_{D}_{wp}x{hp}x{fr}_rows7"] = pe[::7].numpy()
+            out[f"sincos_sum_{D}_{wp}x{hp}x{fr}"] = np.array([pe.double().sum().item(), pe.double().abs().sum().item()])
+        else:
+            out[f"sincos_{D}_{wp}x{hp}x{fr}"] = pe.numpy()
+    for snr in (1.0, 3.0):
+        s = CogVideoXDDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                                   set_alpha_to_one=True, prediction_type="v_prediction", timestep_spacing="trailing",
+                                   rescale_betas_zero_snr=True, snr_shift_scale=snr)
+        out[f"alphas_{snr}"] = s.alphas_cumprod.numpy()
+        for n in (10, 50, 3):
+            s.set_timesteps(n)
+            out[f"timesteps_{n}"] = s.timesteps.numpy()
+    np.savez_compressed(os.path.join(OUT, "tables.npz"), **out)
+
+
+def sched_kwargs(snr):
+    return dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False,
+                set_alpha_to_one=True, prediction_type="v_prediction", timestep_spacing="trailing",
+                rescale_betas_zero_snr=True, snr_shift_scale=snr)
+
+
+def gen_sched():
+    from diffusers import CogVideoXDDIMScheduler, CogVideoXDPMScheduler
+
+    gen = torch.Generator().manual_seed(7)
+    shape = (1, 3, 16, 6, 10)
+    for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        for kind, cls in (("ddim", CogVideoXDDIMScheduler), ("dpm", CogVideoXDPMScheduler)):
+            for n_steps, snr in ((10, 3.0), (50, 1.0)):
+                s = cls(**sched_kwargs(snr))
+                s.set_timesteps(n_steps)
+                ts = s.timesteps
+                out = {"timesteps": ts.numpy(), "snr": np.array(snr), "n_steps": np.array(n_steps)}
+                latents = torch.randn(shape, generator=gen).to(dt)
+                out["latents0"] = latents.float().numpy()
+                old = None
+                steps = list(range(len(ts))) if n_steps == 10 else [0, 1, 2, 25, 48, 49]
+                out["step_ids"] = np.array(steps)
+                for i in range(len(ts)):
+                    t = ts[i]
+                    noise_pred = torch.randn((2,) + shape[1:], generator=gen).to(dt)  # transformer output, model dtype
+                    npf = noise_pred.float()
+                    u, c = npf.chunk(2)
+                    g = 6.0
+                    v = u + g * (c - u)
+                    lat_in = latents
+                    if kind == "ddim":
+                        latents, x0 = s.step(v, t, latents, return_dict=False)
+                        n1 = n2 = None
+                    else:
+                        # capture the randn draws of randn_tensor (scheduling_dpm_cogvideox.py:423,431)
+                        g2 = torch.Generator().manual_seed(1000 + i)
+                        st = g2.get_state()
+                        latents, x0 = s.step(v, old, t, ts[i - 1] if i > 0 else None, latents, generator=g2,
+                                             return_dict=False)
+                        g3 = torch.Generator()
+                        g3.set_state(st)
+                        n1 = torch.randn(shape, generator=g3, dtype=dt)
+                        n2 = torch.randn(shape, generator=g3, dtype=dt)
+                        old = x0
+                    latents = latents.to(dt)
+                    if i in steps:
+                        out[f"noise_pred_{i}"] = noise_pred.float().numpy()
+                        out[f"lat_in_{i}"] = lat_in.float().numpy()
+                        out[f"lat_out_{i}"] = latents.float().numpy()
+                        out[f"x0_{i}"] = x0.float().numpy()
+                        if n1 is not None:
+                            out[f"n1_{i}"] = n1.float().numpy()
+                            out[f"n2_{i}"] = n2.float().numpy()
+                np.savez_compressed(os.path.join(OUT, f"sched_{kind}_{dt_name}_{n_steps}.npz"), **out)
+
+
+TINY = dict(num_attention_heads=2, attention_head_dim=64, in_channels=16, out_channels=16, time_embed_dim=64,
+            text_embed_dim=64, num_layers=2, sample_width=8, sample_height=8, sample_frames=5, max_text_seq_length=5)
+
+
+def gen_transformer():
+    from diffusers import CogVideoXTransformer3DModel
+    from diffusers.models.embeddings import get_3d_rotary_pos_embed
+
+    gen = torch.Generator().manual_seed(11)
+    B, Fr, C, H, W, T = 2, 2, 16, 8, 8, 5
+    lat = torch.randn(B, Fr, C, H, W, generator=gen)
+    ref = torch.randn(1, 1, C, H, W, generator=gen) * 0.7
+    text = torch.randn(B, T, 64, generator=gen)
+    tstep = torch.tensor([979, 979])
+    n = (H // 2) * (W // 2)
+    cos, sin = get_3d_rotary_pos_embed(64, ((0, 0), (H // 2, W // 2)), (H // 2, W // 2), Fr + 1)
+    ref_rope = (cos[:n], sin[:n])
+    vid_rope = (cos[n:], sin[n:])
+    weights = None
+    for variant, use_rope in (("rope", True), ("sincos", False)):
+        m = CogVideoXTransformer3DModel(use_rotary_positional_embeddings=use_rope, **TINY).float().eval()
+        if weights is None:
+            randomize(m, torch.Generator().manual_seed(5))
+            weights = {k: v.clone() for k, v in m.state_dict().items() if "pos_embedding" not in k}
+        else:
+            m.load_state_dict(weights, strict=False)
+        out = {"lat": lat.numpy(), "ref": ref.numpy(), "text": text.numpy(), "timestep": tstep.numpy()}
+        if variant == "rope":
+            out.update(npsd(weights))
+            out.update(rope_cos=cos.numpy(), rope_sin=sin.numpy())
+        for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            mm = m.to(dt)
+            kw = dict(image_rotary_emb=tuple(x for x in vid_rope), ref_image_rotary_emb=tuple(x for x in ref_rope)) \
+                if use_rope else dict(image_rotary_emb=None, ref_image_rotary_emb=None)
+            with torch.no_grad():
+                y = mm(hidden_states=lat.to(dt), encoder_hidden_states=text.to(dt), ref_img_states=ref.to(dt),
+                       timestep=tstep, return_dict=False, eval=True, **kw)[0]
+                out[f"out_{dt_name}"] = y.float().numpy()
+                if use_rope:
+                    # block- and processor-level seams (same weights): CogVideoXBlock.forward / AttnProcessor.__call__
+                    D = 128
+                    g2 = torch.Generator().manual_seed(21)
+                    h = torch.randn(B, Fr * n, D, generator=g2).to(dt)
+                    e0 = torch.randn(B, T, D, generator=g2).to(dt)
+                    e1 = torch.randn(B, n, D, generator=g2).to(dt)
+                    temb = torch.randn(B, 64, generator=g2).to(dt)
+                    blk = mm.transformer_blocks[1]
+                    oh, oe0, oe1 = blk(hidden_states=h, encoder_hidden_states=e0, temb=temb, enc_hidden_states1=e1,
+                                       image_rotary_emb=vid_rope, embed_ref_img=True, ref_img_seq_start=T,
+                                       ref_img_seq_end=T + n, position_delta=0, ref_image_rotary_emb=ref_rope)
+                    ah, ae = blk.attn1(hidden_states=h, encoder_hidden_states=torch.cat([e0, e1], dim=1),
+                                       image_rotary_emb=vid_rope, embed_ref_img=True, ref_img_seq_start=T,
+                                       ref_img_seq_end=T + n, position_delta=0, ref_image_rotary_emb=ref_rope)
+                    if dt_name == "f32":
+                        out.update(blk_h=h.float().numpy(), blk_e0=e0.float().numpy(), blk_e1=e1.float().numpy(),
+                                   blk_temb=temb.float().numpy())
+                    out[f"blk_out_h_{dt_name}"] = oh.float().numpy()
+                    out[f"blk_out_e0_{dt_name}"] = oe0.float().numpy()
+                    out[f"blk_out_e1_{dt_name}"] = oe1.float().numpy()
+                    out[f"attn_out_h_{dt_name}"] = ah.float().numpy()
+                    out[f"attn_out_e_{dt_name}"] = ae.float().numpy()
+            m = mm.float()
+            m.load_state_dict(weights, strict=False)
+        np.savez_compressed(os.path.join(OUT, f"transformer_tiny_{variant}.npz"), **out)
+
+
+VAE_TINY = dict(block_out_channels=(16, 16, 32, 32), layers_per_block=1, norm_num_groups=4, latent_channels=16,
+                sample_height=96, sample_width=160, scaling_factor=0.7, temporal_compression_ratio=4)
+
+
+def gen_vae():
+    from diffusers import AutoencoderKLCogVideoX
+
+    vae = AutoencoderKLCogVideoX(**VAE_TINY).float().eval()
+    randomize(vae.decoder, torch.Generator().manual_seed(3), std=0.08)
+    sd = {k: v for k, v in vae.state_dict().items() if k.startswith("decoder.")}
+    gen = torch.Generator().manual_seed(4)
+    lat = torch.randn(1, 5, 16, 12, 20, generator=gen)  # pipeline layout [B,F,C,H,W]
+    out = npsd(sd)
+    out["latents"] = lat.numpy()
+    z = lat.permute(0, 2, 1, 3, 4) / vae.config.scaling_factor
+    with torch.no_grad():
+        # full outputs would be 3 MB each: keep every 3rd pixel + fp64 per-frame checksums
+        for name, tiling in (("dec_untiled", False), ("dec_tiled", True)):
+            (vae.enable_tiling if tiling else vae.disable_tiling)()
+            y = vae.decode(z).sample
+            out[name + "_s3"] = y[..., ::3, ::3].numpy()
+            out[name + "_sum"] = y.double().sum(dim=(0, 1, 3, 4)).numpy()
+            out[name + "_sq"] = (y.double() ** 2).sum(dim=(0, 1, 3, 4)).numpy()
+        vae.disable_tiling()
+        # a 2-frame latent (even branch everywhere) and a single-frame latent
+        out["dec_2f"] = vae.decode(z[:, :, :2, :6, :8]).sample.numpy()
+        out["dec_1f"] = vae.decode(z[:, :, :1, :6, :8]).sample.numpy()
+    from diffusers.video_processor import VideoProcessor
+
+    vp = VideoProcessor(vae_scale_factor=8)
+    out["post_np"] = vp.postprocess_video(torch.from_numpy(out["dec_2f"]), output_type="np")
+    np.savez_compressed(os.path.join(OUT, "vae_tiny.npz"), **out)
+
+
+def gen_pipeline():
+    """Full CustomCogVideoXPipeline.__call__ (src/custom_cogvideox_pipe.py:125-326) with tiny modules, 480x720
+    (the only geometry the shipped harness supports: 1350 tokens per frame), 3 steps, DDIM and DPM."""
+    from diffusers import AutoencoderKLCogVideoX, CogVideoXDDIMScheduler, CogVideoXDPMScheduler, CogVideoXTransformer3DModel
+    from custom_cogvideox_pipe import CustomCogVideoXPipeline
+
+    cfg = dict(TINY)
+    cfg.update(sample_width=90, sample_height=60, sample_frames=5, max_text_seq_length=6)
+    tr = CogVideoXTransformer3DModel(use_rotary_positional_embeddings=True, **cfg).float().eval()
+    randomize(tr, torch.Generator().manual_seed(9), std=0.1)
+    vae = AutoencoderKLCogVideoX(block_out_channels=(8, 8, 8, 8), layers_per_block=1, norm_num_groups=2,
+                                 latent_channels=16, scaling_factor=0.7).float().eval()
+    gen = torch.Generator().manual_seed(13)
+    pe = torch.randn(1, 6, 64, generator=gen)
+    ne = torch.randn(1, 6, 64, generator=gen)
+    ref = torch.randn(1, 1, 16, 60, 90, generator=gen) * 0.7
+    lat0 = torch.randn(1, 2, 16, 60, 90, generator=gen)
+    weights = {k: v for k, v in tr.state_dict().items() if "pos_embedding" not in k}
+    out = npsd(weights)
+    out.update(prompt_embeds=pe.numpy(), negative_prompt_embeds=ne.numpy(), ref=ref.numpy(), latents0=lat0.numpy())
+    for kind, cls in (("ddim", CogVideoXDDIMScheduler), ("dpm", CogVideoXDPMScheduler)):
+        sched = cls(**sched_kwargs(1.0))
+        pipe = CustomCogVideoXPipeline(tokenizer=None, text_encoder=None, transformer=tr, vae=vae, scheduler=sched,
+                                       customization=True)
+        g = torch.Generator().manual_seed(77)
+        st = g.get_state()
+        res = pipe(prompt=None, prompt_embeds=pe, negative_prompt_embeds=ne, ref_img_states=ref, height=480, width=720,
+                   num_frames=5, num_inference_steps=3, guidance_scale=6.0, latents=lat0.clone(), generator=g,
+                   output_type="latent", return_dict=False)[0]
+        out[f"final_{kind}"] = res.float().numpy()
+        if kind == "dpm":  # the randn draws the DPM steps consumed, in order (2 per step after step 0, 1 on step 0... )
+            g3 = torch.Generator()
+            g3.set_state(st)
+            # the tests regenerate the draws from torch.Generator().manual_seed(77); pin them by checksum
+            nz = torch.stack([torch.randn(lat0.shape, generator=g3) for _ in range(6)])
+            out["dpm_noise_seed"] = np.array(77)
+            out["dpm_noise_sums"] = nz.double().sum(dim=(1, 2, 3, 4, 5)).numpy()
+    np.savez_compressed(os.path.join(OUT, "pipeline_tiny.npz"), **out)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    import_reference()
+    torch.manual_seed(0)
+    which = sys.argv[1:] or ["tables", "sched", "transformer", "vae", "pipeline"]
+    for w in which:
+        print("generating", w, flush=True)
+        globals()["gen_" + w]()
+    print("done")

@@ -1,0 +1,222 @@
+"""Pins the CPU oracle (oracle/*.py) against golden vectors captured from the imported reference
+(oracle/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, weights_of
+from oracle import sched_ref, transformer_ref as tr, vae_ref
+
+TINY_CFG = dict(num_heads=2, num_layers=2, norm_eps=1e-5)
+
+
+def t(x, dt=torch.float32):
+    return torch.from_numpy(np.asarray(x)).to(dt)
+
+
+# ---------------------------------------------------------------------------------------------------- tables
+def test_timestep_sinusoid():
+    g = load_golden("tables.npz")
+    for dim in (128, 1920, 3072):
+        got = tr.timestep_sinusoid(t(g["ts_t"]), dim).numpy()
+        np.testing.assert_array_equal(got, g[f"ts_{dim}"])
+
+
+@pytest.mark.parametrize("h,w,frames", [(256, 256, 3), (480, 720, 13), (720, 1280, 13)])
+def test_rope_tables(h, w, frames):
+    g = load_golden("tables.npz")
+    gh, gw = h // 16, w // 16
+    crops = tr.resize_crop_region((gh, gw), 45, 30)
+    np.testing.assert_array_equal(np.array(crops), g[f"rope_crops_{h}x{w}"])
+    cos, sin = tr.rope_3d(64, crops, (gh, gw), frames + 1)
+    if f"rope_cos_{h}x{w}" in g:
+        np.testing.assert_array_equal(cos.numpy(), g[f"rope_cos_{h}x{w}"])
+        np.testing.assert_array_equal(sin.numpy(), g[f"rope_sin_{h}x{w}"])
+    else:
+        np.testing.assert_array_equal(cos[::61].numpy(), g[f"rope_cos_{h}x{w}_rows61"])
+        np.testing.assert_array_equal(sin[::61].numpy(), g[f"rope_sin_{h}x{w}_rows61"])
+        idx = torch.arange(cos.shape[0])[:, None]
+        sums = [cos.double().sum().item(), sin.double().sum().item(), (cos.double() * idx).sum().item(),
+                (sin.double() * idx).sum().item()]
+        np.testing.assert_allclose(sums, g[f"rope_sum_{h}x{w}"], rtol=1e-12)
+    # the pipeline-level slicing: ref = temporal index 0, video = 1..F
+    (rc, rs), (vc, vs) = tr.pipeline_rope(h, w, frames)
+    n = gh * gw
+    assert rc.shape == (n, 64) and vc.shape == (n * frames, 64)
+    assert torch.equal(rc, cos[:n]) and torch.equal(vs, sin[n:])
+
+
+@pytest.mark.parametrize("D,wp,hp,fr", [(128, 4, 4, 2), (192, 6, 4, 3), (1920, 16, 16, 3)])
+def test_sincos_table(D, wp, hp, fr):
+    g = load_golden("tables.npz")
+    pe = tr.sincos_3d(D, wp, hp, fr)
+    if D == 1920:
+        np.testing.assert_array_equal(pe[::7].numpy(), g[f"sincos_{D}_{wp}x{hp}x{fr}_rows7"])
+        np.testing.assert_allclose([pe.double().sum().item(), pe.double().abs().sum().item()],
+                                   g[f"sincos_sum_{D}_{wp}x{hp}x{fr}"], rtol=1e-12)
+    else:
+        np.testing.assert_array_equal(pe.numpy(), g[f"sincos_{D}_{wp}x{hp}x{fr}"])
+
+
+def test_alphas_and_timesteps():
+    g = load_golden("tables.npz")
+    for snr in (1.0, 3.0):
+        ac = sched_ref.alphas_cumprod(snr)
+        np.testing.assert_array_equal(ac.numpy(), g[f"alphas_{snr}"])
+        assert ac[999].item() == 0.0
+    for n in (3, 10, 50):
+        np.testing.assert_array_equal(sched_ref.trailing_timesteps(n), g[f"timesteps_{n}"])
+
+
+# ---------------------------------------------------------------------------------------------------- schedulers
+@pytest.mark.parametrize("kind", ["ddim", "dpm"])
+@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+@pytest.mark.parametrize("n_steps", [10, 50])
+def test_scheduler_steps_bit_exact(kind, dt_name, n_steps):
+    g = load_golden(f"sched_{kind}_{dt_name}_{n_steps}.npz")
+    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    ac = sched_ref.alphas_cumprod(float(g["snr"]))
+    ts = g["timesteps"]
+    ids = list(g["step_ids"])
+    for i in ids:
+        npred = t(g[f"noise_pred_{i}"], dt)
+        v = sched_ref.cfg_combine(npred, 6.0)
+        lat = t(g[f"lat_in_{i}"], dt)
+        if kind == "ddim":
+            prev, x0 = sched_ref.ddim_step(ac, n_steps, v, int(ts[i]), lat)
+        else:
+            old = t(g[f"x0_{i-1}"]) if (i > 0 and (i - 1) in ids) else None
+            if i > 0 and old is None:
+                continue  # multistep needs the previous x0, only captured for consecutive ids
+            prev, x0 = sched_ref.dpm_step(ac, n_steps, v, old, int(ts[i]), int(ts[i - 1]) if i > 0 else None, lat,
+                                          t(g[f"n1_{i}"], dt), t(g[f"n2_{i}"], dt))
+        np.testing.assert_array_equal(x0.float().numpy(), g[f"x0_{i}"])
+        np.testing.assert_array_equal(prev.to(dt).float().numpy(), g[f"lat_out_{i}"])
+
+
+# ---------------------------------------------------------------------------------------------------- transformer
+def _tiny_inputs(g, dt):
+    return t(g["lat"], dt), t(g["text"], dt), t(g["ref"], dt), t(g["timestep"], torch.int64)
+
+
+@pytest.mark.parametrize("variant", ["rope", "sincos"])
+@pytest.mark.parametrize("dt_name,tol", [("f32", 2e-5), ("bf16", 0.0)])
+def test_transformer_tiny(variant, dt_name, tol):
+    gw = load_golden("transformer_tiny_rope.npz")
+    g = load_golden(f"transformer_tiny_{variant}.npz")
+    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    sd = weights_of(gw, dt)
+    lat, text, ref, ts = _tiny_inputs(g, dt)
+    cfg = dict(TINY_CFG, use_rope=variant == "rope")
+    rope = ref_rope = None
+    if variant == "rope":
+        cos, sin = t(gw["rope_cos"]), t(gw["rope_sin"])
+        n = 16
+        ref_rope, rope = (cos[:n], sin[:n]), (cos[n:], sin[n:])
+    with torch.no_grad():
+        y = tr.transformer_forward(sd, cfg, lat, text, ref, ts, rope, ref_rope)
+    exp = g[f"out_{dt_name}"]
+    if dt_name == "bf16":
+        # same torch ops, same rounding points: the restatement must reproduce the reference's bf16 run closely;
+        # op fusion order inside torch kernels is identical, so allow only a couple of bf16 ulps
+        err = np.abs(y.float().numpy() - exp).max()
+        assert err <= 0.05 * np.abs(exp).max(), err
+    else:
+        np.testing.assert_allclose(y.numpy(), exp, atol=tol * max(1.0, np.abs(exp).max()), rtol=0)
+
+
+@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+def test_block_and_attention_seams(dt_name):
+    g = load_golden("transformer_tiny_rope.npz")
+    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    sd = weights_of(g, dt)
+    cos, sin = t(g["rope_cos"]), t(g["rope_sin"])
+    n, T = 16, 5
+    ref_rope, rope = (cos[:n], sin[:n]), (cos[n:], sin[n:])
+    h, e0, e1, temb = (t(g[k], dt) for k in ("blk_h", "blk_e0", "blk_e1", "blk_temb"))
+    with torch.no_grad():
+        oh, oe0, oe1 = tr.block_forward(sd, "transformer_blocks.1.", 2, h, e0, e1, temb, rope, ref_rope)
+        ah, ae = tr.attn_forward(sd, "transformer_blocks.1.attn1.", 2, h, torch.cat([e0, e1], 1), rope, ref_rope, T, T + n)
+    tol = 2e-5 if dt_name == "f32" else 0.03
+    for got, key in ((oh, "blk_out_h"), (oe0, "blk_out_e0"), (oe1, "blk_out_e1"), (ah, "attn_out_h"), (ae, "attn_out_e")):
+        exp = g[f"{key}_{dt_name}"]
+        assert np.abs(got.float().numpy() - exp).max() <= tol * max(1.0, np.abs(exp).max()), key
+
+
+def test_lora_merge_matches_runtime_adapter():
+    """W' = W + 0.5 B A must equal running the adapter beside the base layer (what PEFT does at runtime)."""
+    gen = torch.Generator().manual_seed(0)
+    W, b = torch.randn(24, 16, generator=gen), torch.randn(24, generator=gen)
+    A, B = torch.randn(4, 16, generator=gen), torch.randn(24, 4, generator=gen)
+    x = torch.randn(7, 16, generator=gen)
+    merged = tr.merge_lora({"w": W}, {"w": (A, B)}, 0.5)["w"]
+    ref = torch.nn.functional.linear(x, W, b) + 0.5 * (x @ A.T) @ B.T
+    np.testing.assert_allclose(torch.nn.functional.linear(x, merged, b).numpy(), ref.numpy(), atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------- pipeline
+@pytest.mark.parametrize("kind", ["ddim", "dpm"])
+def test_pipeline_three_steps(kind):
+    """The oracle denoise loop vs CustomCogVideoXPipeline.__call__ (3 steps, tiny modules, 480x720, fp32)."""
+    g = load_golden("pipeline_tiny.npz")
+    sd = weights_of(g)
+    cfg = dict(TINY_CFG, use_rope=True)
+    pe, ne, ref, lat = t(g["prompt_embeds"]), t(g["negative_prompt_embeds"]), t(g["ref"]), t(g["latents0"])
+    text = torch.cat([ne, pe], dim=0)
+    ref_rope, rope = tr.pipeline_rope(480, 720, lat.shape[1])
+    ac = sched_ref.alphas_cumprod(1.0)
+    ts = sched_ref.trailing_timesteps(3)
+    gen = torch.Generator().manual_seed(int(g["dpm_noise_seed"]))
+    old = None
+    with torch.no_grad():
+        for i, tt in enumerate(ts):
+            x = torch.cat([lat] * 2)
+            npred = tr.transformer_forward(sd, cfg, x, text, ref, torch.tensor([tt, tt]), rope, ref_rope)
+            v = sched_ref.cfg_combine(npred, 6.0)
+            if kind == "ddim":
+                lat, _ = sched_ref.ddim_step(ac, 3, v, int(tt), lat)
+            else:
+                n1 = torch.randn(lat.shape, generator=gen)
+                prev_t = int(tt) - 1000 // 3
+                n2 = torch.randn(lat.shape, generator=gen) if (old is not None and prev_t >= 0) else None
+                lat, old = sched_ref.dpm_step(ac, 3, v, old, int(tt), int(ts[i - 1]) if i > 0 else None, lat, n1, n2)
+            lat = lat.float()
+    exp = g[f"final_{kind}"]
+    np.testing.assert_allclose(lat.numpy(), exp, atol=5e-5 * max(1.0, np.abs(exp).max()), rtol=0)
+
+
+# ---------------------------------------------------------------------------------------------------- VAE
+VAE_CFG = dict(block_out_channels=(16, 16, 32, 32), layers_per_block=1, norm_num_groups=4, latent_channels=16,
+               sample_height=96, sample_width=160, scaling_factor=0.7, temporal_compression_ratio=4)
+
+
+def test_vae_tile_geometry_of_the_real_config():
+    tg = vae_ref.tile_geometry(dict(block_out_channels=(128, 256, 256, 512), sample_height=480, sample_width=720))
+    assert tg == dict(tl_h=30, tl_w=45, ov_h=25, ov_w=36, bl_h=40, bl_w=72, lim_h=200, lim_w=288)
+    assert vae_ref.frame_batches(13) == [(0, 3), (3, 5), (5, 7), (7, 9), (9, 11), (11, 13)]
+
+
+@pytest.mark.parametrize("tiling", [False, True])
+def test_vae_decode(tiling):
+    g = load_golden("vae_tiny.npz")
+    sd = weights_of(g)
+    lat = t(g["latents"])
+    with torch.no_grad():
+        y = vae_ref.decode_latents(sd, VAE_CFG, lat, tiling)
+    name = "dec_tiled" if tiling else "dec_untiled"
+    assert tuple(y.shape) == (1, 3, 17, 96, 160)
+    np.testing.assert_allclose(y[..., ::3, ::3].numpy(), g[name + "_s3"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(y.double().sum(dim=(0, 1, 3, 4)).numpy(), g[name + "_sum"], rtol=1e-5, atol=1e-2)
+    np.testing.assert_allclose((y.double() ** 2).sum(dim=(0, 1, 3, 4)).numpy(), g[name + "_sq"], rtol=1e-5)
+
+
+def test_vae_decode_even_and_single_frame_branches_and_postprocess():
+    g = load_golden("vae_tiny.npz")
+    sd = weights_of(g)
+    lat = t(g["latents"])
+    with torch.no_grad():
+        y2 = vae_ref.decode_latents(sd, VAE_CFG, lat[:, :2, :, :6, :8], False)
+        y1 = vae_ref.decode_latents(sd, VAE_CFG, lat[:, :1, :, :6, :8], False)
+    np.testing.assert_allclose(y2.numpy(), g["dec_2f"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(y1.numpy(), g["dec_1f"], atol=2e-5, rtol=1e-4)
+    np.testing.assert_allclose(vae_ref.postprocess_np(t(g["dec_2f"])), g["post_np"], atol=1e-6)
