@@ -1,0 +1,217 @@
+"""Benchmark of the denoise hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one iteration of the denoise loop of src/custom_cogvideox_pipe.py:241-296 on one video: the B=2 (CFG pair)
+transformer forward + fp32 CFG + DDIM scheduler step + round to bf16, all inside libs2v_hip.so, inputs resident in
+HBM.  Workload (BASELINE.json metric): CogVideoX-5B, 49 frames 480x720 -> latents 13x60x90, N = 226+1350+17550 tokens,
+bf16, synthetic seeded weights (no checkpoints offline).  N > 1: independent replicas, one prompt per GPU, weights
+broadcast once rank0 -> all over RCCL before the timed region; value = total steps/s.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+CLASSES = ["gemm_qkv", "attention", "gemm_out", "gemm_ff1_gelu", "gemm_ff2", "ln_modulate", "qknorm_rope_vt"]
+
+WORKLOADS = {
+    # name: (preset, latent F, H, W, text tokens)
+    "cogvideox-5b-49x480x720": ("cogvideox-5b", 13, 60, 90, 226),
+    "cogvideox-2b-49x480x720": ("cogvideox-2b", 13, 60, 90, 226),
+    "cogvideox-2b-9x256x256": ("cogvideox-2b", 3, 32, 32, 226),
+}
+
+
+def load_synthetic(s2v, eng, cfg, seed):
+    """near-identity N(0, 0.02^2) weights generated tensor by tensor on the GPU (timing weights)"""
+    shapes = s2v.weights.state_dict_shapes(cfg)
+    gen = torch.Generator(device=eng.device).manual_seed(seed)
+    for k, shp in shapes.items():
+        if len(shp) >= 2:
+            t = torch.randn(shp, generator=gen, device=eng.device, dtype=torch.float32) * 0.02
+        elif k.endswith("weight") and ("norm" in k) and ".linear." not in k:
+            t = torch.ones(shp, device=eng.device)
+        else:
+            t = torch.zeros(shp, device=eng.device)
+        eng.load_weight(k, t)
+        eng._keep.clear()
+        del t
+    s2v._lib.check(s2v.lib().s2v_finalize_weights(eng._h, s2v._lib.stream_ptr()))
+    torch.cuda.synchronize()
+
+
+def cpu_baseline(cfg, F, H, W, T, budget_s=60.0):
+    """the oracle (CPU restatement, torch fp32, all host cores) timed on a bounded sample: ONE transformer block for
+    ONE of the two CFG samples at the full token count, extrapolated x2 x num_layers."""
+    from oracle import transformer_ref as tr
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    D, heads = cfg.inner_dim, cfg.num_attention_heads
+    R = (H // 2) * (W // 2)
+    V = F * R
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    p = "transformer_blocks.0."
+    for k, shp in importlib.import_module("disentangled-subject-to-vid_amd").weights.state_dict_shapes(cfg).items():
+        if k.startswith(p):
+            sd[k] = torch.randn(shp, generator=g) * 0.02 if len(shp) >= 2 else torch.zeros(shp)
+    for n in ("norm1", "norm2"):
+        sd[p + n + ".norm.weight"] = torch.ones(D)
+    sd[p + "attn1.norm_q.weight"] = torch.ones(64)
+    sd[p + "attn1.norm_k.weight"] = torch.ones(64)
+    h, e0, e1 = torch.randn(1, V, D, generator=g), torch.randn(1, T, D, generator=g), torch.randn(1, R, D, generator=g)
+    temb = torch.randn(1, cfg.time_embed_dim, generator=g)
+    rope = ref_rope = None
+    if cfg.use_rotary_positional_embeddings:
+        ref_rope, rope = tr.pipeline_rope(H * 8, W * 8, F)
+    with torch.no_grad():
+        t0 = time.time()
+        tr.block_forward(sd, p, heads, h, e0, e1, temb, rope, ref_rope)
+        dt = time.time() - t0
+    step_s = dt * 2 * cfg.num_layers
+    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"1 of {cfg.num_layers} transformer blocks x 1 of 2 CFG samples at the full token count, torch "
+                      f"fp32 on {cores} threads: {dt:.1f} s, extrapolated x{2 * cfg.num_layers}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="cogvideox-5b-49x480x720", choices=sorted(WORKLOADS))
+    ap.add_argument("--graph", type=int, default=0, help="replay the step from a captured hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    s2v = importlib.import_module("disentangled-subject-to-vid_amd")
+    rank, world, local = s2v.dist.init_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(dev)
+    import torch.distributed as dist
+
+    preset, F, H, W, T = WORKLOADS[args.workload]
+    cfg = s2v.config.PRESETS[preset]()
+    dt = torch.bfloat16
+    eng = s2v.S2VEngine(cfg, dt, dev)
+    t_load = time.time()
+    if rank == 0:
+        load_synthetic(s2v, eng, cfg, 1234)
+    bcast_s = None
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        tb = time.time()
+        nbytes = s2v.dist.broadcast_arena(eng.weight_arena(), 0)
+        torch.cuda.synchronize()
+        dist.barrier()
+        bcast_s = time.time() - tb
+        if rank != 0:
+            eng.mark_weights_loaded()
+    t_load = time.time() - t_load
+
+    # one prompt per rank (different seeds), same shapes: weak scaling
+    g = torch.Generator(device=dev).manual_seed(100 + rank)
+    text = torch.randn(2, T, cfg.text_embed_dim, generator=g, device=dev)
+    ref = torch.randn(1, 1, cfg.in_channels, H, W, generator=g, device=dev) * 0.7
+    latents = torch.randn(1, F, cfg.in_channels, H, W, generator=g, device=dev).to(dt).contiguous()
+    eng.set_geometry(2, T, F, H, W)
+    eng.prepare_tables(H * 8, W * 8)
+    eng.set_conditioning(text, ref)
+    sch = s2v.CogVideoXDDIMScheduler(snr_shift_scale=cfg.snr_shift_scale)
+    sch.set_timesteps(50)
+    coefs = [sch.coef(t, dt, 6.0) for t in sch.timesteps]
+
+    def step(i):
+        eng.denoise_step(latents, float(sch.timesteps[i % 50]), coefs[i % 50], use_graph=bool(args.graph))
+
+    for i in range(args.warmup):
+        step(i)
+    profile = (not args.no_roofline) and not args.graph
+    if profile:
+        s2v._lib.check(s2v.lib().s2v_profile_enable(eng._h, 1))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = tt.item()
+    finite = bool(torch.isfinite(latents.float()).all().item())
+
+    roofline = None
+    if profile:
+        import ctypes
+
+        ms = (ctypes.c_float * 8)()
+        cnt = (ctypes.c_int32 * 8)()
+        s2v._lib.check(s2v.lib().s2v_profile_read(eng._h, ms, cnt, 8))
+        s2v._lib.check(s2v.lib().s2v_profile_enable(eng._h, 0))
+        N = T + (F + 1) * (H // 2) * (W // 2)
+        D = cfg.inner_dim
+        flops = {"gemm_qkv": 2 * 2 * N * D * 3 * D, "attention": 4 * 2 * N * N * D, "gemm_out": 2 * 2 * N * D * D,
+                 "gemm_ff1_gelu": 2 * 2 * N * D * 4 * D, "gemm_ff2": 2 * 2 * N * D * 4 * D}
+        per_kernel = {}
+        for k, name in enumerate(CLASSES):
+            if cnt[k] == 0:
+                continue
+            avg = ms[k] / cnt[k]
+            e = {"avg_ms": round(avg, 4), "launches": int(cnt[k]), "share_of_step": round(ms[k] / (elapsed * 1e3), 4)}
+            if name in flops:
+                e["tflops"] = round(flops[name] / avg / 1e9, 1)
+            per_kernel[name] = e
+        dom = max((n for n in per_kernel if n in flops), key=lambda n: per_kernel[n]["avg_ms"] * per_kernel[n]["launches"])
+        ach = per_kernel[dom]["tflops"]
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "algorithmic_flops_per_launch": flops[dom], "avg_launch_ms": per_kernel[dom]["avg_ms"],
+                    "per_kernel": per_kernel}
+
+    if rank == 0:
+        out = {
+            "metric": "denoise steps/sec (CogVideoX-5B, 49f 720x480; one step = CFG-pair transformer forward + CFG + "
+                      "scheduler step)" if "5b" in args.workload else f"denoise steps/sec ({args.workload})",
+            "value": round(args.gpus * args.steps / elapsed, 4),
+            "unit": "steps/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
+            "config": {"workload": args.workload, "latent_frames": F, "latent_hw": [H, W], "tokens": T + (F + 1) * (H // 2) * (W // 2),
+                       "cfg_pair": 2, "scheduler": "ddim-trailing-50", "parallelism": f"replicas x{args.gpus}",
+                       "hipgraph": bool(args.graph), "per_gpu_steps_per_s": round(args.steps / elapsed, 4),
+                       "weight_load_s": round(t_load, 2), "weight_broadcast_s": None if bcast_s is None else round(bcast_s, 3),
+                       "outputs_finite": finite},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and args.gpus == 1:
+            out["cpu_baseline"] = cpu_baseline(cfg, F, H, W, T)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,63 @@
+"""Model hyper-parameters of the hot path.  Source of the 2B / 5B values: the reference's
+diffusers/scripts/convert_cogvideox_to_diffusers.py:205-216,252-265 and the class defaults in
+models/transformers/cogvideox_transformer_3d.py:253-280."""
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+
+
+@dataclass
+class TransformerConfig:
+    num_layers: int = 30
+    num_attention_heads: int = 30
+    attention_head_dim: int = 64
+    in_channels: int = 16
+    out_channels: int = 16
+    patch_size: int = 2
+    time_embed_dim: int = 512
+    text_embed_dim: int = 4096
+    max_text_seq_length: int = 226
+    use_rotary_positional_embeddings: bool = False
+    norm_eps: float = 1e-5
+    spatial_interpolation_scale: float = 1.875
+    temporal_interpolation_scale: float = 1.0
+    snr_shift_scale: float = 3.0          # scheduler config that ships with the model
+    vae_scaling_factor: float = 1.15258426
+
+    @property
+    def inner_dim(self):
+        return self.num_attention_heads * self.attention_head_dim
+
+    def as_namespace(self):
+        return SimpleNamespace(**self.__dict__)
+
+
+def cogvideox_2b():
+    return TransformerConfig()
+
+
+def cogvideox_5b():
+    return TransformerConfig(num_layers=42, num_attention_heads=48, use_rotary_positional_embeddings=True,
+                             snr_shift_scale=1.0, vae_scaling_factor=0.7)
+
+
+def tiny(use_rope=True, heads=2, layers=2, text_dim=64, temb=64):
+    return TransformerConfig(num_layers=layers, num_attention_heads=heads, time_embed_dim=temb, text_embed_dim=text_dim,
+                             max_text_seq_length=5, use_rotary_positional_embeddings=use_rope,
+                             snr_shift_scale=1.0 if use_rope else 3.0, vae_scaling_factor=0.7)
+
+
+@dataclass
+class VAEConfig:
+    """AutoencoderKLCogVideoX defaults (autoencoder_kl_cogvideox.py:1020-1052)."""
+    block_out_channels: tuple = (128, 256, 256, 512)
+    layers_per_block: int = 3
+    norm_num_groups: int = 32
+    latent_channels: int = 16
+    out_channels: int = 3
+    temporal_compression_ratio: int = 4
+    sample_height: int = 480
+    sample_width: int = 720
+    scaling_factor: float = 1.15258426
+
+
+PRESETS = {"cogvideox-2b": cogvideox_2b, "cogvideox-5b": cogvideox_5b}

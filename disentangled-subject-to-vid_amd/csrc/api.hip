@@ -71,6 +71,31 @@ struct s2v_ctx {
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
     GraphKey gkey{nullptr, nullptr, nullptr};
+    // optional per-kernel-class timing with HIP events on the launch stream (bench.py's live roofline figure)
+    bool prof_on = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[8];
+    size_t prof_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+enum { PK_QKV = 0, PK_ATTN = 1, PK_OUT = 2, PK_FF1 = 3, PK_FF2 = 4, PK_LNMOD = 5, PK_QKNORM = 6, PK_OTHER = 7, PK_NUM = 8 };
+
+struct ProfScope {
+    s2v_ctx* c; int k; hipStream_t st; bool on;
+    ProfScope(s2v_ctx* c_, int k_, hipStream_t st_) : c(c_), k(k_), st(st_) {
+        on = c->prof_on && st != c->cap_stream;
+        if (!on) return;
+        if (c->prof_used[k] == c->prof_ev[k].size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            c->prof_ev[k].push_back({a, b});
+        }
+        (void)hipEventRecord(c->prof_ev[k][c->prof_used[k]].first, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(c->prof_ev[k][c->prof_used[k]].second, st);
+        c->prof_used[k]++;
+    }
 };
 
 static const int RING = 256;
@@ -383,16 +408,17 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st) {
     GemmArgs g{};
     g.A = c->Xn; g.lda = D; g.W = w.wqkv; g.ldw = D; g.bias = w.bqkv;
     g.C = c->QKV; g.ldc = 3 * D; g.M = (int)c->M; g.N = 3 * D; g.K = D;
-    S2V_TRY(linear(c, g, EPI_BIAS, st));
+    { ProfScope ps(c, PK_QKV, st); S2V_TRY(linear(c, g, EPI_BIAS, st)); }
     QkNormRopeArgs q{};
     q.qkv = c->QKV; q.ld_qkv = 3 * D; q.B = c->B; q.H = c->cfg.num_heads; q.Ntok = c->Ntok; q.text_len = c->T;
     q.nq_w = w.nq_w; q.nq_b = w.nq_b; q.nk_w = w.nk_w; q.nk_b = w.nk_b; q.eps = 1e-6f;
     q.cos = c->have_rope ? c->rope_cos : nullptr; q.sin = c->have_rope ? c->rope_sin : nullptr;
     q.vt = c->mfma ? c->VT : nullptr; q.ntok_pad = c->ntok_pad;
-    S2V_TRY(launch_qk_norm_rope(q, c->dtype, st));
+    { ProfScope ps(c, PK_QKNORM, st); S2V_TRY(launch_qk_norm_rope(q, c->dtype, st)); }
     AttnArgs a{};
     a.qkv = c->QKV; a.ld_qkv = 3 * D; a.vt = c->VT; a.ntok_pad = c->ntok_pad; a.out = c->Xn; a.ld_out = D;
     a.B = c->B; a.H = c->cfg.num_heads; a.Ntok = c->Ntok; a.scale = 0.125f;
+    ProfScope ps(c, PK_ATTN, st);
     if (c->mfma) S2V_TRY(launch_attn_bf16(a, st));
     else S2V_TRY(launch_attn_simple(a, c->dtype, st));
     return 0;
@@ -410,20 +436,22 @@ static int run_block(s2v_ctx* c, int l, const char* mod_base /* [B][mod_stride] 
         n.w = half ? w.ln2_w : w.ln1_w; n.b = half ? w.ln2_b : w.ln1_b; n.eps = c->cfg.norm_eps;
         n.shift_vid = mb; n.scale_vid = mb + D * E; n.shift_txt = mb + 3 * D * E; n.scale_txt = mb + 4 * D * E;
         n.mod_stride = (int)mod_stride; n.B = c->B; n.Ntok = c->Ntok; n.text_len = c->T; n.D = D;
-        S2V_TRY(launch_ln_modulate(n, c->dtype, st));
+        { ProfScope ps(c, PK_LNMOD, st); S2V_TRY(launch_ln_modulate(n, c->dtype, st)); }
         GemmArgs g{};
         g.X = c->X; g.ldx = D; g.gate_vid = mb + 2 * D * E; g.gate_txt = mb + 5 * D * E; g.gate_stride = (int)mod_stride;
         g.tok_per_batch = c->Ntok; g.text_len = c->T; g.M = (int)c->M; g.N = D;
         if (half == 0) {
             S2V_TRY(run_attention(c, l, st));
             g.A = c->Xn; g.lda = D; g.W = w.wo; g.ldw = D; g.bias = w.bo; g.K = D;
+            ProfScope ps(c, PK_OUT, st);
             S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
         } else {
             GemmArgs f{};
             f.A = c->Xn; f.lda = D; f.W = w.w1; f.ldw = D; f.bias = w.b1; f.C = c->Hb; f.ldc = 4 * D;
             f.M = (int)c->M; f.N = 4 * D; f.K = D;
-            S2V_TRY(linear(c, f, EPI_BIAS_GELU, st));
+            { ProfScope ps(c, PK_FF1, st); S2V_TRY(linear(c, f, EPI_BIAS_GELU, st)); }
             g.A = c->Hb; g.lda = 4 * D; g.W = w.w2; g.ldw = 4 * D; g.bias = w.b2; g.K = 4 * D;
+            ProfScope ps(c, PK_FF2, st);
             S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
         }
     }
@@ -539,21 +567,20 @@ static void fill_coef(SchedCoef& d, const s2v_sched_coef& s) {
     d.m1 = s.m1; d.m2 = s.m2; d.m3 = s.m3; d.m4 = s.m4; d.mn = s.mn; d.pad = 0.f;
 }
 
-extern "C" int s2v_sched_step(s2v_ctx* c, const s2v_sched_coef* coef_host, const void* noise_pred, int32_t cfg,
+extern "C" int s2v_sched_step(s2v_ctx* c, const s2v_sched_coef* coef_host, const void* noise_pred, int32_t flags,
                               const void* latents_in, void* latents_out, float* x0_hist, const void* noise, int64_t n,
-                              s2v_stream stream) {
-    S2V_REQUIRE(c && coef_host && noise_pred && latents_in && latents_out, "s2v_sched_step: null argument");
+                              int32_t dtype, s2v_stream stream) {
+    S2V_REQUIRE(coef_host && noise_pred && latents_in && latents_out, "s2v_sched_step: null argument");
     S2V_REQUIRE(coef_host->kind == 0 || noise, "s2v_sched_step: DPM step needs a noise tensor");
     S2V_REQUIRE(coef_host->kind != 2 || x0_hist, "s2v_sched_step: DPM multistep needs x0_hist");
-    hipStream_t st = (hipStream_t)stream;
-    s2v_ctx::Stage& sg = c->ring[c->ring_pos];
-    c->ring_pos = (c->ring_pos + 1) % RING;
-    fill_coef(sg.c, *coef_host);
-    S2V_CHECK_HIP(hipMemcpyAsync(c->coef_dev, &sg.c, sizeof(SchedCoef), hipMemcpyHostToDevice, st));
+    S2V_REQUIRE(dtype == S2V_DTYPE_F32 || dtype == S2V_DTYPE_BF16, "s2v_sched_step: unsupported dtype");
+    (void)c;
     SchedArgs a{};
     a.noise_pred = noise_pred; a.latents_in = latents_in; a.latents_out = latents_out; a.x0_hist = x0_hist;
-    a.noise = noise; a.n = n; a.cfg = cfg; a.coef = c->coef_dev;
-    return launch_sched_step(a, c->dtype, st);
+    a.noise = noise; a.n = n; a.cfg = flags & 1; a.np_f32 = (flags >> 1) & 1; a.out_f32 = (flags >> 2) & 1;
+    a.coef = nullptr;
+    fill_coef(a.cval, *coef_host);
+    return launch_sched_step(a, dtype, (hipStream_t)stream);
 }
 
 static int step_launches(s2v_ctx* c, void* latents, float* x0_hist, const void* noise, hipStream_t st) {
@@ -593,6 +620,32 @@ extern "C" int s2v_denoise_step(s2v_ctx* c, void* latents, float timestep, const
         c->gkey = key;
     }
     S2V_CHECK_HIP(hipGraphLaunch(c->gexec, st));
+    return 0;
+}
+
+// Per-kernel-class timing (HIP events recorded on the launch stream around every launch of the class).
+// classes: 0 qkv GEMM, 1 attention, 2 out-proj GEMM, 3 FF1 GEMM, 4 FF2 GEMM, 5 LN-modulate, 6 qk-norm/rope/V^T
+extern "C" int s2v_profile_enable(s2v_ctx* c, int32_t on) {
+    S2V_REQUIRE(c, "null context");
+    c->prof_on = on != 0;
+    for (int k = 0; k < PK_NUM; ++k) c->prof_used[k] = 0;
+    return 0;
+}
+// Synchronises, then returns total milliseconds and launch counts per class since the last read; resets.
+extern "C" int s2v_profile_read(s2v_ctx* c, float* ms_by_class, int32_t* launches_by_class, int32_t nclass) {
+    S2V_REQUIRE(c && ms_by_class && launches_by_class, "s2v_profile_read: null argument");
+    S2V_CHECK_HIP(hipDeviceSynchronize());
+    for (int k = 0; k < nclass && k < PK_NUM; ++k) {
+        float tot = 0.f;
+        for (size_t i = 0; i < c->prof_used[k]; ++i) {
+            float ms = 0.f;
+            S2V_CHECK_HIP(hipEventElapsedTime(&ms, c->prof_ev[k][i].first, c->prof_ev[k][i].second));
+            tot += ms;
+        }
+        ms_by_class[k] = tot;
+        launches_by_class[k] = (int32_t)c->prof_used[k];
+        c->prof_used[k] = 0;
+    }
     return 0;
 }
 

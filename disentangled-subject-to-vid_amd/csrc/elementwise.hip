@@ -463,16 +463,22 @@ int launch_copy_rows(const void* src, int lds_, const void* add, int ldadd, void
 // (no fma contraction), so the fp32 arithmetic is bit-identical to the CPU reference.
 template <typename T>
 __global__ void sched_step_k(const SchedArgs a) {
+#pragma clang fp contract(off)  // hipcc defaults to -ffp-contract=fast and __fmul_rn is a plain multiply in HIP
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= a.n) return;
-    const SchedCoef k = *a.coef;
-    const T* np = (const T*)a.noise_pred;
+    const SchedCoef k = a.coef ? *a.coef : a.cval;
     float v;
-    if (a.cfg) {
-        const float u = ET<T>::ld(np + i), c = ET<T>::ld(np + a.n + i);
-        v = __fadd_rn(u, __fmul_rn(k.guidance, __fsub_rn(c, u)));
+    if (a.np_f32) {
+        const float* np = (const float*)a.noise_pred;
+        v = a.cfg ? __fadd_rn(np[i], __fmul_rn(k.guidance, __fsub_rn(np[a.n + i], np[i]))) : np[i];
     } else {
-        v = ET<T>::ld(np + i);
+        const T* np = (const T*)a.noise_pred;
+        if (a.cfg) {
+            const float u = ET<T>::ld(np + i), c = ET<T>::ld(np + a.n + i);
+            v = __fadd_rn(u, __fmul_rn(k.guidance, __fsub_rn(c, u)));
+        } else {
+            v = ET<T>::ld(np + i);
+        }
     }
     const float x = ET<T>::ld((const T*)a.latents_in + i);
     const float x0 = __fsub_rn(ET<T>::rnd(__fmul_rn(x, k.c_x0_x)), __fmul_rn(k.c_x0_v, v));
@@ -486,7 +492,8 @@ __global__ void sched_step_k(const SchedArgs a) {
         prev = __fadd_rn(__fsub_rn(ET<T>::rnd(__fmul_rn(k.m1, x)), __fmul_rn(k.m2, d)), ET<T>::rnd(__fmul_rn(k.mn, nz)));
     }
     if (a.x0_hist) a.x0_hist[i] = x0;
-    ET<T>::st((T*)a.latents_out + i, prev);
+    if (a.out_f32) ((float*)a.latents_out)[i] = prev;
+    else ET<T>::st((T*)a.latents_out + i, prev);
 }
 int launch_sched_step(const SchedArgs& a, int dtype, hipStream_t st) {
     dim3 grid((unsigned)((a.n + 255) / 256));

@@ -111,7 +111,10 @@ struct SchedArgs {
     float* x0_hist;           // [n] fp32: read as x0_old (kind 2), overwritten with this step's x0 (may be null for DDIM)
     const void* noise;        // [n] model dtype, DPM only
     int64_t n; int cfg;
-    const SchedCoef* coef;    // device pointer
+    const SchedCoef* coef;    // device pointer, or null => use cval
+    SchedCoef cval;
+    int np_f32;               // noise_pred is fp32 (the scheduler-object seam: model_output after .float())
+    int out_f32;              // latents_out is fp32 and un-rounded (scheduler.step's return value)
 };
 int launch_sched_step(const SchedArgs& a, int dtype, hipStream_t st);
 // dst[i] = (Tdst) src[i]

@@ -1,0 +1,75 @@
+"""Data-parallel replicas of the denoise path over the GPUs of one node (the path does not
+shard inside a video, every prompt is an independent unit).  One process per GPU; the only collective is the one-off
+broadcast of the packed weight arena rank0 -> all (RCCL over xGMI when the backend is "nccl"), plus an optional
+gather of results.  No per-step communication.  The host logic is backend-agnostic and covered with gloo on CPU
+(tests/test_dist_gloo.py)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_prompts(num_prompts, rank, world):
+    """prompt p runs on rank p mod world"""
+    return [p for p in range(num_prompts) if p % world == rank]
+
+
+def broadcast_arena(arena, src=0, chunk_bytes=256 << 20):
+    """replicate a finalized model: `arena` is the uint8 view of the packed weights (S2VEngine.weight_arena()).
+    Chunked so that each collective is large enough to saturate an xGMI link (>= 64 MB) without needing a second
+    full-size staging buffer."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    flat = arena.view(-1)
+    n = flat.numel()
+    for off in range(0, n, chunk_bytes):
+        dist.broadcast(flat[off : min(off + chunk_bytes, n)], src=src)
+    return n
+
+
+def gather_results(local_results, dst=0):
+    """collect {prompt_id: tensor} from every rank on `dst` (CPU tensors; result latents are a few MB)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return dict(local_results)
+    payload = {k: v.detach().cpu() for k, v in local_results.items()}
+    gathered = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+    dist.gather_object(payload, gathered, dst=dst)
+    if dist.get_rank() != dst:
+        return None
+    out = {}
+    for g in gathered:
+        out.update(g)
+    return out
+
+
+def run_replicas(make_engine, load_weights_rank0, prompts, run_prompt):
+    """generic driver: rank 0 ingests the checkpoint, everybody else receives the arena; then each rank runs its
+    prompts.  make_engine() -> engine with .weight_arena() / .mark_weights_loaded();
+    load_weights_rank0(engine) loads + finalizes; run_prompt(engine, prompt_id, prompt) -> tensor."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    eng = make_engine()
+    if rank == 0:
+        load_weights_rank0(eng)
+    if world > 1:
+        broadcast_arena(eng.weight_arena(), 0)
+        if rank != 0:
+            eng.mark_weights_loaded()
+    mine = {p: run_prompt(eng, p, prompts[p]) for p in shard_prompts(len(prompts), rank, world)}
+    return gather_results(mine, 0)

@@ -1,0 +1,173 @@
+"""Thin object wrapper over the C ABI context (include/s2v_hip.h).  torch is used for device memory and streams
+only; every arithmetic step of the path runs in libs2v_hip.so."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, tables
+from .config import TransformerConfig
+
+
+class _ArenaView:
+    """exposes a raw device range through __cuda_array_interface__ so torch.distributed can broadcast it"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+
+class S2VEngine:
+    def __init__(self, cfg: TransformerConfig, dtype=torch.bfloat16, device="cuda:0", force_simple=False):
+        if dtype not in _lib.DTYPE_OF:
+            raise _lib.S2VError(f"unsupported model dtype {dtype} (float32 and bfloat16 are implemented)")
+        if cfg.attention_head_dim != 64:
+            raise _lib.S2VError("attention_head_dim must be 64")
+        self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
+        self.D = cfg.inner_dim
+        torch.cuda.set_device(self.device)
+        c = _lib.ModelConfigC()
+        c.num_layers, c.num_heads = cfg.num_layers, cfg.num_attention_heads
+        c.in_channels, c.out_channels, c.patch_size = cfg.in_channels, cfg.out_channels, cfg.patch_size
+        c.time_embed_dim, c.text_embed_dim = cfg.time_embed_dim, cfg.text_embed_dim
+        c.use_rope = int(cfg.use_rotary_positional_embeddings)
+        c.dtype = _lib.DTYPE_OF[dtype]
+        c.norm_eps = cfg.norm_eps
+        c.force_simple = int(force_simple)
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().s2v_create(ctypes.byref(c), ctypes.byref(self._h)))
+        self.geometry = None
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            torch.cuda.synchronize(self.device)
+            _lib.lib().s2v_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights -----------------------------------------------------------------------------------------
+    def load_weight(self, name, tensor):
+        t = tensor.to(self.device)
+        if t.dtype not in _lib.DTYPE_OF:
+            t = t.float()
+        t = t.contiguous()
+        shape = (ctypes.c_int64 * t.ndim)(*t.shape)
+        _lib.check(_lib.lib().s2v_load_weight(self._h, name.encode(), _lib.ptr(t), shape, t.ndim,
+                                              _lib.DTYPE_OF[t.dtype], _lib.stream_ptr()))
+        self._keep.append(t)  # alive until the stream has consumed it
+
+    def load_state_dict(self, sd, lora=None, lora_scale=0.5):
+        """sd: {reference state-dict key: tensor}; lora: {weight key: (A [r,in..], B [out,r])} merged as
+        W + lora_scale * B A (src/inference.py:218-229: alpha/r = 64/128)."""
+        for k, v in sd.items():
+            if "pos_embedding" in k:
+                continue  # non-persistent buffer, rebuilt by tables.sincos_table
+            self.load_weight(k, v)
+        for k, (A, B) in (lora or {}).items():
+            A2 = A.to(self.device).float().reshape(A.shape[0], -1).contiguous()
+            B2 = B.to(self.device).float().contiguous()
+            _lib.check(_lib.lib().s2v_merge_lora(self._h, k.encode(), _lib.ptr(A2), _lib.ptr(B2), A2.shape[0],
+                                                 float(lora_scale), _lib.stream_ptr()))
+        _lib.check(_lib.lib().s2v_finalize_weights(self._h, _lib.stream_ptr()))
+        torch.cuda.synchronize(self.device)
+        self._keep.clear()
+
+    def weight_arena(self):
+        """uint8 CUDA tensor aliasing the packed, context-owned weights (one RCCL broadcast replicates a model)."""
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(_lib.lib().s2v_weight_arena(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return torch.as_tensor(_ArenaView(p.value, n.value), device=self.device)
+
+    def mark_weights_loaded(self):
+        _lib.check(_lib.lib().s2v_mark_weights_loaded(self._h))
+
+    # ---- geometry / tables / conditioning ----------------------------------------------------------------------
+    def set_geometry(self, B, T, F, H, W):
+        _lib.check(_lib.lib().s2v_set_geometry(self._h, B, T, F, H, W))
+        self.geometry = (B, T, F, H, W)
+
+    def set_rope(self, cos, sin):
+        cos = cos.to(self.device, torch.float32).contiguous()
+        sin = sin.to(self.device, torch.float32).contiguous()
+        B, T, F, H, W = self.geometry
+        n = (H // 2) * (W // 2) * (F + 1)
+        if tuple(cos.shape) != (n, 64) or tuple(sin.shape) != (n, 64):
+            raise _lib.S2VError(f"RoPE tables must be [{n}, 64] ([ref | video] rows)")
+        _lib.check(_lib.lib().s2v_set_rope(self._h, _lib.ptr(cos), _lib.ptr(sin), _lib.stream_ptr()))
+        torch.cuda.current_stream().synchronize()
+
+    def set_pos_embed(self, table):
+        t = table.to(self.device, self.dtype).contiguous()
+        _lib.check(_lib.lib().s2v_set_pos_embed(self._h, _lib.ptr(t), _lib.stream_ptr()))
+        torch.cuda.current_stream().synchronize()
+
+    def prepare_tables(self, height, width):
+        """build + upload the step-invariant positional tables for a video of height x width pixels"""
+        B, T, F, H, W = self.geometry
+        if self.cfg.use_rotary_positional_embeddings:
+            cos, sin = tables.rope_tables(height, width, F)
+            self.set_rope(torch.from_numpy(cos), torch.from_numpy(sin))
+        else:
+            pe = tables.sincos_table(self.D, H // 2, W // 2, F, self.cfg.spatial_interpolation_scale,
+                                     self.cfg.temporal_interpolation_scale)
+            self.set_pos_embed(torch.from_numpy(pe))
+
+    def set_conditioning(self, text, ref_latent):
+        text = text.to(self.device, self.dtype).contiguous()
+        ref = ref_latent.to(self.device, self.dtype).contiguous()
+        B, T, F, H, W = self.geometry
+        if tuple(text.shape) != (B, T, self.cfg.text_embed_dim):
+            raise _lib.S2VError(f"text embeddings must be [{B},{T},{self.cfg.text_embed_dim}], got {tuple(text.shape)}")
+        if ref.numel() != self.cfg.in_channels * H * W:
+            raise _lib.S2VError("ref_img_states must be [1,1,C,H,W] with the geometry's H, W")
+        _lib.check(_lib.lib().s2v_set_conditioning(self._h, _lib.ptr(text), _lib.ptr(ref), _lib.stream_ptr()))
+        torch.cuda.current_stream().synchronize()
+
+    # ---- compute -------------------------------------------------------------------------------------------
+    def forward(self, latents, timesteps, shared_latent=False):
+        """CogVideoXTransformer3DModel.forward seam: latents [B,F,C,H,W] (or [1,F,C,H,W] with shared_latent)."""
+        B, T, F, H, W = self.geometry
+        lat = latents.to(self.device, self.dtype).contiguous()
+        t = timesteps.to(self.device, torch.float32).contiguous()
+        if t.numel() != B:
+            t = t.reshape(-1)[:1].expand(B).contiguous()
+        out = torch.empty((B, F, self.cfg.out_channels, H, W), dtype=self.dtype, device=self.device)
+        stride = 0 if shared_latent else F * self.cfg.in_channels * H * W
+        _lib.check(_lib.lib().s2v_transformer_forward(self._h, _lib.ptr(lat), stride, _lib.ptr(t), _lib.ptr(out),
+                                                      _lib.stream_ptr()))
+        return out
+
+    def block_forward(self, layer, hidden, enc0, enc1, temb):
+        hidden, enc0, enc1, temb = (x.to(self.device, self.dtype).contiguous() for x in (hidden, enc0, enc1, temb))
+        oh, o0, o1 = torch.empty_like(hidden), torch.empty_like(enc0), torch.empty_like(enc1)
+        _lib.check(_lib.lib().s2v_block_forward(self._h, layer, _lib.ptr(hidden), _lib.ptr(enc0), _lib.ptr(enc1),
+                                                _lib.ptr(temb), _lib.ptr(oh), _lib.ptr(o0), _lib.ptr(o1),
+                                                _lib.stream_ptr()))
+        return oh, o0, o1
+
+    def attn_forward(self, layer, hidden, encoder):
+        hidden, encoder = (x.to(self.device, self.dtype).contiguous() for x in (hidden, encoder))
+        oh, oe = torch.empty_like(hidden), torch.empty_like(encoder)
+        _lib.check(_lib.lib().s2v_attn_forward(self._h, layer, _lib.ptr(hidden), _lib.ptr(encoder), _lib.ptr(oh),
+                                               _lib.ptr(oe), _lib.stream_ptr()))
+        return oh, oe
+
+    def denoise_step(self, latents, timestep, coef, x0_hist=None, noise=None, use_graph=False):
+        """one iteration of the denoise loop, latents [1,F,C,H,W] (model dtype) updated in place"""
+        if latents.dtype != self.dtype or not latents.is_contiguous():
+            raise _lib.S2VError("latents must be a contiguous model-dtype tensor (it is updated in place)")
+        _lib.check(_lib.lib().s2v_denoise_step(self._h, _lib.ptr(latents), float(timestep), ctypes.byref(coef),
+                                               _lib.ptr(x0_hist), _lib.ptr(noise), int(use_graph), _lib.stream_ptr()))
+
+    def last_noise_pred(self):
+        B, T, F, H, W = self.geometry
+        p = ctypes.c_void_p()
+        _lib.check(_lib.lib().s2v_last_noise_pred(self._h, ctypes.byref(p)))
+        n = B * F * self.cfg.out_channels * H * W * (2 if self.dtype == torch.bfloat16 else 4)
+        raw = torch.as_tensor(_ArenaView(p.value, n), device=self.device)
+        return raw.view(self.dtype).view(B, F, self.cfg.out_channels, H, W).clone()

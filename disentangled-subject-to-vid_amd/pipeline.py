@@ -1,0 +1,142 @@
+"""The denoise loop of the hot path, mirroring CustomCogVideoXPipeline.__call__
+(src/custom_cogvideox_pipe.py:125-326) from step 4 on: prompt embeddings are inputs (the T5 encoder is a caller-side
+step), everything after them runs here.
+
+Two execution modes with identical results:
+  fused=True  (default) one s2v_denoise_step per iteration: transformer on the CFG pair, fp32 CFG, scheduler step
+               and the round to the model dtype in one (optionally hipGraph-captured) launch sequence;
+  fused=False the reference's own sequence of seam calls: transformer(...) -> .float() -> CFG -> scheduler.step ->
+               .to(dtype), each through its drop-in object.
+
+Deviations from the shipped harness, both explicit: the 1350-tokens-per-frame constant (:228-235) is generalised to
+(H/16)(W/16) and non-RoPE models skip the RoPE slicing instead of crashing (:223-231) -- needed for the 2B and
+non-480x720 configurations of BASELINE.json; module arithmetic is unchanged.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib, tables
+from .schedulers import CogVideoXDPMScheduler
+
+
+class S2VPipeline:
+    def __init__(self, transformer, scheduler, vae=None, vae_scale_factor_spatial=8, vae_scale_factor_temporal=4):
+        self.transformer, self.scheduler, self.vae = transformer, scheduler, vae
+        self.vae_scale_factor_spatial = vae_scale_factor_spatial
+        self.vae_scale_factor_temporal = vae_scale_factor_temporal
+        self._guidance_scale = 1.0
+        self.interrupt = False
+
+    @property
+    def guidance_scale(self):
+        return self._guidance_scale
+
+    def check_inputs(self, height, width, prompt_embeds, negative_prompt_embeds):
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if prompt_embeds is None:
+            raise ValueError("Provide `prompt_embeds` (the text encoder is not part of this path).")
+        if negative_prompt_embeds is not None and prompt_embeds.shape != negative_prompt_embeds.shape:
+            raise ValueError("`prompt_embeds` and `negative_prompt_embeds` must have the same shape when passed "
+                             f"directly, but got {prompt_embeds.shape} != {negative_prompt_embeds.shape}.")
+
+    def prepare_latents(self, num_frames, height, width, dtype, device, generator, latents=None):
+        shape = (1, (num_frames - 1) // self.vae_scale_factor_temporal + 1, self.transformer.config.in_channels,
+                 height // self.vae_scale_factor_spatial, width // self.vae_scale_factor_spatial)
+        if latents is None:
+            gdev = generator.device if generator is not None else device
+            latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+        else:
+            latents = latents.to(device)
+        return latents * self.scheduler.init_noise_sigma
+
+    @torch.no_grad()
+    def __call__(self, prompt_embeds=None, negative_prompt_embeds=None, ref_img_states=None, height=480, width=720,
+                 num_frames=49, num_inference_steps=50, guidance_scale=6.0, use_dynamic_cfg=False, generator=None,
+                 latents=None, output_type="latent", return_dict=True, fused=True, use_graph=False,
+                 callback_on_step_end=None):
+        if num_frames > 49:
+            raise ValueError("The number of frames must be less than or equal to 49 due to static positional embeddings.")
+        self.check_inputs(height, width, prompt_embeds, negative_prompt_embeds)
+        if prompt_embeds.shape[0] != 1:
+            raise RuntimeError("one prompt per call: the transformer duplicates the reference tokens exactly x2 "
+                               "(cogvideox_transformer_3d.py:503-504)")
+        if guidance_scale <= 1.0:
+            raise RuntimeError("guidance_scale must be > 1: eval=True duplicates the reference tokens for the CFG pair")
+        tr, sch = self.transformer, self.scheduler
+        eng, dt, dev = tr.engine, tr.dtype, tr.device
+        text = torch.cat([negative_prompt_embeds, prompt_embeds], dim=0).to(dev, dt)
+        sch.set_timesteps(num_inference_steps, device="cpu")
+        timesteps = sch.timesteps
+        latents = self.prepare_latents(num_frames, height, width, dt, dev, generator, latents).to(dt).contiguous()
+        F, H, W = latents.shape[1], latents.shape[3], latents.shape[4]
+        ref = ref_img_states.to(dev, dt)
+        is_dpm = isinstance(sch, CogVideoXDPMScheduler)
+        rope = ref_rope = None
+        if tr.config.use_rotary_positional_embeddings:
+            cos, sin = tables.rope_tables(height, width, F)
+            n = (H // 2) * (W // 2)
+            cos, sin = torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev)
+            ref_rope, rope = (cos[:n], sin[:n]), (cos[n:], sin[n:])
+
+        if fused:
+            eng.set_geometry(2, text.shape[1], F, H, W)
+            eng.prepare_tables(height, width)
+            eng.set_conditioning(text, ref)
+            x0_hist = torch.zeros(latents.shape, dtype=torch.float32, device=dev) if is_dpm else None
+            noise = torch.empty_like(latents) if is_dpm else None
+        old = None
+        for i, t in enumerate(timesteps):
+            if self.interrupt:
+                break
+            g = guidance_scale
+            if use_dynamic_cfg:
+                g = 1 + guidance_scale * ((1 - math.cos(math.pi * ((num_inference_steps - i) / num_inference_steps) ** 5.0)) / 2)
+            self._guidance_scale = g
+            if fused:
+                if is_dpm:
+                    coef = sch.coef(t, timesteps[i - 1] if i > 0 else None, i == 0, dt, g)
+                    self._draw(noise, generator)
+                    if coef.kind == 2:
+                        self._draw(noise, generator)  # the reference discards its first draw on multistep steps
+                else:
+                    coef = sch.coef(t, dt, g)
+                eng.denoise_step(latents, float(t), coef, x0_hist, noise, use_graph)
+            else:
+                x = torch.cat([latents] * 2)
+                x = sch.scale_model_input(x, t)
+                noise_pred = tr(hidden_states=x, encoder_hidden_states=text, ref_img_states=ref,
+                                timestep=t.expand(2), image_rotary_emb=rope, ref_image_rotary_emb=ref_rope,
+                                return_dict=False, eval=True)[0].float()
+                u, c = noise_pred.chunk(2)
+                noise_pred = u + g * (c - u)
+                if not is_dpm:
+                    latents = sch.step(noise_pred, t, latents, return_dict=False)[0]
+                else:
+                    latents, old = sch.step(noise_pred, old, t, timesteps[i - 1] if i > 0 else None, latents,
+                                            generator=generator, return_dict=False)
+                latents = latents.to(dt)
+            if callback_on_step_end is not None:
+                callback_on_step_end(self, i, t, {"latents": latents})
+        if output_type == "latent":
+            video = latents
+        else:
+            if self.vae is None:
+                raise ValueError("a VAE object is needed for output_type != 'latent'")
+            video = self.decode_latents(latents)
+            video = self.vae.postprocess_video(video, output_type)
+        return (video,) if not return_dict else {"frames": video}
+
+    @staticmethod
+    def _draw(buf, generator):
+        gdev = generator.device.type if generator is not None else buf.device.type
+        if gdev == "cpu":
+            buf.copy_(torch.randn(buf.shape, generator=generator, dtype=buf.dtype))
+        else:
+            buf.normal_(generator=generator)
+
+    def decode_latents(self, latents):
+        """pipeline_cogvideox.py:346-351"""
+        return self.vae.decode_latents(latents)

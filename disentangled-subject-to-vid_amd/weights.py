@@ -1,0 +1,93 @@
+"""Synthetic, seeded weights of the CogVideoX transformer with the reference's state-dict keys and shapes
+ -- there are no real checkpoints offline.  `parity=True` uses larger-variance weights,
+non-zero biases and LN affines so that gates, modulation and every residual term contribute measurably;
+`parity=False` is the near-identity N(0, 0.02^2) initialisation used for timing runs."""
+import torch
+
+from .config import TransformerConfig
+
+
+def state_dict_shapes(cfg: TransformerConfig):
+    D, TE, TX = cfg.inner_dim, cfg.time_embed_dim, cfg.text_embed_dim
+    C, p = cfg.in_channels, cfg.patch_size
+    s = {
+        "patch_embed.proj.weight": (D, C, p, p), "patch_embed.proj.bias": (D,),
+        "patch_embed.text_proj.weight": (D, TX), "patch_embed.text_proj.bias": (D,),
+        "time_embedding.linear_1.weight": (TE, D), "time_embedding.linear_1.bias": (TE,),
+        "time_embedding.linear_2.weight": (TE, TE), "time_embedding.linear_2.bias": (TE,),
+        "norm_final.weight": (D,), "norm_final.bias": (D,),
+        "norm_out.linear.weight": (2 * D, TE), "norm_out.linear.bias": (2 * D,),
+        "norm_out.norm.weight": (D,), "norm_out.norm.bias": (D,),
+        "proj_out.weight": (cfg.out_channels * p * p, D), "proj_out.bias": (cfg.out_channels * p * p,),
+    }
+    for i in range(cfg.num_layers):
+        b = f"transformer_blocks.{i}."
+        for n in ("norm1", "norm2"):
+            s[b + n + ".linear.weight"] = (6 * D, TE)
+            s[b + n + ".linear.bias"] = (6 * D,)
+            s[b + n + ".norm.weight"] = (D,)
+            s[b + n + ".norm.bias"] = (D,)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            s[b + "attn1." + n + ".weight"] = (D, D)
+            s[b + "attn1." + n + ".bias"] = (D,)
+        for n in ("norm_q", "norm_k"):
+            s[b + "attn1." + n + ".weight"] = (64,)
+            s[b + "attn1." + n + ".bias"] = (64,)
+        s[b + "ff.net.0.proj.weight"] = (4 * D, D)
+        s[b + "ff.net.0.proj.bias"] = (4 * D,)
+        s[b + "ff.net.2.weight"] = (D, 4 * D)
+        s[b + "ff.net.2.bias"] = (D,)
+    return s
+
+
+LORA_TARGETS = ("to_q", "to_k", "to_v", "to_out.0", "proj", "text_proj", "norm1.linear", "norm2.linear", "ff.net.2")
+
+
+def lora_target_keys(cfg):
+    """weight keys the reference's LoraConfig(target_modules=...) matches (src/inference.py:218-225; PEFT matches
+    module-name suffixes, so "proj" also catches ff.net.0.proj and patch_embed.proj)"""
+    keys = []
+    for k in state_dict_shapes(cfg):
+        if not k.endswith(".weight"):
+            continue
+        mod = k[: -len(".weight")]
+        if any(mod == t or mod.endswith("." + t) for t in LORA_TARGETS):
+            keys.append(k)
+    return keys
+
+
+def synthetic_state_dict(cfg, seed=1234, device="cpu", dtype=torch.float32, parity=False):
+    gen = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for k, shape in state_dict_shapes(cfg).items():
+        is_norm = ".norm" in k or k.startswith("norm_final") or "norm_q" in k or "norm_k" in k
+        if len(shape) >= 2:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            std = (0.7 / fan_in**0.5) if parity else 0.02
+            if parity and ".linear." in k:
+                std = 0.5 / fan_in**0.5
+            t = torch.randn(shape, generator=gen, device=device, dtype=torch.float32) * std
+        elif is_norm and k.endswith("weight") and ".linear." not in k:
+            t = torch.ones(shape, device=device)
+            if parity:
+                t = t + 0.2 * torch.randn(shape, generator=gen, device=device)
+        else:
+            t = torch.zeros(shape, device=device)
+            if parity:
+                t = 0.1 * torch.randn(shape, generator=gen, device=device)
+        sd[k] = t.to(dtype)
+    return sd
+
+
+def synthetic_lora(cfg, rank=128, seed=99, device="cpu", std=0.02):
+    gen = torch.Generator(device=device).manual_seed(seed)
+    shapes = state_dict_shapes(cfg)
+    out = {}
+    for k in lora_target_keys(cfg):
+        shp = shapes[k]
+        A = torch.randn((rank,) + tuple(shp[1:]), generator=gen, device=device) * std
+        B = torch.randn((shp[0], rank), generator=gen, device=device) * std
+        out[k] = (A, B)
+    return out

@@ -107,12 +107,15 @@ typedef struct s2v_sched_coef {
     float pad;
 } s2v_sched_coef;
 
-/* scheduler.step (+ optional CFG combine, custom_cogvideox_pipe.py:266-296):
- * noise_pred [2,n] (cfg=1: uncond, cond) or [n]; latents in/out [n] model dtype (may alias); x0_hist fp32 [n]
- * (DPM: read as old x0, then overwritten; may be NULL for DDIM); noise [n] model dtype (DPM only). */
-int s2v_sched_step(s2v_ctx* ctx, const s2v_sched_coef* coef_host, const void* noise_pred, int32_t cfg,
+/* scheduler.step (+ optional CFG combine, custom_cogvideox_pipe.py:266-296); ctx may be NULL.
+ * flags bit0: noise_pred is the CFG pair [2,n] (uncond, cond) and is combined with coef->guidance;
+ *       bit1: noise_pred is fp32 (what the reference hands to scheduler.step after .float());
+ *       bit2: latents_out is fp32 and un-rounded (scheduler.step's own return value) instead of `dtype`.
+ * latents in/out [n] (may alias); x0_hist fp32 [n] (DPM: read as old x0, then overwritten; may be NULL for DDIM);
+ * noise [n] in `dtype` (DPM only). */
+int s2v_sched_step(s2v_ctx* ctx, const s2v_sched_coef* coef_host, const void* noise_pred, int32_t flags,
                    const void* latents_in, void* latents_out, float* x0_hist, const void* noise, int64_t n,
-                   s2v_stream stream);
+                   int32_t dtype, s2v_stream stream);
 
 /* One iteration of the denoise loop (custom_cogvideox_pipe.py:241-296): transformer on the CFG pair sharing
  * `latents` [1,F,C,H,W], fp32 CFG, scheduler step, round to the model dtype; latents updated IN PLACE.
@@ -122,6 +125,15 @@ int s2v_denoise_step(s2v_ctx* ctx, void* latents, float timestep, const s2v_sche
                      const void* noise, int32_t use_graph, s2v_stream stream);
 /* pointer to the [B,F,C,H,W] model output of the last s2v_denoise_step (context-owned, model dtype) */
 int s2v_last_noise_pred(s2v_ctx* ctx, void** dev_ptr);
+
+/* Live per-kernel timing for the roofline report (bench.py): HIP events are recorded on the launch stream around
+ * every launch of a class; classes 0 qkv GEMM, 1 attention, 2 out-proj GEMM, 3 FF1 GEMM, 4 FF2 GEMM,
+ * 5 LN-modulate, 6 qk-norm/rope/V^T.  Not recorded inside a captured graph.  s2v_profile_read synchronises the
+ * device, returns total ms and launch counts per class since the previous read, and resets the counters. */
+int s2v_profile_enable(s2v_ctx* ctx, int32_t on);
+int s2v_profile_read(s2v_ctx* ctx, float* ms_by_class, int32_t* launches_by_class, int32_t nclass);
+/* Marks every tensor as loaded on a replica whose arena was filled by a broadcast of s2v_weight_arena. */
+int s2v_mark_weights_loaded(s2v_ctx* ctx);
 
 /* ---- operator-level entry points (used by the parity tests and micro-benchmarks) ------------------------- */
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic */

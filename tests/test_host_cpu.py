@@ -1,0 +1,145 @@
+"""CPU tests of the product's host side: tables vs the reference's golden vectors, scheduler scalars (the kernel
+arithmetic is emulated here in numpy with the product's coefficients and must reproduce the reference bit for bit),
+the C ABI surface, argument validation.  No compute call reaches the GPU library here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+
+
+# ------------------------------------------------------------------------------------------------ tables
+def test_tables_match_reference(s2v):
+    g = load_golden("tables.npz")
+    for snr in (1.0, 3.0):
+        np.testing.assert_array_equal(s2v.tables.alphas_cumprod(snr), g[f"alphas_{snr}"])
+    for n in (3, 10, 50):
+        np.testing.assert_array_equal(s2v.tables.trailing_timesteps(n), g[f"timesteps_{n}"])
+    c, s = s2v.tables.rope_tables(256, 256, 3)
+    np.testing.assert_array_equal(c, g["rope_cos_256x256"])
+    np.testing.assert_array_equal(s, g["rope_sin_256x256"])
+    for hw in ((480, 720), (720, 1280)):
+        c, s = s2v.tables.rope_tables(hw[0], hw[1], 13)
+        np.testing.assert_array_equal(c[::61], g[f"rope_cos_{hw[0]}x{hw[1]}_rows61"])
+        np.testing.assert_array_equal(s[::61], g[f"rope_sin_{hw[0]}x{hw[1]}_rows61"])
+        assert c.shape == ((hw[0] // 16) * (hw[1] // 16) * 14, 64)
+    np.testing.assert_array_equal(s2v.tables.sincos_table(128, 4, 4, 2), g["sincos_128_4x4x2"])
+    np.testing.assert_array_equal(s2v.tables.sincos_table(192, 4, 6, 3), g["sincos_192_6x4x3"])
+    np.testing.assert_array_equal(s2v.tables.sincos_table(1920, 16, 16, 3)[::7], g["sincos_1920_16x16x3_rows7"])
+    assert s2v.tables.crop_region(45, 80) == ((2, 0), (27, 45))   # 720x1280: fractional h grid
+    assert s2v.tables.crop_region(16, 16) == ((0, 8), (30, 38))   # 256x256
+
+
+# ------------------------------------------------------------------------------------------------ schedulers
+def _rnd(x, bf16):
+    """ET<T>::rnd of the kernels: identity for fp32, round-trip through bf16 otherwise (numpy emulation)"""
+    if not bf16:
+        return x.astype(np.float32)
+    return torch.from_numpy(x.astype(np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def _emulate_kernel(c, npred, x, x0_old, noise, bf16):
+    """numpy mirror of sched_step_k (csrc/elementwise.hip) -- every op a separately rounded fp32 op"""
+    f = np.float32
+    u, cc = npred[0:1], npred[1:2]
+    v = (u + f(c.guidance) * (cc - u).astype(f)).astype(f)
+    x0 = (_rnd(x * f(c.c_x0_x), bf16) - (f(c.c_x0_v) * v).astype(f)).astype(f)
+    if c.kind == 0:
+        prev = (_rnd(f(c.a_t) * x, bf16) + (f(c.b_t) * x0).astype(f)).astype(f)
+    else:
+        d = x0
+        if c.kind == 2:
+            d = ((f(c.m3) * x0).astype(f) - (f(c.m4) * x0_old).astype(f)).astype(f)
+        prev = ((_rnd(f(c.m1) * x, bf16) - (f(c.m2) * d).astype(f)).astype(f) + _rnd(f(c.mn) * noise, bf16)).astype(f)
+    return _rnd(prev, bf16), x0
+
+
+@pytest.mark.parametrize("kind", ["ddim", "dpm"])
+@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+@pytest.mark.parametrize("n_steps", [10, 50])
+def test_scheduler_coefficients_reproduce_reference_bits(s2v, kind, dt_name, n_steps):
+    g = load_golden(f"sched_{kind}_{dt_name}_{n_steps}.npz")
+    bf16 = dt_name == "bf16"
+    dt = torch.bfloat16 if bf16 else torch.float32
+    cls = s2v.CogVideoXDDIMScheduler if kind == "ddim" else s2v.CogVideoXDPMScheduler
+    sch = cls(snr_shift_scale=float(g["snr"]))
+    sch.set_timesteps(n_steps)
+    np.testing.assert_array_equal(sch.timesteps.numpy(), g["timesteps"])
+    ids = list(g["step_ids"])
+    with np.errstate(all="ignore"):
+        for i in ids:
+            t = sch.timesteps[i]
+            if kind == "ddim":
+                c = sch.coef(t, dt, 6.0)
+                x0_old = noise = None
+            else:
+                first = i == 0
+                if not first and (i - 1) not in ids:
+                    continue
+                c = sch.coef(t, sch.timesteps[i - 1] if i > 0 else None, first, dt, 6.0)
+                x0_old = g[f"x0_{i-1}"] if not first else None
+                noise = g[f"n2_{i}"] if c.kind == 2 else g[f"n1_{i}"]
+            prev, x0 = _emulate_kernel(c, g[f"noise_pred_{i}"], g[f"lat_in_{i}"], x0_old, noise, bf16)
+            np.testing.assert_array_equal(x0, g[f"x0_{i}"], err_msg=f"x0 step {i}")
+            np.testing.assert_array_equal(prev, g[f"lat_out_{i}"], err_msg=f"latents step {i}")
+
+
+def test_scheduler_protocol_surface(s2v):
+    s = s2v.CogVideoXDDIMScheduler(snr_shift_scale=1.0)
+    assert s.order == 1 and s.init_noise_sigma == 1.0
+    x = torch.zeros(3)
+    assert s.scale_model_input(x, 5) is x
+    with pytest.raises(ValueError):
+        s.set_timesteps(2000)
+    with pytest.raises(ValueError):
+        s.coef(999, torch.float32)  # set_timesteps not called
+    with pytest.raises(NotImplementedError):
+        s2v.CogVideoXDDIMScheduler(prediction_type="epsilon")
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol(s2v):
+    hdr = open(os.path.join(ROOT, "include", "s2v_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(s2v_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    lib = ctypes.CDLL(s2v._lib.LIB_PATH)
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    # everything the Python binding uses is declared in the header
+    bound = set(s2v._lib._SIGS)
+    assert bound <= declared | {"s2v_mark_weights_loaded"}, bound - declared
+    assert s2v.lib().s2v_version().startswith(b"s2v_hip")
+
+
+def test_missing_library_fails_loudly(s2v, monkeypatch):
+    monkeypatch.setattr(s2v._lib, "_lib", None)
+    monkeypatch.setattr(s2v._lib, "LIB_PATH", "/nonexistent/libs2v_hip.so")
+    with pytest.raises(s2v.S2VError, match="no CPU fallback"):
+        s2v._lib.lib()
+
+
+def test_cpu_tensor_is_rejected(s2v):
+    with pytest.raises(s2v.S2VError):
+        s2v._lib.ptr(torch.zeros(4))
+
+
+def test_weight_key_inventory(s2v):
+    cfg5 = s2v.cogvideox_5b()
+    shapes = s2v.weights.state_dict_shapes(cfg5)
+    n = sum(int(np.prod(s)) for s in shapes.values())
+    assert abs(n - 5.570e9) < 0.01e9  # 5.570 B parameters
+    cfg2 = s2v.cogvideox_2b()
+    n2 = sum(int(np.prod(s)) for s in s2v.weights.state_dict_shapes(cfg2).values())
+    assert abs(n2 - 1.694e9) < 0.01e9
+    keys = s2v.weights.lora_target_keys(s2v.tiny())
+    assert "patch_embed.proj.weight" in keys and "transformer_blocks.0.ff.net.0.proj.weight" in keys
+    assert "transformer_blocks.0.norm1.linear.weight" in keys and "norm_out.linear.weight" not in keys
+    # the golden tiny transformer has exactly these keys
+    g = load_golden("transformer_tiny_rope.npz")
+    gk = {k[2:] for k in g if k.startswith("w:")}
+    assert gk == set(s2v.weights.state_dict_shapes(s2v.tiny()))

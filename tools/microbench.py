@@ -1,0 +1,67 @@
+"""Kernel micro-benchmarks at the C3 (CogVideoX-5B, 49x480x720, CFG pair) shapes; prints TFLOP/s per kernel.
+Usage: python tools/microbench.py [gemm] [attn] [ew]"""
+import importlib
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+s2v = importlib.import_module("disentangled-subject-to-vid_amd")
+L = s2v._lib
+DEV = "cuda:0"
+
+
+def timeit(fn, iters=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def bench_gemm():
+    M = 38400
+    for name, N, K, epi in (("qkv", 9216, 3072, 0), ("out", 3072, 3072, 0), ("ff1+gelu", 12288, 3072, 1), ("ff2", 3072, 12288, 0)):
+        A = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
+        W = (torch.randn(N, K, device=DEV) * 0.02).bfloat16()
+        b = torch.zeros(N, device=DEV, dtype=torch.bfloat16)
+        C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        f = lambda: L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, epi, 1, 0, L.stream_ptr()))
+        ms = timeit(f)
+        print(f"gemm {name:9s} M={M} N={N} K={K}: {ms:8.3f} ms  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
+        t = timeit(lambda: torch.matmul(A, W.T), iters=5)
+        print(f"   (hipBLASLt via torch.matmul: {t:8.3f} ms  {2*M*N*K/t/1e9:8.1f} TFLOP/s)", flush=True)
+        del A, W, C
+
+
+def bench_attn():
+    for (B, H, N) in ((2, 48, 19126), (2, 30, 19126), (2, 30, 1250)):
+        D = H * 64
+        qkv = torch.randn(B * N + 64, 3 * D, device=DEV).bfloat16()
+        out = torch.empty(B * N, D, device=DEV, dtype=torch.bfloat16)
+        vt = torch.zeros(B * H * 64 * ((N + 63) // 64 * 64), dtype=torch.bfloat16, device=DEV)
+        f = lambda: L.check(L.lib().s2v_op_attention(L.ptr(qkv), L.ptr(vt), L.ptr(out), B, H, N, 1, 0, L.stream_ptr()))
+        ms = timeit(f, iters=5, warm=2)
+        fl = 4 * B * H * N * N * 64
+        print(f"attn B={B} H={H} N={N}: {ms:8.3f} ms  {fl/ms/1e9:8.1f} TFLOP/s (incl. V^T transpose)", flush=True)
+        q, k, v = (qkv[: B * N, i * D : (i + 1) * D].reshape(B, N, H, 64).transpose(1, 2) for i in range(3))
+        t = timeit(lambda: torch.nn.functional.scaled_dot_product_attention(q, k, v), iters=3, warm=1)
+        print(f"   (torch SDPA: {t:8.3f} ms  {fl/t/1e9:8.1f} TFLOP/s)", flush=True)
+        del qkv, out, vt
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["gemm", "attn"]
+    print(torch.cuda.get_device_name(0), flush=True)
+    if "gemm" in what:
+        bench_gemm()
+    if "attn" in what:
+        bench_attn()
