@@ -42,8 +42,14 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, const
         }
         return;
     }
+    if (EPI == EPI_BIAS_ADD) {
+        const T* r = (const T*)a.R + (size_t)m * a.ldr + n;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (n + i < a.N) y[i] = y[i] + ET<T>::ld(r + i);
+    }
     T* c = (T*)a.C + (size_t)m * a.ldc + n;
-    if (n + 3 < a.N) {
+    if (n + 3 < a.N && (a.ldc & 3) == 0) {
         if (sizeof(T) == 2) {
             u32x2 p;
             p.x = pack2bf(y[0], y[1]);
@@ -65,6 +71,42 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, const
 #define BN 128
 #define BK 64
 #define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand per stage
+
+// element offset of A[m][0] (plain: m*lda; conv: the top-left-front input pixel of output pixel m)
+__device__ __forceinline__ int64_t a_row_base(const GemmArgs& a, int m) {
+    if (!a.conv) return (int64_t)m * a.lda;
+    m = min(m, a.M - 1);
+    const int hw = a.oH * a.oW;
+    const int f = m / hw, rem = m - f * hw;
+    const int y = rem / a.oW, x = rem - y * a.oW;
+    return (((int64_t)f * a.Hp + y) * a.Wp + x) * a.cin;
+}
+// element offset added for column k (plain: k; conv: tap displacement + channel)
+__device__ __forceinline__ int64_t a_k_off(const GemmArgs& a, int k) {
+    if (!a.conv) return k;
+    const int tap = k / a.cin, ci = k - tap * a.cin;
+    const int dt = a.kt == 3 ? tap / 9 : 0;
+    const int r9 = tap - dt * 9;
+    const int dy = r9 / 3, dx = r9 - dy * 3;
+    return (((int64_t)dt * a.Hp + dy) * a.Wp + dx) * a.cin + ci;
+}
+
+// A operand: per-thread row bases (fixed for the whole K loop) + a per-k-step displacement
+__device__ __forceinline__ void stage_tile_a(const bf16_t* __restrict__ g, const int64_t rb[4], int64_t koff, char* lds,
+                                             int tid) {
+    const int wave = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gi = i * 256 + tid;
+        const int row = gi >> 3;
+        const int cp = gi & 7;
+        const int c = cp ^ ((row >> 1) & 7);
+        const bf16_t* src = g + rb[i] + koff + c * 8;
+        char* dst = lds + (i * 256 + wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+}
 
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld, int row0, int k0, char* lds, int tid) {
     // 128 rows x 128 B; thread t of round i owns LDS chunk (i*256+t): row = g>>3, physical 16-B chunk = g&7.
@@ -120,7 +162,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int ti
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int nt = a.K / BK;
-    stage_tile(A, a.lda, m0, 0, smem, tid);
+    int64_t rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rb[i] = a_row_base(a, m0 + ((i * 256 + tid) >> 3));
+    stage_tile_a(A, rb, a_k_off(a, 0), smem, tid);
     stage_tile(W, a.ldw, n0, 0, smem + TILE_BYTES, tid);
     __syncthreads();
 
@@ -128,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int ti
     for (int t = 0; t < nt; ++t) {
         const int cur = t & 1;
         if (t + 1 < nt) {
-            stage_tile(A, a.lda, m0, (t + 1) * BK, smem + (cur ^ 1) * 2 * TILE_BYTES, tid);
+            stage_tile_a(A, rb, a_k_off(a, (t + 1) * BK), smem + (cur ^ 1) * 2 * TILE_BYTES, tid);
             stage_tile(W, a.ldw, n0, (t + 1) * BK, smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES, tid);
         }
         const char* tA = smem + cur * 2 * TILE_BYTES;
@@ -166,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int ti
 
 int launch_gemm_bf16(const GemmArgs& a, int epi, hipStream_t st) {
     S2V_REQUIRE(a.K % BK == 0, "gemm_bf16: K must be a multiple of 64");
-    S2V_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm_bf16: leading dims must be multiples of 8");
+    S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int grid = tiles_m * tiles_n;
     const size_t shmem = 4 * TILE_BYTES;
@@ -179,6 +224,9 @@ int launch_gemm_bf16(const GemmArgs& a, int epi, hipStream_t st) {
             break;
         case EPI_BIAS_GATE_RES:
             hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_GATE_RES>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            break;
+        case EPI_BIAS_ADD:
+            hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_ADD>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
             break;
         default:
             return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
@@ -207,7 +255,7 @@ __global__ __launch_bounds__(256) void gemm_simple_k(const GemmArgs a) {
             const int row = e >> 4, k = e & 15;
             float va = 0.f, vw = 0.f;
             if (k0 + k < a.K) {
-                if (m0 + row < a.M) va = ET<T>::ld(A + (size_t)(m0 + row) * a.lda + k0 + k);
+                if (m0 + row < a.M) va = ET<T>::ld(A + a_row_base(a, m0 + row) + a_k_off(a, k0 + k));
                 if (n0 + row < a.N) vw = ET<T>::ld(W + (size_t)(n0 + row) * a.ldw + k0 + k);
             }
             sA[k][row] = va;
@@ -243,6 +291,7 @@ static int launch_simple_t(const GemmArgs& a, int epi, hipStream_t st) {
         case EPI_BIAS_GATE_RES:
             hipLaunchKernelGGL((gemm_simple_k<T, EPI_BIAS_GATE_RES>), grid, dim3(256), 0, st, a);
             break;
+        case EPI_BIAS_ADD: hipLaunchKernelGGL((gemm_simple_k<T, EPI_BIAS_ADD>), grid, dim3(256), 0, st, a); break;
         default: return s2v_fail(__FILE__, __LINE__, "gemm_simple: bad epilogue", -1);
     }
     S2V_CHECK_HIP(hipGetLastError());
@@ -250,8 +299,7 @@ static int launch_simple_t(const GemmArgs& a, int epi, hipStream_t st) {
 }
 
 int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st) {
-    // vector stores in the epilogue need 4-element aligned rows
-    S2V_REQUIRE(a.ldc % 4 == 0 || epi == EPI_BIAS_GATE_RES, "gemm_simple: ldc must be a multiple of 4");
+    S2V_REQUIRE((a.M + 63) / 64 <= 65535, "gemm_simple: M too large for the generic kernel");
     return dtype == S2V_BF16 ? launch_simple_t<bf16_t>(a, epi, st) : launch_simple_t<float>(a, epi, st);
 }
 

@@ -22,7 +22,15 @@ struct GemmArgs {
     void* X; int ldx;
     const void* gate_vid; const void* gate_txt; int gate_stride;
     int tok_per_batch; int text_len;
+    // EPI_BIAS_ADD: C = rnd(rnd(acc + bias) + R[m][n])  (resnet skip, autoencoder_kl_cogvideox.py:318)
+    const void* R; int ldr;
+    // Implicit-GEMM convolution addressing of A (conv != 0).  A is a zero-bordered channels-last tensor
+    // [frames][Hp][Wp][cin]; output row m = (f, y, x) of an [F][oH][oW] grid; k = (tap, ci) with tap = (dt, dy, dx),
+    // dt in [0,kt), dy,dx in [0,3): A[m][k] = in[f + dt][y + dy][x + dx][ci].  kt = 3: causal conv (frames 0,1 of the
+    // buffer hold the conv cache); kt = 1: per-frame 3x3 conv.  (CogVideoXCausalConv3d, autoencoder_kl_cogvideox.py:120-137)
+    int conv, cin, Hp, Wp, oH, oW, kt;
 };
+enum { EPI_BIAS_ADD = 3 };
 
 int launch_gemm_bf16(const GemmArgs& a, int epi, hipStream_t st);              // MFMA path, bf16 only
 int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st);  // any dtype, any shape
