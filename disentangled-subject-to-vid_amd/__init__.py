@@ -7,4 +7,5 @@ from .engine import S2VEngine  # noqa: F401
 from .schedulers import CogVideoXDDIMScheduler, CogVideoXDPMScheduler  # noqa: F401
 from .transformer import HipCogVideoXAttnProcessor2_0, HipCogVideoXBlock, HipCogVideoXTransformer3DModel  # noqa: F401
 from .pipeline import S2VPipeline  # noqa: F401
+from .vae import HipAutoencoderKLCogVideoX  # noqa: F401
 from . import dist  # noqa: F401

@@ -1,0 +1,411 @@
+// HBM-bound kernels of the CogVideoX 3-D causal VAE decoder (autoencoder_kl_cogvideox.py).  Activations are
+// channels-last: dense [F][H][W][C] between layers, and zero-bordered [frames][H+2][W+2][C] ("padded") as the
+// operand of every 3x3(x3) convolution, so the implicit-GEMM conv (gemm.hip, conv addressing) needs no bounds
+// checks and a 64-channel k-step is one contiguous 128-byte line.  Two leading frames of a causal conv's padded
+// buffer hold its conv_cache (CogVideoXCausalConv3d.forward :128-137).
+//   latent_to_zq      decode_latents' 1/scaling_factor * z, [1,F,C,h,w] -> dense [F][th][tw][C] (tile window)
+//   dense_to_padded   interior copy (conv_in operand)
+//   gn_stats          GroupNorm statistics over (frames, pixels, channels of the group) of one frame batch
+//   snorm_apply       SpatialNorm3D (:167-188): GN(f) * conv_y(zq^) + conv_b(zq^), optional SiLU, written padded
+//   upsample          CogVideoXUpsample3D's nearest x2 (+ time, first-frame rule) (upsampling.py:384-404), padded
+//   to_ncfhw / blend  output layout + the tile cross-fades of tiled_decode (:1284-1298,1437-1447)
+//   postprocess       VideoProcessor.postprocess_video 'np' (video_processor.py:99-113): clamp(x/2+.5) -> [F,H,W,3]
+#define S2V_HOST
+#include "common.h"
+#include "kernels.h"
+#include "vae_kernels.h"
+
+template <typename T> struct V16;
+template <> struct V16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void ld(const float* p, float* v) { f32x4 t = *(const f32x4*)p; v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static __device__ __forceinline__ void st(float* p, const float* v) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
+};
+template <> struct V16<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* v) {
+        u32x4 t = *(const u32x4*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[2 * i] = __uint_as_float(t[i] << 16); v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u); }
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* v) {
+        u32x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+        *(u32x4*)p = t;
+    }
+};
+
+static inline unsigned grid_for(int64_t n, int cap = 1 << 20) {
+    int64_t g = (n + 255) / 256;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void latent_to_zq_k(const T* lat, int F, int C, int h, int w, float inv_sf, T* out, int y0, int x0, int th,
+                               int tw) {
+    const int64_t total = (int64_t)F * th * tw * C;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % tw);
+        const int y = (int)((i / ((int64_t)C * tw)) % th);
+        const int f = (int)(i / ((int64_t)C * tw * th));
+        const float v = ET<T>::ld(lat + (((int64_t)f * C + c) * h + y0 + y) * w + x0 + x);
+        ET<T>::st(out + i, inv_sf * v);
+    }
+}
+int launch_latent_to_zq(const void* lat, int F, int C, int h, int w, float inv_sf, void* out, int y0, int x0, int th,
+                        int tw, int dtype, hipStream_t st) {
+    const int64_t total = (int64_t)F * th * tw * C;
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(latent_to_zq_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)lat, F, C, h, w,
+                           inv_sf, (bf16_t*)out, y0, x0, th, tw);
+    else
+        hipLaunchKernelGGL(latent_to_zq_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)lat, F, C, h, w,
+                           inv_sf, (float*)out, y0, x0, th, tw);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+__global__ void dense_to_padded_k(const T* in, int F, int H, int W, int C, T* out, int f_off) {
+    const int64_t total = (int64_t)F * H * W * C;
+    const int Hp = H + 2, Wp = W + 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % W);
+        const int y = (int)((i / ((int64_t)C * W)) % H);
+        const int f = (int)(i / ((int64_t)C * W * H));
+        out[((((int64_t)(f + f_off)) * Hp + y + 1) * Wp + x + 1) * C + c] = in[i];
+    }
+}
+int launch_dense_to_padded(const void* in, int F, int H, int W, int C, void* out, int f_off, int dtype, hipStream_t st) {
+    const int64_t total = (int64_t)F * H * W * C;
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(dense_to_padded_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)in, F, H, W,
+                           C, (bf16_t*)out, f_off);
+    else
+        hipLaunchKernelGGL(dense_to_padded_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)in, F, H, W, C,
+                           (float*)out, f_off);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm statistics: sums[g] = {sum x, sum x^2} in fp64 over P pixels x (C/G) channels
+#define GN_PIX_PER_BLOCK 512
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_k(const T* x, int64_t P, int C, int G, double* sums) {
+    constexpr int VN = V16<T>::N;
+    __shared__ float s_sum[1024], s_sq[1024];
+    const int tid = threadIdx.x;
+    const int vpp = C / VN;              // 16-byte vectors per pixel
+    const int ppi = 256 / vpp;           // pixels per iteration
+    for (int c = tid; c < C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
+    __syncthreads();
+    const int vi = tid % vpp, pl = tid / vpp;
+    float a[VN], q[VN];
+#pragma unroll
+    for (int e = 0; e < VN; ++e) { a[e] = 0.f; q[e] = 0.f; }
+    const int64_t p0 = (int64_t)blockIdx.x * GN_PIX_PER_BLOCK;
+    const int64_t p1 = min(p0 + GN_PIX_PER_BLOCK, P);
+    if (pl < ppi) {
+        for (int64_t p = p0 + pl; p < p1; p += ppi) {
+            float v[VN];
+            V16<T>::ld(x + p * C + vi * VN, v);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) { a[e] += v[e]; q[e] += v[e] * v[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { atomicAdd(&s_sum[vi * VN + e], a[e]); atomicAdd(&s_sq[vi * VN + e], q[e]); }
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int g = tid; g < G; g += 256) {
+        double s = 0.0, s2 = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += (double)s_sum[c]; s2 += (double)s_sq[c]; }
+        atomicAdd(&sums[2 * g], s);
+        atomicAdd(&sums[2 * g + 1], s2);
+    }
+}
+int launch_gn_stats(const void* x, int64_t P, int C, int G, double* sums, int dtype, hipStream_t st) {
+    const int VN = dtype == S2V_BF16 ? 8 : 4;
+    S2V_REQUIRE(C % VN == 0 && C <= 1024 && 256 % (C / VN) == 0 && C % G == 0, "gn_stats: unsupported channel count");
+    S2V_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * G, st));
+    const unsigned grid = (unsigned)((P + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK);
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(gn_stats_k<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, P, C, G, sums);
+    else
+        hipLaunchKernelGGL(gn_stats_k<float>, dim3(grid), dim3(256), 0, st, (const float*)x, P, C, G, sums);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// nearest-neighbour source frame of torch.nn.functional.interpolate under SpatialNorm3D's first-frame rule (:177-185)
+__device__ __forceinline__ int zq_frame(int f, int Ff, int Fz) {
+    if (Ff > 1 && (Ff & 1)) {
+        if (f == 0) return 0;
+        return 1 + (int)(((int64_t)(f - 1) * (Fz - 1)) / (Ff - 1));
+    }
+    return (int)(((int64_t)f * Fz) / Ff);
+}
+
+// out_padded[f + f_off][y+1][x+1][c] = act( GN(x)[c] * (Wy zq^ + by)[c] + (Wb zq^ + bb)[c] )
+template <typename T>
+__global__ __launch_bounds__(256) void snorm_apply_k(const SNormArgs a) {
+    constexpr int VN = V16<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // wy [Cz][C], wb [Cz][C], mean[G], rstd[G]
+    const int C = a.C, Cz = a.Cz, G = a.G, cpg = C / G;
+    float* wy = lds;
+    float* wb = lds + Cz * C;
+    float* mean = wb + Cz * C;
+    float* rstd = mean + G;
+    for (int i = threadIdx.x; i < Cz * C; i += 256) { wy[i] = a.wy[i]; wb[i] = a.wb[i]; }
+    const double cnt = (double)a.F * a.H * a.W * cpg;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        const double m = a.sums[2 * g] / cnt;
+        const double var = a.sums[2 * g + 1] / cnt - m * m;
+        mean[g] = (float)m;
+        rstd[g] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)a.eps));
+    }
+    __syncthreads();
+    const int vpp = C / VN;
+    const int64_t P = (int64_t)a.F * a.H * a.W;
+    const int64_t total = P * vpp;
+    const int Hp = a.H + 2, Wp = a.W + 2;
+    const T* x = (const T*)a.x;
+    const T* zq = (const T*)a.zq;
+    const T* gw = (const T*)a.gn_w;
+    const T* gb = (const T*)a.gn_b;
+    T* out = (T*)a.out;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int vi = (int)(i % vpp);
+        const int64_t p = i / vpp;
+        const int xx = (int)(p % a.W);
+        const int yy = (int)((p / a.W) % a.H);
+        const int f = (int)(p / ((int64_t)a.W * a.H));
+        const int c0 = vi * VN;
+        float v[VN], g_w[VN], g_b[VN];
+        V16<T>::ld(x + p * C + c0, v);
+        V16<T>::ld(gw + c0, g_w);
+        V16<T>::ld(gb + c0, g_b);
+        const int fz = zq_frame(f, a.F, a.Fz);
+        const int yz = (int)(((int64_t)yy * a.hz) / a.H), xz = (int)(((int64_t)xx * a.wz) / a.W);
+        const T* zp = zq + (((int64_t)fz * a.hz + yz) * a.wz + xz) * Cz;
+        float cy[VN], cb[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { cy[e] = 0.f; cb[e] = 0.f; }
+        for (int j = 0; j < Cz; ++j) {
+            const float z = ET<T>::ld(zp + j);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                cy[e] = fmaf(z, wy[j * C + c0 + e], cy[e]);
+                cb[e] = fmaf(z, wb[j * C + c0 + e], cb[e]);
+            }
+        }
+        float o[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) {
+            const int g = (c0 + e) / cpg;
+            const float n = ET<T>::rnd((v[e] - mean[g]) * rstd[g] * g_w[e] + g_b[e]);
+            const float y = ET<T>::rnd(cy[e] + a.by[c0 + e]);
+            const float b = ET<T>::rnd(cb[e] + a.bb[c0 + e]);
+            float r = ET<T>::rnd(ET<T>::rnd(n * y) + b);
+            if (a.silu) r = ET<T>::rnd(silu_f(r));
+            o[e] = r;
+        }
+        V16<T>::st(out + ((((int64_t)(f + a.f_off)) * Hp + yy + 1) * Wp + xx + 1) * C + c0, o);
+    }
+}
+int launch_snorm_apply(const SNormArgs& a, int dtype, hipStream_t st) {
+    const int VN = dtype == S2V_BF16 ? 8 : 4;
+    S2V_REQUIRE(a.C % VN == 0 && a.C % a.G == 0, "snorm_apply: unsupported channel count");
+    const size_t shmem = sizeof(float) * ((size_t)2 * a.Cz * a.C + 2 * a.G);
+    S2V_REQUIRE(shmem <= 160 * 1024, "snorm_apply: weights do not fit LDS");
+    const int64_t total = (int64_t)a.F * a.H * a.W * (a.C / VN);
+    const unsigned grid = grid_for(total, 2048);
+    if (dtype == S2V_BF16) {
+        if (shmem > 64 * 1024)
+            S2V_CHECK_HIP(hipFuncSetAttribute((const void*)snorm_apply_k<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(snorm_apply_k<bf16_t>, dim3(grid), dim3(256), shmem, st, a);
+    } else {
+        if (shmem > 64 * 1024)
+            S2V_CHECK_HIP(hipFuncSetAttribute((const void*)snorm_apply_k<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        hipLaunchKernelGGL(snorm_apply_k<float>, dim3(grid), dim3(256), shmem, st, a);
+    }
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// nearest x2 in H, W (+ in time with the first-frame rule when compress_time) -> padded [Fo][2H+2][2W+2][C]
+__host__ __device__ inline int upsample_out_frames(int F, int compress_time) {
+    if (!compress_time || F == 1) return F;
+    return (F & 1) ? 1 + 2 * (F - 1) : 2 * F;
+}
+template <typename T>
+__global__ void upsample_k(const T* x, int F, int H, int W, int C, int compress_time, T* out) {
+    constexpr int VN = V16<T>::N;
+    const int Fo = upsample_out_frames(F, compress_time), Ho = 2 * H, Wo = 2 * W;
+    const int vpp = C / VN;
+    const int64_t total = (int64_t)Fo * Ho * Wo * vpp;
+    const int Hp = Ho + 2, Wp = Wo + 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int vi = (int)(i % vpp);
+        const int64_t p = i / vpp;
+        const int xx = (int)(p % Wo);
+        const int yy = (int)((p / Wo) % Ho);
+        const int fo = (int)(p / ((int64_t)Wo * Ho));
+        int fs = fo;
+        if (compress_time && F > 1) fs = (F & 1) ? (fo == 0 ? 0 : 1 + (fo - 1) / 2) : fo / 2;
+        float v[VN];
+        V16<T>::ld(x + ((((int64_t)fs * H + yy / 2) * W) + xx / 2) * C + vi * VN, v);
+        V16<T>::st(out + ((((int64_t)fo * Hp + yy + 1) * Wp) + xx + 1) * C + vi * VN, v);
+    }
+}
+int launch_upsample(const void* x, int F, int H, int W, int C, int compress_time, void* out, int dtype, hipStream_t st) {
+    const int VN = dtype == S2V_BF16 ? 8 : 4;
+    S2V_REQUIRE(C % VN == 0, "upsample: unsupported channel count");
+    const int64_t total = (int64_t)upsample_out_frames(F, compress_time) * 4 * H * W * (C / VN);
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(upsample_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)x, F, H, W, C,
+                           compress_time, (bf16_t*)out);
+    else
+        hipLaunchKernelGGL(upsample_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, F, H, W, C,
+                           compress_time, (float*)out);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dense [F][H][W][Co] -> out[co][f0 + f][y][x] of a [Co][Ftot][H][W] tensor
+template <typename T>
+__global__ void to_ncfhw_k(const T* y, int F, int H, int W, int Co, T* out, int Ftot, int f0) {
+    const int64_t total = (int64_t)F * H * W * Co;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        const int yy = (int)((i / W) % H);
+        const int f = (int)((i / ((int64_t)W * H)) % F);
+        const int co = (int)(i / ((int64_t)W * H * F));
+        out[(((int64_t)co * Ftot + f0 + f) * H + yy) * W + xx] = y[(((int64_t)f * H + yy) * W + xx) * Co + co];
+    }
+}
+int launch_to_ncfhw(const void* y, int F, int H, int W, int Co, void* out, int Ftot, int f0, int dtype, hipStream_t st) {
+    const int64_t total = (int64_t)F * H * W * Co;
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(to_ncfhw_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)y, F, H, W, Co,
+                           (bf16_t*)out, Ftot, f0);
+    else
+        hipLaunchKernelGGL(to_ncfhw_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)y, F, H, W, Co,
+                           (float*)out, Ftot, f0);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// blend_v / blend_h of tiled_decode, in place on tile b ([C][F][Hb][Wb]) from its already-blended neighbour a:
+//   vertical  : b[.., y, :] = a[.., Ha-E+y, :]*(1-y/E) + b[.., y, :]*(y/E),  y < E
+//   horizontal: b[.., :, x] = a[.., :, Wa-E+x]*(1-x/E) + b[.., :, x]*(x/E),  x < E
+// (python-float weights stay fp32 scalars in torch; each product and the sum round to the tensor dtype)
+template <typename T>
+__global__ void blend_k(const T* a, int Ha, int Wa, T* b, int Hb, int Wb, int CF, int E, int vertical) {
+    const int rows = vertical ? E : min(Ha, Hb), cols = vertical ? min(Wa, Wb) : E;
+    const int64_t total = (int64_t)CF * rows * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % cols);
+        const int y = (int)((i / cols) % rows);
+        const int cf = (int)(i / ((int64_t)cols * rows));
+        const int k = vertical ? y : x;
+        const float wb_ = (float)((double)k / (double)E), wa_ = (float)(1.0 - (double)k / (double)E);
+        const int ya = vertical ? Ha - E + y : y, xa = vertical ? x : Wa - E + x;
+        const float va = ET<T>::ld(a + ((int64_t)cf * Ha + ya) * Wa + xa);
+        T* pb = b + ((int64_t)cf * Hb + y) * Wb + x;
+        const float vb = ET<T>::ld(pb);
+        ET<T>::st(pb, ET<T>::rnd(va * wa_) + ET<T>::rnd(vb * wb_));
+    }
+}
+int launch_blend(const void* a, int Ha, int Wa, void* b, int Hb, int Wb, int CF, int E, int vertical, int dtype,
+                 hipStream_t st) {
+    const int64_t total = (int64_t)CF * (vertical ? E : (Ha < Hb ? Ha : Hb)) * (vertical ? (Wa < Wb ? Wa : Wb) : E);
+    if (total <= 0) return 0;
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(blend_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)a, Ha, Wa, (bf16_t*)b,
+                           Hb, Wb, CF, E, vertical);
+    else
+        hipLaunchKernelGGL(blend_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)a, Ha, Wa, (float*)b, Hb,
+                           Wb, CF, E, vertical);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// crop-copy of a tile [CF][Ht][Wt] (first ch x cw pixels) into the frame [CF][H][W] at (y0, x0)
+template <typename T>
+__global__ void paste_k(const T* tile, int Ht, int Wt, int ch, int cw, T* out, int H, int W, int y0, int x0, int CF) {
+    const int64_t total = (int64_t)CF * ch * cw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % cw);
+        const int y = (int)((i / cw) % ch);
+        const int cf = (int)(i / ((int64_t)cw * ch));
+        out[((int64_t)cf * H + y0 + y) * W + x0 + x] = tile[((int64_t)cf * Ht + y) * Wt + x];
+    }
+}
+int launch_paste(const void* tile, int Ht, int Wt, int ch, int cw, void* out, int H, int W, int y0, int x0, int CF,
+                 int dtype, hipStream_t st) {
+    const int64_t total = (int64_t)CF * ch * cw;
+    if (total <= 0) return 0;
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(paste_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)tile, Ht, Wt, ch, cw,
+                           (bf16_t*)out, H, W, y0, x0, CF);
+    else
+        hipLaunchKernelGGL(paste_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)tile, Ht, Wt, ch, cw,
+                           (float*)out, H, W, y0, x0, CF);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// video [C][F][H][W] (model dtype) -> [F][H][W][C] float32, clamp(x/2 + 0.5, 0, 1)
+template <typename T>
+__global__ void postprocess_k(const T* v, int C, int F, int H, int W, float* out) {
+    const int64_t total = (int64_t)C * F * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;  // (f, y, x)
+        const int64_t fhw = (int64_t)F * H * W;
+        float x = ET<T>::ld(v + (int64_t)c * fhw + p);
+        x = ET<T>::rnd(ET<T>::rnd(x / 2.0f) + 0.5f);
+        out[i] = fminf(fmaxf(x, 0.f), 1.f);
+    }
+}
+int launch_postprocess(const void* v, int C, int F, int H, int W, float* out, int dtype, hipStream_t st) {
+    const int64_t total = (int64_t)C * F * H * W;
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(postprocess_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)v, C, F, H, W, out);
+    else
+        hipLaunchKernelGGL(postprocess_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)v, C, F, H, W, out);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// conv weight re-pack: src [cout][cin][kt][3][3] (or [cout][cin][3][3], or 1x1...) -> dst [cout][(dt,dy,dx)][cin]
+template <typename TS, typename TD>
+__global__ void conv_w_repack_k(const TS* src, int cout, int cin, int taps, TD* dst) {
+    const int64_t total = (int64_t)cout * cin * taps;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % cin);
+        const int tap = (int)((i / cin) % taps);
+        const int co = (int)(i / ((int64_t)cin * taps));
+        ET<TD>::st(dst + i, ET<TS>::ld(src + ((int64_t)co * cin + ci) * taps + tap));
+    }
+}
+int launch_conv_w_repack(const void* src, int sdt, int cout, int cin, int taps, void* dst, int ddt, hipStream_t st) {
+    const int64_t total = (int64_t)cout * cin * taps;
+    dim3 g(grid_for(total));
+#define RP(TS, TD) hipLaunchKernelGGL((conv_w_repack_k<TS, TD>), g, dim3(256), 0, st, (const TS*)src, cout, cin, taps, (TD*)dst)
+    if (sdt == S2V_F32 && ddt == S2V_F32) RP(float, float);
+    else if (sdt == S2V_F32 && ddt == S2V_BF16) RP(float, bf16_t);
+    else if (sdt == S2V_BF16 && ddt == S2V_F32) RP(bf16_t, float);
+    else RP(bf16_t, bf16_t);
+#undef RP
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}

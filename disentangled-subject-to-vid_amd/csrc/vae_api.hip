@@ -1,0 +1,506 @@
+// C ABI of the CogVideoX 3-D causal VAE decode (include/s2v_hip.h, s2v_vae_*): weight ingest / re-packing, buffer plan,
+// and the launch sequence of AutoencoderKLCogVideoX.decode (autoencoder_kl_cogvideox.py:1231-1282, 1374-1455).
+#define S2V_HOST
+#include "common.h"
+#include "kernels.h"
+#include "vae_kernels.h"
+#include "../../include/s2v_hip.h"
+
+#include <cmath>
+#include <cstdio>
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+static inline int64_t rup64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+struct ConvL {
+    int cin = 0, cout = 0, kt = 3;      // kt: 3 causal 3x3x3, 1 per-frame 3x3, 0 pointwise 1x1x1
+    char* w = nullptr; char* b = nullptr;  // repacked [cout_pad][taps*cin], [cout]
+    char* pad = nullptr; int64_t pad_bytes = 0;  // own zero-bordered operand buffer (conv cache in frames 0,1 when kt==3)
+    int level = 0;
+};
+struct SNormL {
+    int C = 0;
+    char* gn_w = nullptr; char* gn_b = nullptr;
+    float *wy = nullptr, *by = nullptr, *wb = nullptr, *bb = nullptr;
+};
+struct ResnetL { SNormL n1, n2; ConvL c1, c2, sc; bool has_sc = false; int cin = 0, cout = 0; };
+struct StageL { std::vector<ResnetL> res; bool has_up = false; ConvL up; int compress_time = 0; };
+
+struct VSlot { int kind; void* dst; int64_t d0, d1, taps; bool loaded; };  // kind 0 vector(model dtype) 1 conv repack 2 snorm W^T fp32 3 fp32 vector
+
+struct s2v_vae {
+    s2v_vae_config cfg;
+    int dtype = 0, esz = 0, G = 0, Cz = 0;
+    bool mfma = false, finalized = false;
+    ConvL conv_in, conv_out;
+    SNormL norm_out;
+    std::vector<StageL> stages;
+    std::unordered_map<std::string, VSlot> slots;
+    std::vector<void*> allocs;
+    // geometry-dependent
+    int th = 0, tw = 0;        // allocated tile capacity (latent)
+    int cur_h = 0, cur_w = 0;  // layout the zero borders are currently valid for
+    int fmax[8] = {0};
+    char* dense[3] = {nullptr, nullptr, nullptr};
+    int64_t dense_bytes = 0;
+    char* zq = nullptr;
+    double* sums = nullptr;
+    std::vector<void*> geo_allocs;
+    std::vector<char*> tiles; std::vector<int> tile_h, tile_w;
+    int tiles_F = 0;
+};
+
+static int vfail(const char* m) { return s2v_fail(__FILE__, __LINE__, m, -1); }
+
+template <typename T>
+static int dmalloc(s2v_vae* v, T** p, int64_t bytes, bool geo = false) {
+    void* q = nullptr;
+    S2V_CHECK_HIP(hipMalloc(&q, (size_t)(bytes > 0 ? bytes : 16)));
+    S2V_CHECK_HIP(hipMemset(q, 0, (size_t)(bytes > 0 ? bytes : 16)));
+    (geo ? v->geo_allocs : v->allocs).push_back(q);
+    *p = (T*)q;
+    return 0;
+}
+
+static int make_conv(s2v_vae* v, ConvL& c, const std::string& name, int cin, int cout, int kt, int level) {
+    c.cin = cin; c.cout = cout; c.kt = kt; c.level = level;
+    const int taps = kt == 3 ? 27 : (kt == 1 ? 9 : 1);
+    S2V_TRY(dmalloc(v, &c.w, rup64(cout, 128) * taps * cin * v->esz));
+    S2V_TRY(dmalloc(v, &c.b, (int64_t)cout * v->esz));
+    v->slots[name + ".weight"] = VSlot{1, c.w, cout, cin, taps, false};
+    v->slots[name + ".bias"] = VSlot{0, c.b, cout, 1, 1, false};
+    return 0;
+}
+static int make_snorm(s2v_vae* v, SNormL& n, const std::string& name, int C) {
+    n.C = C;
+    const int Cz = v->Cz;
+    S2V_TRY(dmalloc(v, &n.gn_w, (int64_t)C * v->esz));
+    S2V_TRY(dmalloc(v, &n.gn_b, (int64_t)C * v->esz));
+    S2V_TRY(dmalloc(v, &n.wy, (int64_t)C * Cz * 4));
+    S2V_TRY(dmalloc(v, &n.wb, (int64_t)C * Cz * 4));
+    S2V_TRY(dmalloc(v, &n.by, (int64_t)C * 4));
+    S2V_TRY(dmalloc(v, &n.bb, (int64_t)C * 4));
+    v->slots[name + ".norm_layer.weight"] = VSlot{0, n.gn_w, C, 1, 1, false};
+    v->slots[name + ".norm_layer.bias"] = VSlot{0, n.gn_b, C, 1, 1, false};
+    v->slots[name + ".conv_y.conv.weight"] = VSlot{2, n.wy, C, Cz, 1, false};
+    v->slots[name + ".conv_b.conv.weight"] = VSlot{2, n.wb, C, Cz, 1, false};
+    v->slots[name + ".conv_y.conv.bias"] = VSlot{3, n.by, C, 1, 1, false};
+    v->slots[name + ".conv_b.conv.bias"] = VSlot{3, n.bb, C, 1, 1, false};
+    return 0;
+}
+static int make_resnet(s2v_vae* v, ResnetL& r, const std::string& name, int cin, int cout, int level) {
+    r.cin = cin; r.cout = cout; r.has_sc = cin != cout;
+    S2V_TRY(make_snorm(v, r.n1, name + ".norm1", cin));
+    S2V_TRY(make_conv(v, r.c1, name + ".conv1.conv", cin, cout, 3, level));
+    S2V_TRY(make_snorm(v, r.n2, name + ".norm2", cout));
+    S2V_TRY(make_conv(v, r.c2, name + ".conv2.conv", cout, cout, 3, level));
+    if (r.has_sc) S2V_TRY(make_conv(v, r.sc, name + ".conv_shortcut", cin, cout, 0, level));
+    return 0;
+}
+
+extern "C" void s2v_vae_destroy(s2v_vae* v) {
+    if (!v) return;
+    (void)hipDeviceSynchronize();
+    for (void* p : v->allocs) (void)hipFree(p);
+    for (void* p : v->geo_allocs) (void)hipFree(p);
+    for (char* p : v->tiles) (void)hipFree(p);
+    delete v;
+}
+
+extern "C" int s2v_vae_create(const s2v_vae_config* cfg, s2v_vae** out) {
+    S2V_REQUIRE(cfg && out, "s2v_vae_create: null argument");
+    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_vae_create: unsupported dtype");
+    S2V_REQUIRE(cfg->num_blocks >= 1 && cfg->num_blocks <= 6, "s2v_vae_create: 1..6 blocks");
+    s2v_vae* v = new s2v_vae();
+    v->cfg = *cfg;
+    v->dtype = cfg->dtype;
+    v->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
+    v->G = cfg->norm_num_groups;
+    v->Cz = cfg->latent_channels;
+    v->mfma = cfg->dtype == S2V_DTYPE_BF16 && !cfg->force_simple;
+    const int nb = cfg->num_blocks;
+    // decoder channel plan = reversed block_out_channels (autoencoder_kl_cogvideox.py:871-915)
+    std::vector<int> rc(nb);
+    for (int i = 0; i < nb; ++i) rc[i] = cfg->block_out_channels[nb - 1 - i];
+    const int tlevel = (int)std::lround(std::log2((double)cfg->temporal_compression_ratio));
+    int r = make_conv(v, v->conv_in, "decoder.conv_in.conv", v->Cz, rc[0], 3, 0);
+    v->stages.resize(nb + 1);
+    char nm[128];
+    if (!r) {
+        v->stages[0].res.resize(2);
+        for (int i = 0; i < 2 && !r; ++i) {
+            snprintf(nm, sizeof(nm), "decoder.mid_block.resnets.%d", i);
+            r = make_resnet(v, v->stages[0].res[i], nm, rc[0], rc[0], 0);
+        }
+    }
+    int prev = rc[0], level = 0;
+    for (int b = 0; b < nb && !r; ++b) {
+        StageL& s = v->stages[b + 1];
+        s.res.resize(cfg->layers_per_block + 1);
+        for (int i = 0; i <= cfg->layers_per_block && !r; ++i) {
+            snprintf(nm, sizeof(nm), "decoder.up_blocks.%d.resnets.%d", b, i);
+            r = make_resnet(v, s.res[i], nm, i == 0 ? prev : rc[b], rc[b], level);
+        }
+        prev = rc[b];
+        s.has_up = b != nb - 1;
+        s.compress_time = b < tlevel;
+        if (s.has_up && !r) {
+            snprintf(nm, sizeof(nm), "decoder.up_blocks.%d.upsamplers.0.conv", b);
+            r = make_conv(v, s.up, nm, rc[b], rc[b], 1, level + 1);
+            level++;
+        }
+    }
+    if (!r) r = make_snorm(v, v->norm_out, "decoder.norm_out", rc[nb - 1]);
+    if (!r) r = make_conv(v, v->conv_out, "decoder.conv_out.conv", rc[nb - 1], cfg->out_channels, 3, level);
+    if (!r) r = dmalloc(v, &v->sums, sizeof(double) * 2 * v->G);
+    if (r) { s2v_vae_destroy(v); return r; }
+    *out = v;
+    return 0;
+}
+
+template <typename TS>
+__global__ void to_f32_transposed_k(const TS* src, int rows, int cols, float* dst) {  // dst[c][r] = src[r][c]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int r = i / cols, c = i - r * cols;
+    dst[(size_t)c * rows + r] = ET<TS>::ld(src + i);
+}
+
+extern "C" int s2v_vae_load_weight(s2v_vae* v, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
+                                   int32_t src_dtype, s2v_stream stream) {
+    S2V_REQUIRE(v && name && dev_ptr && shape, "s2v_vae_load_weight: null argument");
+    S2V_REQUIRE(src_dtype == S2V_DTYPE_F32 || src_dtype == S2V_DTYPE_BF16, "s2v_vae_load_weight: unsupported dtype");
+    auto it = v->slots.find(name);
+    if (it == v->slots.end()) {
+        std::string m = std::string("s2v_vae_load_weight: unknown tensor name: ") + name;
+        return s2v_fail(__FILE__, __LINE__, m.c_str(), -3);
+    }
+    VSlot& s = it->second;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    if (n != s.d0 * s.d1 * s.taps || shape[0] != s.d0) {
+        std::string m = std::string("s2v_vae_load_weight: shape mismatch for ") + name;
+        return s2v_fail(__FILE__, __LINE__, m.c_str(), -3);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (s.kind == 0) S2V_TRY(launch_convert(dev_ptr, src_dtype, s.dst, v->dtype, n, st));
+    else if (s.kind == 3) S2V_TRY(launch_convert(dev_ptr, src_dtype, s.dst, S2V_F32, n, st));
+    else if (s.kind == 1) S2V_TRY(launch_conv_w_repack(dev_ptr, src_dtype, (int)s.d0, (int)s.d1, (int)s.taps, s.dst, v->dtype, st));
+    else {
+        // the reference holds conv_y / conv_b in the model dtype: round first, then widen
+        const int tot = (int)n;
+        if (src_dtype == S2V_DTYPE_BF16 || v->dtype == S2V_DTYPE_F32) {
+            if (src_dtype == S2V_DTYPE_BF16)
+                hipLaunchKernelGGL(to_f32_transposed_k<bf16_t>, dim3((tot + 255) / 256), dim3(256), 0, st, (const bf16_t*)dev_ptr, (int)s.d0, (int)s.d1, (float*)s.dst);
+            else
+                hipLaunchKernelGGL(to_f32_transposed_k<float>, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)dev_ptr, (int)s.d0, (int)s.d1, (float*)s.dst);
+        } else {
+            bf16_t* tmp = nullptr;
+            S2V_CHECK_HIP(hipMalloc((void**)&tmp, sizeof(bf16_t) * n));
+            int r = launch_convert(dev_ptr, src_dtype, tmp, S2V_BF16, n, st);
+            if (!r) hipLaunchKernelGGL(to_f32_transposed_k<bf16_t>, dim3((tot + 255) / 256), dim3(256), 0, st, tmp, (int)s.d0, (int)s.d1, (float*)s.dst);
+            (void)hipStreamSynchronize(st);
+            (void)hipFree(tmp);
+            if (r) return r;
+        }
+        S2V_CHECK_HIP(hipGetLastError());
+    }
+    if (s.kind == 3 && v->dtype == S2V_DTYPE_BF16 && src_dtype == S2V_DTYPE_F32) {
+        // bias held in bf16 by the reference: round through the model dtype
+        bf16_t* tmp = nullptr;
+        S2V_CHECK_HIP(hipMalloc((void**)&tmp, sizeof(bf16_t) * n));
+        int r = launch_convert(dev_ptr, src_dtype, tmp, S2V_BF16, n, st);
+        if (!r) r = launch_convert(tmp, S2V_BF16, s.dst, S2V_F32, n, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(tmp);
+        if (r) return r;
+    }
+    s.loaded = true;
+    return 0;
+}
+
+extern "C" int s2v_vae_finalize(s2v_vae* v) {
+    S2V_REQUIRE(v, "null vae");
+    for (auto& kv : v->slots)
+        if (!kv.second.loaded) {
+            std::string m = std::string("s2v_vae_finalize: tensor was never loaded: ") + kv.first;
+            return s2v_fail(__FILE__, __LINE__, m.c_str(), -3);
+        }
+    v->finalized = true;
+    return 0;
+}
+
+// ---- geometry ------------------------------------------------------------------------------------------------
+static int up_frames(int F, int ct) { return (!ct || F == 1) ? F : ((F & 1) ? 1 + 2 * (F - 1) : 2 * F); }
+
+static void for_each_conv(s2v_vae* v, const std::function<void(ConvL&)>& fn) {
+    fn(v->conv_in);
+    for (auto& s : v->stages) {
+        for (auto& r : s.res) { fn(r.c1); fn(r.c2); }
+        if (s.has_up) fn(s.up);
+    }
+    fn(v->conv_out);
+}
+
+static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max) {
+    if (v->th >= th && v->tw >= tw && v->fmax[0] >= fz_max) return 0;
+    S2V_CHECK_HIP(hipDeviceSynchronize());
+    for (void* p : v->geo_allocs) (void)hipFree(p);
+    v->geo_allocs.clear();
+    th = th > v->th ? th : v->th;
+    tw = tw > v->tw ? tw : v->tw;
+    fz_max = fz_max > v->fmax[0] ? fz_max : v->fmax[0];
+    v->th = th; v->tw = tw;
+    // frames per level
+    int f = fz_max, lvl = 0;
+    v->fmax[0] = f;
+    for (size_t s = 1; s < v->stages.size(); ++s)
+        if (v->stages[s].has_up) { f = up_frames(f, v->stages[s].compress_time); v->fmax[++lvl] = f; }
+    int rc = 0;
+    int64_t dmax = 0;
+    for_each_conv(v, [&](ConvL& c) {
+        const int64_t H = (int64_t)th << c.level, W = (int64_t)tw << c.level;
+        const int F = v->fmax[c.level] + (c.kt == 3 ? 2 : 0);
+        c.pad_bytes = (int64_t)F * (H + 2) * (W + 2) * c.cin * v->esz + 1024;
+        if (!rc) rc = dmalloc(v, &c.pad, c.pad_bytes, true);
+        const int64_t d = (int64_t)v->fmax[c.level] * H * W * (c.cin > c.cout ? c.cin : c.cout) * v->esz;
+        dmax = d > dmax ? d : dmax;
+    });
+    if (rc) return rc;
+    v->dense_bytes = dmax + (int64_t)256 * 1024 * v->esz;  // + one 128-row MFMA tile of slack
+    for (int i = 0; i < 3; ++i) S2V_TRY(dmalloc(v, &v->dense[i], v->dense_bytes, true));
+    S2V_TRY(dmalloc(v, &v->zq, (int64_t)fz_max * th * tw * v->Cz * v->esz + 64, true));
+    v->cur_h = v->cur_w = 0;
+    return 0;
+}
+
+static int set_layout(s2v_vae* v, int h, int w, hipStream_t st) {
+    if (v->cur_h == h && v->cur_w == w) return 0;
+    int rc = 0;
+    for_each_conv(v, [&](ConvL& c) {
+        if (!rc && hipMemsetAsync(c.pad, 0, (size_t)c.pad_bytes, st) != hipSuccess) rc = -2;
+    });
+    if (rc) return vfail("memset failed");
+    v->cur_h = h; v->cur_w = w;
+    return 0;
+}
+
+// ---- launch sequences --------------------------------------------------------------------------------------------
+static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int epi, const void* resid, void* out,
+                    hipStream_t st) {
+    const int64_t fb = (int64_t)(H + 2) * (W + 2) * c.cin * v->esz;
+    if (c.kt == 3 && first) {
+        S2V_CHECK_HIP(hipMemcpyAsync(c.pad, c.pad + 2 * fb, fb, hipMemcpyDeviceToDevice, st));
+        S2V_CHECK_HIP(hipMemcpyAsync(c.pad + fb, c.pad + 2 * fb, fb, hipMemcpyDeviceToDevice, st));
+    }
+    const int taps = c.kt == 3 ? 27 : 9;
+    GemmArgs g{};
+    g.A = c.pad; g.W = c.w; g.ldw = taps * c.cin; g.bias = c.b; g.C = out; g.ldc = c.cout;
+    g.M = F * H * W; g.N = c.cout; g.K = taps * c.cin;
+    g.R = resid; g.ldr = c.cout;
+    g.conv = 1; g.cin = c.cin; g.Hp = H + 2; g.Wp = W + 2; g.oH = H; g.oW = W; g.kt = c.kt;
+    if (v->mfma && c.cin % 64 == 0 && c.cout >= 32) S2V_TRY(launch_gemm_bf16(g, epi, st));
+    else S2V_TRY(launch_gemm_simple(g, epi, v->dtype, st));
+    if (c.kt == 3) {
+        S2V_CHECK_HIP(hipMemcpyAsync(c.pad, c.pad + (int64_t)F * fb, fb, hipMemcpyDeviceToDevice, st));
+        S2V_CHECK_HIP(hipMemcpyAsync(c.pad + fb, c.pad + (int64_t)(F + 1) * fb, fb, hipMemcpyDeviceToDevice, st));
+    }
+    return 0;
+}
+
+static int run_snorm(s2v_vae* v, const SNormL& n, const void* x, int F, int H, int W, int Fz, int hz, int wz, void* out_pad,
+                     int f_off, hipStream_t st) {
+    S2V_TRY(launch_gn_stats(x, (int64_t)F * H * W, n.C, v->G, v->sums, v->dtype, st));
+    SNormArgs a{};
+    a.x = x; a.F = F; a.H = H; a.W = W; a.C = n.C; a.G = v->G; a.sums = v->sums; a.eps = v->cfg.norm_eps;
+    a.gn_w = n.gn_w; a.gn_b = n.gn_b; a.wy = n.wy; a.by = n.by; a.wb = n.wb; a.bb = n.bb;
+    a.zq = v->zq; a.Fz = Fz; a.hz = hz; a.wz = wz; a.Cz = v->Cz; a.out = out_pad; a.f_off = f_off; a.silu = 1;
+    return launch_snorm_apply(a, v->dtype, st);
+}
+
+// one decoder pass over a frame batch of `Fz` latent frames of an (h x w) latent window; writes its output frames
+static int decode_batch(s2v_vae* v, int Fz, int h, int w, bool first, char* dst, int Ftot, int f0, int* frames_out,
+                        hipStream_t st) {
+    int cur = 0, t1 = 1, t2 = 2;
+    int F = Fz, H = h, W = w;
+    S2V_TRY(launch_dense_to_padded(v->zq, Fz, h, w, v->Cz, v->conv_in.pad, 2, v->dtype, st));
+    S2V_TRY(run_conv(v, v->conv_in, F, H, W, first, EPI_BIAS, nullptr, v->dense[cur], st));
+    for (auto& s : v->stages) {
+        for (auto& r : s.res) {
+            S2V_TRY(run_snorm(v, r.n1, v->dense[cur], F, H, W, Fz, h, w, r.c1.pad, 2, st));
+            S2V_TRY(run_conv(v, r.c1, F, H, W, first, EPI_BIAS, nullptr, v->dense[t1], st));
+            S2V_TRY(run_snorm(v, r.n2, v->dense[t1], F, H, W, Fz, h, w, r.c2.pad, 2, st));
+            if (r.has_sc) {
+                GemmArgs g{};
+                g.A = v->dense[cur]; g.lda = r.cin; g.W = r.sc.w; g.ldw = r.cin; g.bias = r.sc.b;
+                g.C = v->dense[t2]; g.ldc = r.cout; g.M = F * H * W; g.N = r.cout; g.K = r.cin;
+                if (v->mfma && r.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, EPI_BIAS, st));
+                else S2V_TRY(launch_gemm_simple(g, EPI_BIAS, v->dtype, st));
+                S2V_TRY(run_conv(v, r.c2, F, H, W, first, EPI_BIAS_ADD, v->dense[t2], v->dense[t2], st));
+                std::swap(cur, t2);
+            } else {
+                S2V_TRY(run_conv(v, r.c2, F, H, W, first, EPI_BIAS_ADD, v->dense[cur], v->dense[cur], st));
+            }
+        }
+        if (s.has_up) {
+            S2V_TRY(launch_upsample(v->dense[cur], F, H, W, s.up.cin, s.compress_time, s.up.pad, v->dtype, st));
+            F = up_frames(F, s.compress_time); H *= 2; W *= 2;
+            S2V_TRY(run_conv(v, s.up, F, H, W, first, EPI_BIAS, nullptr, v->dense[t1], st));
+            std::swap(cur, t1);
+        }
+    }
+    S2V_TRY(run_snorm(v, v->norm_out, v->dense[cur], F, H, W, Fz, h, w, v->conv_out.pad, 2, st));
+    S2V_TRY(run_conv(v, v->conv_out, F, H, W, first, EPI_BIAS, nullptr, v->dense[t1], st));
+    S2V_TRY(launch_to_ncfhw(v->dense[t1], F, H, W, v->cfg.out_channels, dst, Ftot, f0, v->dtype, st));
+    *frames_out = F;
+    return 0;
+}
+
+struct Batch { int s, e; };
+static std::vector<Batch> frame_batches(int F) {  // autoencoder_kl_cogvideox.py:1237-1245 (num_latent_frames_batch_size = 2)
+    const int fbs = 2;
+    const int nb = F / fbs > 1 ? F / fbs : 1, rem = F % fbs;
+    std::vector<Batch> b;
+    for (int i = 0; i < nb; ++i) b.push_back({fbs * i + (i == 0 ? 0 : rem), std::min(fbs * (i + 1) + rem, F)});
+    return b;
+}
+static int out_frames_of(s2v_vae* v, int F) {
+    int tot = 0;
+    for (auto b : frame_batches(F)) {
+        int f = b.e - b.s;
+        for (size_t s = 1; s < v->stages.size(); ++s)
+            if (v->stages[s].has_up) f = up_frames(f, v->stages[s].compress_time);
+        tot += f;
+    }
+    return tot;
+}
+static int spatial_scale(s2v_vae* v) { return 1 << (v->cfg.num_blocks - 1); }
+
+struct TileGeo { int tl_h, tl_w, ov_h, ov_w, bl_h, bl_w, lim_h, lim_w; };
+static TileGeo tile_geo(s2v_vae* v) {  // :1102-1114, 1400-1406 incl. the int() truncations
+    TileGeo t;
+    const int ts_h = v->cfg.sample_height / 2, ts_w = v->cfg.sample_width / 2, sc = spatial_scale(v);
+    t.tl_h = (int)((double)ts_h / sc); t.tl_w = (int)((double)ts_w / sc);
+    t.ov_h = (int)(t.tl_h * (1.0 - 1.0 / 6.0)); t.ov_w = (int)(t.tl_w * (1.0 - 1.0 / 5.0));
+    t.bl_h = (int)(ts_h * (1.0 / 6.0)); t.bl_w = (int)(ts_w * (1.0 / 5.0));
+    t.lim_h = ts_h - t.bl_h; t.lim_w = ts_w - t.bl_w;
+    return t;
+}
+static bool use_tiles(s2v_vae* v, int h, int w, int tiling) {
+    TileGeo t = tile_geo(v);
+    return tiling && (w > t.tl_w || h > t.tl_h);
+}
+
+extern "C" int s2v_vae_out_shape(s2v_vae* v, int32_t F, int32_t h, int32_t w, int32_t tiling, int32_t* Fo, int32_t* Ho,
+                                 int32_t* Wo) {
+    S2V_REQUIRE(v && Fo && Ho && Wo && F >= 1 && h >= 1 && w >= 1, "s2v_vae_out_shape: bad argument");
+    *Fo = out_frames_of(v, F);
+    const int sc = spatial_scale(v);
+    if (!use_tiles(v, h, w, tiling)) { *Ho = h * sc; *Wo = w * sc; return 0; }
+    TileGeo t = tile_geo(v);
+    S2V_REQUIRE(t.ov_h > 0 && t.ov_w > 0, "s2v_vae_out_shape: degenerate tile overlap");
+    int H = 0, W = 0;
+    for (int i = 0; i < h; i += t.ov_h) H += std::min(std::min(t.tl_h, h - i) * sc, t.lim_h);
+    for (int j = 0; j < w; j += t.ov_w) W += std::min(std::min(t.tl_w, w - j) * sc, t.lim_w);
+    *Ho = H; *Wo = W;
+    return 0;
+}
+
+static int decode_window(s2v_vae* v, const char* lat, int F, int h, int w, int y0, int x0, int th, int tw, char* dst,
+                         int Ftot, int scaled, hipStream_t st) {
+    S2V_TRY(set_layout(v, th, tw, st));
+    const float inv_sf = scaled ? (float)(1.0 / (double)v->cfg.scaling_factor) : 1.0f;
+    int f0 = 0;
+    bool first = true;
+    for (auto b : frame_batches(F)) {
+        const int Fz = b.e - b.s;
+        S2V_TRY(launch_latent_to_zq(lat + (int64_t)b.s * v->Cz * h * w * v->esz, Fz, v->Cz, h, w, inv_sf, v->zq, y0, x0, th,
+                                    tw, v->dtype, st));
+        int fo = 0;
+        S2V_TRY(decode_batch(v, Fz, th, tw, first, dst, Ftot, f0, &fo, st));
+        f0 += fo;
+        first = false;
+    }
+    return 0;
+}
+
+extern "C" int s2v_vae_decode(s2v_vae* v, const void* latents, int32_t F, int32_t h, int32_t w, int32_t tiling,
+                              int32_t scaled, void* out, s2v_stream stream) {
+    S2V_REQUIRE(v && latents && out, "s2v_vae_decode: null argument");
+    S2V_REQUIRE(v->finalized, "s2v_vae_decode: weights not finalized");
+    S2V_REQUIRE(F >= 1 && h >= 1 && w >= 1, "s2v_vae_decode: bad geometry");
+    hipStream_t st = (hipStream_t)stream;
+    const int sc = spatial_scale(v);
+    const int Ftot = out_frames_of(v, F);
+    int fz_max = 0;
+    for (auto b : frame_batches(F)) fz_max = std::max(fz_max, b.e - b.s);
+    if (!use_tiles(v, h, w, tiling)) {
+        S2V_TRY(prepare_tile_capacity(v, h, w, fz_max));
+        return decode_window(v, (const char*)latents, F, h, w, 0, 0, h, w, (char*)out, Ftot, scaled, st);
+    }
+    TileGeo t = tile_geo(v);
+    S2V_REQUIRE(t.ov_h > 0 && t.ov_w > 0, "s2v_vae_decode: degenerate tile overlap");
+    S2V_TRY(prepare_tile_capacity(v, std::min(t.tl_h, h), std::min(t.tl_w, w), fz_max));
+    std::vector<int> is, js;
+    for (int i = 0; i < h; i += t.ov_h) is.push_back(i);
+    for (int j = 0; j < w; j += t.ov_w) js.push_back(j);
+    const size_t nt = is.size() * js.size();
+    const int C = v->cfg.out_channels;
+    // per-tile outputs [C][Ftot][8 th][8 tw] (re-allocated only when the tiling changes)
+    bool realloc_tiles = v->tiles.size() != nt || v->tiles_F != Ftot;
+    for (size_t k = 0; !realloc_tiles && k < nt; ++k) {
+        const int th = std::min(t.tl_h, h - is[k / js.size()]), tw = std::min(t.tl_w, w - js[k % js.size()]);
+        if (v->tile_h[k] != th * sc || v->tile_w[k] != tw * sc) realloc_tiles = true;
+    }
+    if (realloc_tiles) {
+        S2V_CHECK_HIP(hipDeviceSynchronize());
+        for (char* p : v->tiles) (void)hipFree(p);
+        v->tiles.assign(nt, nullptr); v->tile_h.assign(nt, 0); v->tile_w.assign(nt, 0);
+        for (size_t k = 0; k < nt; ++k) {
+            const int th = std::min(t.tl_h, h - is[k / js.size()]), tw = std::min(t.tl_w, w - js[k % js.size()]);
+            v->tile_h[k] = th * sc; v->tile_w[k] = tw * sc;
+            S2V_CHECK_HIP(hipMalloc((void**)&v->tiles[k], (size_t)C * Ftot * th * sc * tw * sc * v->esz));
+        }
+        v->tiles_F = Ftot;
+    }
+    for (size_t k = 0; k < nt; ++k) {
+        const int i = is[k / js.size()], j = js[k % js.size()];
+        S2V_TRY(decode_window(v, (const char*)latents, F, h, w, i, j, v->tile_h[k] / sc, v->tile_w[k] / sc, v->tiles[k], Ftot, scaled, st));
+    }
+    // raster-order in-place blends, then crop + concatenate (:1437-1450)
+    int32_t Fo, Ho, Wo;
+    S2V_TRY(s2v_vae_out_shape(v, F, h, w, 1, &Fo, &Ho, &Wo));
+    int y0 = 0;
+    for (size_t r = 0; r < is.size(); ++r) {
+        int x0 = 0, ch = 0;
+        for (size_t c = 0; c < js.size(); ++c) {
+            const size_t k = r * js.size() + c;
+            const int Ht = v->tile_h[k], Wt = v->tile_w[k];
+            if (r > 0) {
+                const size_t ka = (r - 1) * js.size() + c;
+                const int E = std::min(std::min(v->tile_h[ka], Ht), t.bl_h);
+                S2V_TRY(launch_blend(v->tiles[ka], v->tile_h[ka], v->tile_w[ka], v->tiles[k], Ht, Wt, C * Ftot, E, 1, v->dtype, st));
+            }
+            if (c > 0) {
+                const size_t ka = k - 1;
+                const int E = std::min(std::min(v->tile_w[ka], Wt), t.bl_w);
+                S2V_TRY(launch_blend(v->tiles[ka], v->tile_h[ka], v->tile_w[ka], v->tiles[k], Ht, Wt, C * Ftot, E, 0, v->dtype, st));
+            }
+            ch = std::min(Ht, t.lim_h);
+            const int cw = std::min(Wt, t.lim_w);
+            S2V_TRY(launch_paste(v->tiles[k], Ht, Wt, ch, cw, out, Ho, Wo, y0, x0, C * Ftot, v->dtype, st));
+            x0 += cw;
+        }
+        y0 += ch;
+    }
+    return 0;
+}
+
+extern "C" int s2v_vae_postprocess(const void* video, int32_t C, int32_t F, int32_t H, int32_t W, float* out, int32_t dtype,
+                                   s2v_stream stream) {
+    S2V_REQUIRE(video && out, "s2v_vae_postprocess: null argument");
+    return launch_postprocess(video, C, F, H, W, out, dtype, (hipStream_t)stream);
+}

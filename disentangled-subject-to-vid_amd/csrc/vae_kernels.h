@@ -1,0 +1,28 @@
+// launchers of csrc/vae.hip
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct SNormArgs {
+    const void* x; int F, H, W, C, G;       // dense [F][H][W][C]
+    const double* sums; float eps;          // from gn_stats
+    const void* gn_w; const void* gn_b;     // model dtype [C]
+    const float* wy; const float* by; const float* wb; const float* bb;  // fp32 [Cz][C] / [C]
+    const void* zq; int Fz, hz, wz, Cz;     // dense latent frames of this frame batch [Fz][hz][wz][Cz]
+    void* out; int f_off;                   // padded [f_off + F][H+2][W+2][C]
+    int silu;
+};
+
+int launch_latent_to_zq(const void* lat, int F, int C, int h, int w, float inv_sf, void* out, int y0, int x0, int th,
+                        int tw, int dtype, hipStream_t st);
+int launch_dense_to_padded(const void* in, int F, int H, int W, int C, void* out, int f_off, int dtype, hipStream_t st);
+int launch_gn_stats(const void* x, int64_t P, int C, int G, double* sums, int dtype, hipStream_t st);
+int launch_snorm_apply(const SNormArgs& a, int dtype, hipStream_t st);
+int launch_upsample(const void* x, int F, int H, int W, int C, int compress_time, void* out, int dtype, hipStream_t st);
+int launch_to_ncfhw(const void* y, int F, int H, int W, int Co, void* out, int Ftot, int f0, int dtype, hipStream_t st);
+int launch_blend(const void* a, int Ha, int Wa, void* b, int Hb, int Wb, int CF, int E, int vertical, int dtype,
+                 hipStream_t st);
+int launch_paste(const void* tile, int Ht, int Wt, int ch, int cw, void* out, int H, int W, int y0, int x0, int CF,
+                 int dtype, hipStream_t st);
+int launch_postprocess(const void* v, int C, int F, int H, int W, float* out, int dtype, hipStream_t st);
+int launch_conv_w_repack(const void* src, int sdt, int cout, int cin, int taps, void* dst, int ddt, hipStream_t st);

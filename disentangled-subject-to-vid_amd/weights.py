@@ -91,3 +91,64 @@ def synthetic_lora(cfg, rank=128, seed=99, device="cpu", std=0.02):
         B = torch.randn((shp[0], rank), generator=gen, device=device) * std
         out[k] = (A, B)
     return out
+
+
+def vae_decoder_shapes(cfg):
+    """state-dict keys/shapes of AutoencoderKLCogVideoX.decoder (autoencoder_kl_cogvideox.py:860-919)"""
+    rc = list(reversed(cfg.block_out_channels))
+    Cz = cfg.latent_channels
+    s = {}
+
+    def conv(name, cin, cout, k):
+        s[name + ".weight"] = (cout, cin) + k
+        s[name + ".bias"] = (cout,)
+
+    def snorm(name, C):
+        s[name + ".norm_layer.weight"] = (C,)
+        s[name + ".norm_layer.bias"] = (C,)
+        conv(name + ".conv_y.conv", Cz, C, (1, 1, 1))
+        conv(name + ".conv_b.conv", Cz, C, (1, 1, 1))
+
+    def resnet(name, cin, cout):
+        snorm(name + ".norm1", cin)
+        conv(name + ".conv1.conv", cin, cout, (3, 3, 3))
+        snorm(name + ".norm2", cout)
+        conv(name + ".conv2.conv", cout, cout, (3, 3, 3))
+        if cin != cout:
+            conv(name + ".conv_shortcut", cin, cout, (1, 1, 1))
+
+    conv("decoder.conv_in.conv", Cz, rc[0], (3, 3, 3))
+    for i in range(2):
+        resnet(f"decoder.mid_block.resnets.{i}", rc[0], rc[0])
+    prev = rc[0]
+    for b, ch in enumerate(rc):
+        for i in range(cfg.layers_per_block + 1):
+            resnet(f"decoder.up_blocks.{b}.resnets.{i}", prev if i == 0 else ch, ch)
+        prev = ch
+        if b != len(rc) - 1:
+            conv(f"decoder.up_blocks.{b}.upsamplers.0.conv", ch, ch, (3, 3))
+    snorm("decoder.norm_out", rc[-1])
+    conv("decoder.conv_out.conv", rc[-1], cfg.out_channels, (3, 3, 3))
+    return s
+
+
+def synthetic_vae_state_dict(cfg, seed=4321, device="cpu", dtype=torch.float32):
+    """seeded decoder weights scaled so activations stay O(1) through the stack"""
+    gen = torch.Generator(device=device).manual_seed(seed)
+    sd = {}
+    for k, shape in vae_decoder_shapes(cfg).items():
+        if len(shape) >= 2:
+            fan_in = 1
+            for d in shape[1:]:
+                fan_in *= d
+            t = torch.randn(shape, generator=gen, device=device) * (1.0 / fan_in**0.5)
+            if "conv_y" in k:
+                t = t * 0.5
+        elif k.endswith("norm_layer.weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=gen, device=device)
+        elif "conv_y.conv.bias" in k:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=gen, device=device)
+        else:
+            t = 0.05 * torch.randn(shape, generator=gen, device=device)
+        sd[k] = t.to(dtype)
+    return sd

@@ -135,6 +135,49 @@ int s2v_profile_read(s2v_ctx* ctx, float* ms_by_class, int32_t* launches_by_clas
 /* Marks every tensor as loaded on a replica whose arena was filled by a broadcast of s2v_weight_arena. */
 int s2v_mark_weights_loaded(s2v_ctx* ctx);
 
+/* ---- CogVideoX 3-D causal VAE decode ------------------------------------------------------------------------- */
+typedef struct s2v_vae s2v_vae;
+/* AutoencoderKLCogVideoX.__init__ (models/autoencoders/autoencoder_kl_cogvideox.py:1020-1052), decoder part */
+typedef struct s2v_vae_config {
+    int32_t latent_channels;          /* 16 */
+    int32_t out_channels;             /* 3 */
+    int32_t num_blocks;               /* len(block_out_channels) = 4 */
+    int32_t block_out_channels[8];    /* (128, 256, 256, 512): encoder order, the decoder walks it reversed */
+    int32_t layers_per_block;         /* 3 */
+    int32_t norm_num_groups;          /* 32 */
+    int32_t temporal_compression_ratio; /* 4 */
+    int32_t sample_height, sample_width; /* 480, 720: only used for the tile geometry */
+    int32_t dtype;                    /* S2V_DTYPE_* */
+    int32_t force_simple;             /* 1 = generic kernels only (cross-check) */
+    float scaling_factor;             /* 1.15258426 (2B) / 0.7 (5B) */
+    float norm_eps;                   /* 1e-6 */
+    int32_t reserved[4];
+} s2v_vae_config;
+
+int s2v_vae_create(const s2v_vae_config* cfg, s2v_vae** out);
+void s2v_vae_destroy(s2v_vae* vae);
+/* name = the reference's state-dict key ("decoder.conv_in.conv.weight", "decoder.up_blocks.1.resnets.0.conv_shortcut.
+ * weight", "decoder.mid_block.resnets.0.norm1.conv_y.conv.bias", ...); conv weights are re-packed to
+ * [cout][(dt,dy,dx)][cin] for the channels-last implicit GEMM. */
+int s2v_vae_load_weight(s2v_vae* vae, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
+                        int32_t src_dtype, s2v_stream stream);
+int s2v_vae_finalize(s2v_vae* vae);
+/* output extent of s2v_vae_decode for latents [1,F,C,h,w] */
+int s2v_vae_out_shape(s2v_vae* vae, int32_t F, int32_t h, int32_t w, int32_t tiling, int32_t* Fo, int32_t* Ho, int32_t* Wo);
+/* CogVideoXPipeline.decode_latents (pipeline_cogvideox.py:346-351) = 1/scaling_factor * latents, then
+ * AutoencoderKLCogVideoX.decode (:1259-1282): frame batches (3,2,2,...) with conv_cache, GroupNorm statistics per
+ * frame batch (and per tile when tiling != 0: tiled_decode :1374-1455 incl. its raster-order in-place blends).
+ * latents [1,F,C,h,w] model dtype (the pipeline's layout); scaled != 0: pipeline latents (multiplied by
+ * 1/scaling_factor here), scaled == 0: already z = latents/scaling_factor (the argument of vae.decode);
+ * out [1,out_channels,Fo,Ho,Wo] model dtype.
+ * Buffers are (re)allocated when a larger geometry is seen for the first time, never otherwise. */
+int s2v_vae_decode(s2v_vae* vae, const void* latents, int32_t F, int32_t h, int32_t w, int32_t tiling, int32_t scaled,
+                   void* out, s2v_stream stream);
+/* VideoProcessor.postprocess_video(output_type="np") (video_processor.py:89-113, image_processor.py:227-240):
+ * video [C,F,H,W] -> float32 [F,H,W,C], clamp(x/2 + 0.5, 0, 1) */
+int s2v_vae_postprocess(const void* video, int32_t C, int32_t F, int32_t H, int32_t W, float* out, int32_t dtype,
+                        s2v_stream stream);
+
 /* ---- operator-level entry points (used by the parity tests and micro-benchmarks) ------------------------- */
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic */
 int s2v_op_linear(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
