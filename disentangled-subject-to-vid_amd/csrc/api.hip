@@ -322,11 +322,11 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     c->Ntok = T + c->R + c->V;
     c->ntok_pad = (int)rup(c->Ntok, 64);
     c->M = (int64_t)B * c->Ntok;
-    c->Mpad = rup(c->M, 128) + 128;
+    c->Mpad = rup(c->M, 256) + 256;
     c->have_rope = c->have_pos = c->have_cond = false;
     const int64_t D = c->D, E = c->esz;
     const int64_t Cin4 = c->cfg.in_channels * 4, Cout4 = c->cfg.out_channels * 4;
-    const int64_t BVp = rup((int64_t)B * c->V, 128) + 128;
+    const int64_t BVp = rup((int64_t)B * c->V, 256) + 256;
     int64_t off = 0;
     auto carve = [&](int64_t bytes) { int64_t o = off; off += rup(bytes, 256); return o; };
     const int64_t oX = carve(c->Mpad * D * E), oXn = carve(c->Mpad * D * E), oQKV = carve(c->Mpad * 3 * D * E);
@@ -369,7 +369,10 @@ extern "C" int s2v_set_pos_embed(s2v_ctx* c, const void* table_dev, s2v_stream s
     return 0;
 }
 
-static int linear(s2v_ctx* c, const GemmArgs& g, int epi, hipStream_t st) {
+static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
+    GemmArgs g = g0;
+    // every GEMM operand of the transformer lives in a workspace buffer with >= 256 rows of slack behind it
+    g.a_rows_padded = (int)(rup(g.M, 256));
     if (c->mfma && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0) return launch_gemm_bf16(g, epi, st);
     return launch_gemm_simple(g, epi, c->dtype, st);
 }
@@ -665,6 +668,7 @@ extern "C" int s2v_op_linear(const void* A, const void* W, const void* bias, voi
     if (impl == 0) {
         S2V_REQUIRE(dtype == S2V_DTYPE_BF16, "s2v_op_linear: the MFMA kernel is bf16 only");
         S2V_REQUIRE(M % 128 == 0 && N % 128 == 0, "s2v_op_linear: impl 0 needs M and N padded to 128 by the caller");
+        g.a_rows_padded = M;  // the 256-row ring kernel is used when M is a multiple of 256
         return launch_gemm_bf16(g, epilogue, (hipStream_t)stream);
     }
     return launch_gemm_simple(g, epilogue, dtype, (hipStream_t)stream);

@@ -129,6 +129,86 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + off);
 }
 
+// Epilogue of one wave's 64(m) x 64(n) accumulator tile (2x2 MFMA 32x32 blocks, D[i = n][j = m]).
+// Accumulator layout -> +bias, (GELU), round to bf16 in registers -> the wave's private 8 KiB LDS patch (rows of
+// 128 B, 16-B chunks XOR-swizzled by row&7) -> read back row-major, 16 B per lane, 8 lanes per 128-B line -> gate /
+// residual in that layout -> full-line global stores.  A row-per-lane epilogue (8-B stores at a row stride) was
+// store-issue bound: ~0.7 ms of a 3.4 ms FF1 launch.
+template <int EPI>
+__device__ __forceinline__ void epilogue_wave64(const GemmArgs& a, const f32x16 (&acc)[2][2], int mw, int nw, char* patch,
+                                                int lane) {
+    const int fr = lane & 31, hi = lane >> 5;
+    const bf16_t* bias = (const bf16_t*)a.bias;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const int nl = i * 32 + 8 * rq + 4 * hi;  // local column of 4 consecutive outputs
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (nw + nl + e < a.N) bv[e] = bf2f(bias[nw + nl + e]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float y[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y[e] = bf2f(f2bf(acc[i][j][rq * 4 + e] + bv[e]));
+                    if (EPI == EPI_BIAS_GELU) y[e] = gelu_tanh_fast(y[e]);
+                }
+                const int row = j * 32 + fr;
+                u32x2 p;
+                p.x = pack2bf(y[0], y[1]);
+                p.y = pack2bf(y[2], y[3]);
+                *(u32x2*)(patch + row * 128 + ((((nl >> 3) ^ (row & 7))) << 4) + (nl & 4) * 2) = p;
+            }
+        }
+    // same-wave LDS accesses are ordered; the compiler inserts the lgkmcnt wait for the dependent reads
+    const int c16 = lane & 7;
+    const int n = nw + c16 * 8;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3);
+        const int m = mw + row;
+        u32x4 v = *(const u32x4*)(patch + row * 128 + ((c16 ^ (row & 7)) << 4));
+        if (m >= a.M || n >= a.N) continue;
+        if (EPI == EPI_BIAS_GATE_RES) {
+            const int b = m / a.tok_per_batch;
+            const int r = m - b * a.tok_per_batch;
+            const bf16_t* gate = (const bf16_t*)(r < a.text_len ? a.gate_txt : a.gate_vid) + (size_t)b * a.gate_stride + n;
+            bf16_t* x = (bf16_t*)a.X + (size_t)m * a.ldx + n;
+            const u32x4 g = *(const u32x4*)gate;
+            const u32x4 xo = *(const u32x4*)x;
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float t0 = bf2f(f2bf(__uint_as_float(g[e] << 16) * __uint_as_float(v[e] << 16)));
+                const float t1 = bf2f(f2bf(__uint_as_float(g[e] & 0xffff0000u) * __uint_as_float(v[e] & 0xffff0000u)));
+                o[e] = pack2bf(__uint_as_float(xo[e] << 16) + t0, __uint_as_float(xo[e] & 0xffff0000u) + t1);
+            }
+            *(u32x4*)x = o;
+        } else {
+            if (EPI == EPI_BIAS_ADD) {
+                const u32x4 rr = *(const u32x4*)((const bf16_t*)a.R + (size_t)m * a.ldr + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = pack2bf(__uint_as_float(v[e] << 16) + __uint_as_float(rr[e] << 16),
+                                   __uint_as_float(v[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u));
+            }
+            *(u32x4*)((bf16_t*)a.C + (size_t)m * a.ldc + n) = v;
+        }
+    }
+}
+// vectorised epilogue is usable when whole 8-column groups exist and rows are 16-byte aligned
+__device__ __forceinline__ bool epi_vec_ok(const GemmArgs& a, int epi) {
+    if ((a.N & 7) != 0) return false;
+    if (epi == EPI_BIAS_GATE_RES) return (a.ldx & 7) == 0 && (a.gate_stride & 7) == 0;
+    if (epi == EPI_BIAS_ADD && (a.ldr & 7) != 0) return false;
+    return (a.ldc & 7) == 0;
+}
+
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -194,6 +274,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int ti
         __syncthreads();
     }
 
+    if (epi_vec_ok(a, EPI)) {  // the k-loop ended with a barrier: the operand stages are free
+        epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
+        return;
+    }
     // epilogue: D[i = n][j = m]; lane: m = fr, n = (reg&3) + 8*(reg>>2) + 4*hi
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -209,8 +293,772 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int ti
         }
 }
 
-int launch_gemm_bf16(const GemmArgs& a, int epi, hipStream_t st) {
+// ---------------------------------------------------------------------------------------------------
+// gemm_bf16_ring: 256(M) x 128(N) x 64 block tile, 8 waves (4 x 2, 64x64 each), THREE LDS stages (3 x 48 KiB) filled by
+// global_load_lds two k-steps ahead.  One raw s_barrier per k-step; the loads of tile t+2 stay in flight across it:
+// each wave waits only for its own tile-(t+1) loads with a counted s_waitcnt vmcnt(6) (6 LDS-DMA per thread per tile)
+// before the barrier that publishes them (cdna_hip_programming.md section 5 "Pipelining across barriers").
+//   RAW: tile t+1 is read after { every wave's vmcnt(6) ; barrier(t+1) }.
+//   WAR: tile t+2 overwrites stage (t-1)%3, whose last ds_reads completed before each wave arrived at barrier(t).
+#define RBM 256
+#define RBN 128
+#define RA_BYTES (RBM * BK * 2)   // 32 KiB
+#define RW_BYTES (RBN * BK * 2)   // 16 KiB
+#define RSTAGE (RA_BYTES + RW_BYTES)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_ring(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int GM = 4;  // 4 x 256 rows per group: same 1024-row x all-columns sweep as the 128-tile kernel
+    const int per_group = GM * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = wg - group * per_group;
+    const int m0 = (first_m + in_g % gsz) * RBM, n0 = (in_g / gsz) * RBN;
+
+    const bf16_t* A = (const bf16_t*)a.A;
+    const bf16_t* W = (const bf16_t*)a.W;
+
+    // per-thread staging assignments: A tile 2048 chunks (4 per thread), W tile 1024 chunks (2 per thread)
+    int64_t rbA[4], rbW[2];
+    int cA[4], cW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gi = i * 512 + tid, row = gi >> 3;
+        rbA[i] = a_row_base(a, m0 + row);
+        cA[i] = ((gi & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int gi = i * 512 + tid, row = gi >> 3;
+        rbW[i] = (int64_t)(n0 + row) * a.ldw;
+        cW[i] = ((gi & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+    auto stage = [&](int t, int s) {
+        char* base = smem + s * RSTAGE;
+        const int64_t ka = a_k_off(a, t * BK);
+        const int kw = t * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            char* dst = base + (i * 512 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + rbA[i] + ka + cA[i]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            char* dst = base + RA_BYTES + (i * 512 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + rbW[i] + kw + cW[i]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nt = a.K / BK;
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    const int fr = lane & 31, hi = lane >> 5;
+    for (int t = 0; t < nt; ++t) {
+        // tile t must have landed: everything except the most recent tile's 6 loads
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt && !(a.ablate & 1)) stage(t + 2, (t + 2) % 3);
+        if (a.ablate & 2) continue;
+        const char* tA = smem + (t % 3) * RSTAGE;
+        const char* tW = tA + RA_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            bf16x8 wf[2], af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[i] = lds_frag(tW, wn * 64 + i * 32 + fr, kk * 2 + hi);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) af[j] = lds_frag(tA, wm * 64 + j * 32 + fr, kk * 2 + hi);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    if (epi_vec_ok(a, EPI)) {
+        __builtin_amdgcn_s_barrier();  // every wave has consumed the last operand stage
+        epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wm * 64 + j * 32 + fr;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
+                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
+                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gemm_bf16_stag: same 256x128x64 tile / 3-stage LDS-DMA ring, but the two wave groups (waves 0-3 / 4-7, one wave of
+// each per SIMD) run half a k-step apart: a k-step is split into a LOAD slot (16 ds_read_b128 -> fragments in VGPRs)
+// and a COMPUTE slot (16 MFMA), slots are separated by s_barrier, and group B starts one barrier late.  At any time
+// one wave of every SIMD is in its MFMA slot (s_setprio 1) while its partner issues LDS reads / LDS-DMA, so the
+// matrix pipe and the LDS/VMEM pipes overlap instead of alternating.
+//   odd slot of step t : everybody issues the DMA of tile t+2 (stage (t-1)%3: its last reads were consumed >= 1
+//                        barrier ago), A computes tile t, B loads tile t; both end with the counted vmcnt that
+//                        retires tile t+1, then barrier
+//   even slot          : A loads tile t+1, B computes tile t
+template <int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_stag(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int wm = wave & 3, wn = grp;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = wg - group * per_group;
+    const int m0 = (first_m + in_g % gsz) * RBM, n0 = (in_g / gsz) * RBN;
+
+    const bf16_t* A = (const bf16_t*)a.A;
+    const bf16_t* W = (const bf16_t*)a.W;
+    int64_t rbA[4], rbW[2];
+    int cA[4], cW[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gi = i * 512 + tid, row = gi >> 3;
+        rbA[i] = a_row_base(a, m0 + row);
+        cA[i] = ((gi & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int gi = i * 512 + tid, row = gi >> 3;
+        rbW[i] = (int64_t)(n0 + row) * a.ldw;
+        cW[i] = ((gi & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+    auto stage = [&](int t, int s) {
+        char* base = smem + s * RSTAGE;
+        const int64_t ka = a_k_off(a, t * BK);
+        const int kw = t * BK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            char* dst = base + (i * 512 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + rbA[i] + ka + cA[i]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            char* dst = base + RA_BYTES + (i * 512 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + rbW[i] + kw + cW[i]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bf16x8 wf[4][2], af[4][2];
+    const int fr = lane & 31, hi = lane >> 5;
+
+    auto load_frags = [&](int t) {
+        const char* tA = smem + (t % 3) * RSTAGE;
+        const char* tW = tA + RA_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[kk][i] = lds_frag(tW, wn * 64 + i * 32 + fr, kk * 2 + hi);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) af[kk][j] = lds_frag(tA, wm * 64 + j * 32 + fr, kk * 2 + hi);
+        }
+    };
+    auto compute = [&]() {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int nt = a.K / BK;
+    stage(0, 0);
+    if (nt > 1) {
+        stage(1, 1);
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+
+    if (grp == 0) {
+        for (int t = 0; t < nt; ++t) {
+            load_frags(t);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            if (t + 2 < nt) stage(t + 2, (t + 2) % 3);
+            compute();
+            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+    } else {
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nt; ++t) {
+            if (t + 2 < nt) stage(t + 2, (t + 2) % 3);
+            load_frags(t);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 2 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // last step: group A starts overwriting the stages (epilogue patches) right behind this barrier
+            if (t + 1 == nt) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            compute();
+            if (t + 1 < nt) __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    if (epi_vec_ok(a, EPI)) {
+        // group A left the loop through a barrier that B passed after its last LDS reads: the stages are free
+        epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wm * 64 + j * 32 + fr;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
+                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
+                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gemm_bf16_r32: 256 x 128 tile, BK = 32, three 24-KiB LDS stages (72 KiB) so that TWO workgroups (16 waves) share a
+// CU: one block's prologue / epilogue / barrier stalls are covered by the other block's k-loop.  LDS rows are 64 B;
+// 16-B chunk index is XOR-ed with (row>>2)&3, which makes every ds_read_b128 lane-group of the 32x32x16 fragment
+// read hit 16 distinct slots.  3 LDS-DMA per thread per k-step, counted vmcnt(3), one raw barrier per k-step.
+#define K32 32
+#define R32_A (RBM * K32 * 2)  // 16 KiB
+#define R32_W (RBN * K32 * 2)  // 8 KiB
+#define R32_STAGE (R32_A + R32_W)
+
+__device__ __forceinline__ bf16x8 lds_frag32(const char* tile, int row, int cl) {
+    return *(const bf16x8*)(tile + row * 64 + ((cl ^ ((row >> 2) & 3)) << 4));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void gemm_bf16_r32(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = wg - group * per_group;
+    const int m0 = (first_m + in_g % gsz) * RBM, n0 = (in_g / gsz) * RBN;
+
+    const bf16_t* A = (const bf16_t*)a.A;
+    const bf16_t* W = (const bf16_t*)a.W;
+    int64_t rbA[2], rbW;
+    int cA[2], cW;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int gi = i * 512 + tid, row = gi >> 2;
+        rbA[i] = a_row_base(a, m0 + row);
+        cA[i] = ((gi & 3) ^ ((row >> 2) & 3)) * 8;
+    }
+    {
+        const int row = tid >> 2;
+        rbW = (int64_t)(n0 + row) * a.ldw;
+        cW = ((tid & 3) ^ ((row >> 2) & 3)) * 8;
+    }
+    auto stage = [&](int t, int s) {
+        char* base = smem + s * R32_STAGE;
+        const int64_t ka = a_k_off(a, t * K32);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            char* dst = base + (i * 512 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + rbA[i] + ka + cA[i]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+        char* dst = base + R32_A + (wave * 64) * 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + rbW + t * K32 + cW),
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nt = a.K / K32;
+    stage(0, 0);
+    if (nt > 1) stage(1, 1);
+    const int fr = lane & 31, hi = lane >> 5;
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 2 < nt) stage(t + 2, (t + 2) % 3);
+        const char* tA = smem + (t % 3) * R32_STAGE;
+        const char* tW = tA + R32_A;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 wf[2], af[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[i] = lds_frag32(tW, wn * 64 + i * 32 + fr, kk * 2 + hi);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) af[j] = lds_frag32(tA, wm * 64 + j * 32 + fr, kk * 2 + hi);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    if (epi_vec_ok(a, EPI)) {
+        __builtin_amdgcn_s_barrier();
+        epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wm * 64 + j * 32 + fr;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
+                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
+                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gemm_bf16_w128: 256 x 256 x 64 block tile, FOUR waves (2 x 2), one wave per SIMD, each wave owns a 128 x 128 output
+// tile = 4 x 4 MFMA 32x32 blocks = 256 accumulator registers of the unified 512-register file.  Per 32-cycle MFMA the
+// wave reads half an operand fragment from LDS (vs one with 64 x 64 wave tiles) and the block stages 2/3 of the bytes
+// per flop, which is what the LDS-DMA / ds_read contention of the smaller tiles was costing.  Two 64-KiB LDS stages:
+//   barrier -> DMA(t+1) -> 64 MFMA on stage t (fragment reads of k-slice kk+1 issued ahead of the MFMAs of kk)
+//           -> s_waitcnt vmcnt(0) -> barrier.
+#define WBM 256
+#define WBN 256
+#define W_A_BYTES (WBM * BK * 2)  // 32 KiB
+#define W_STAGE (2 * W_A_BYTES)   // 64 KiB
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w128_v1(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = wg - group * per_group;
+    const int m0 = (first_m + in_g % gsz) * WBM, n0 = (in_g / gsz) * WBN;
+
+    const bf16_t* A = (const bf16_t*)a.A;
+    const bf16_t* W = (const bf16_t*)a.W;
+    // staging: 2048 16-B chunks per operand per k-step, 8 per thread
+    int64_t rbA[8], rbW[8];
+    int cc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int gi = i * 256 + tid, row = gi >> 3;
+        rbA[i] = a_row_base(a, m0 + row);
+        rbW[i] = (int64_t)(n0 + row) * a.ldw;
+        cc[i] = ((gi & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+    auto stage = [&](int t, int s) {
+        char* base = smem + s * W_STAGE;
+        const int64_t ka = a_k_off(a, t * BK);
+        const int kw = t * BK;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            char* dst = base + (i * 256 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + rbA[i] + ka + cc[i]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            char* dst = base + W_A_BYTES + (i * 256 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + rbW[i] + kw + cc[i]),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nt = a.K / BK;
+    const int fr = lane & 31, hi = lane >> 5;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int t = 0; t < nt; ++t) {
+        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
+        const char* tA = smem + (t & 1) * W_STAGE;
+        const char* tW = tA + W_A_BYTES;
+        bf16x8 wf[2][4], af[2][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            wf[0][i] = lds_frag(tW, wn * 128 + i * 32 + fr, hi);
+            af[0][i] = lds_frag(tA, wm * 128 + i * 32 + fr, hi);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    wf[nxt][i] = lds_frag(tW, wn * 128 + i * 32 + fr, (kk + 1) * 2 + hi);
+                    af[nxt][i] = lds_frag(tA, wm * 128 + i * 32 + fr, (kk + 1) * 2 + hi);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], af[cur][j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // epilogue: four 64 x 64 quadrants through the wave's 8 KiB LDS patch (the k-loop ended with a barrier)
+    char* patch = smem + wave * 8192;
+    if (epi_vec_ok(a, EPI)) {
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int qj = 0; qj < 2; ++qj) {
+                f32x16 sub[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) sub[i][j] = acc[qi * 2 + i][qj * 2 + j];
+                epilogue_wave64<EPI>(a, sub, m0 + wm * 128 + qj * 64, n0 + wn * 128 + qi * 64, patch, lane);
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 128 + j * 32 + fr;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + wn * 128 + i * 32 + 8 * rq + 4 * hi;
+                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
+                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
+            }
+        }
+}
+
+// gemm_bf16_w128 (v2): same 256 x 256 block / four waves / 128 x 128 wave tiles, but the k-loop advances in HALF steps of
+// 32 with FOUR 32-KiB LDS stages (rows of 64 B, lds_frag32 swizzle): the LDS-DMA of half-tile h+3 is issued while
+// half-tile h is computed (3 half-steps = 3 x 32 MFMA of lead instead of 1 k-step), its 8 instructions are spread
+// between the MFMA groups instead of a burst in front of them, and the wait at the top of a half-step is the counted
+// vmcnt that leaves the two newest half-tiles in flight across the barrier.
+#define WH_A (WBM * K32 * 2)   // 16 KiB
+#define WH_STAGE (2 * WH_A)    // 32 KiB
+#define WH_NST 4
+
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_bf16_w128(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = wg - group * per_group;
+    const int m0 = (first_m + in_g % gsz) * WBM, n0 = (in_g / gsz) * WBN;
+
+    // staging: per half-step 1024 16-B chunks per operand (256 rows x 4 chunks), 4 per thread:
+    // chunk gi = i*256 + tid -> row = gi>>2 = i*64 + (tid>>2), physical chunk = tid&3, source chunk = phys ^ ((row>>2)&3)
+    const int srow = tid >> 2;
+    const int scol = ((tid & 3) ^ ((srow >> 2) & 3)) * 8;  // (row>>2)&3 does not depend on i (i*64 >> 2 = 16 i)
+    const bf16_t* pA = (const bf16_t*)a.A + a_row_base(a, m0 + srow) + scol;
+    const bf16_t* pW = (const bf16_t*)a.W + (int64_t)(n0 + srow) * a.ldw + scol;
+    int dA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dA[i] = (int)(a_row_base(a, m0 + srow + i * 64) - a_row_base(a, m0 + srow));
+    const int64_t dW = (int64_t)64 * a.ldw;
+    int64_t ka_cur = 0;  // A-operand displacement of the half-tile being staged (one evaluation per half-step)
+    auto glds_one = [&](int h, int s, int idx8) {  // idx8 0..3 -> A piece, 4..7 -> W piece
+        char* base = smem + s * WH_STAGE;
+        const int i = idx8 & 3;
+        if (idx8 < 4) {
+            char* dst = base + (i * 256 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pA + dA[i] + ka_cur),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        } else {
+            char* dst = base + WH_A + (i * 256 + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pW + i * dW + h * K32),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int nh = a.K / K32;
+    const int fr = lane & 31, hi = lane >> 5;
+    // Pipeline (half-tile t lives in LDS stage t & 3):
+    //   during half-step h the wave issues, between its 32 MFMA on the fragments of half-tile h (already in VGPRs):
+    //     - the 16 ds_read_b128 of half-tile h+1 (published by the barrier at the top of h) into the other fragment set,
+    //     - the 8 LDS-DMA of half-tile h+4 into stage h & 3 (free: every wave finished reading it before that barrier).
+    //   top of half-step h: s_waitcnt vmcnt(16) => half-tiles <= h+1 landed (h+2, h+3 stay in flight), lgkmcnt(0) =>
+    //   this wave's reads of stage h & 3 are done, then ONE barrier.
+    // The loop body is branch-free (a conditional LDS-DMA or read splits the basic block and the register allocator
+    // then spills the fragment sets): past the end of K the DMA re-loads the last half-tile into a free stage and the
+    // reads fetch fragments that are never used, so every half-step issues exactly 8 LDS-DMA and vmcnt(16) is constant.
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int tp = min(p, nh - 1);
+        ka_cur = a.conv ? a_k_off(a, tp * K32) : (int64_t)tp * K32;
+#pragma unroll
+        for (int g8 = 0; g8 < 8; ++g8) glds_one(tp, p, g8);
+    }
+    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    bf16x8 wfA[2][4], afA[2][4], wfB[2][4], afB[2][4];
+    auto read_frags = [&](int t, bf16x8 (&wf)[2][4], bf16x8 (&af)[2][4], int kk, int i) {
+        const char* tA = smem + (t & 3) * WH_STAGE;
+        const char* tW = tA + WH_A;
+        wf[kk][i] = lds_frag32(tW, wn * 128 + i * 32 + fr, kk * 2 + hi);
+        af[kk][i] = lds_frag32(tA, wm * 128 + i * 32 + fr, kk * 2 + hi);
+    };
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) read_frags(0, wfA, afA, kk, i);
+
+    auto half_step = [&](int h, bf16x8 (&wf)[2][4], bf16x8 (&af)[2][4], bf16x8 (&wfn)[2][4], bf16x8 (&afn)[2][4]) {
+        asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int tl = min(h + 4, nh - 1);
+        ka_cur = a.conv ? a_k_off(a, tl * K32) : (int64_t)tl * K32;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                read_frags(h + 1, wfn, afn, kk, i);
+                glds_one(tl, h & 3, kk * 4 + i);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
+            }
+    };
+    for (int h = 0; h < nh; h += 2) {  // nh = K/32 is even (K % 64 == 0)
+        half_step(h, wfA, afA, wfB, afB);
+        half_step(h + 1, wfB, afB, wfA, afA);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // all waves are done with the operand stages before the epilogue patches reuse them
+
+    char* patch = smem + wave * 8192;
+    if (epi_vec_ok(a, EPI)) {
+#pragma unroll
+        for (int qi = 0; qi < 2; ++qi)
+#pragma unroll
+            for (int qj = 0; qj < 2; ++qj) {
+                f32x16 sub[2][2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) sub[i][j] = acc[qi * 2 + i][qj * 2 + j];
+                epilogue_wave64<EPI>(a, sub, m0 + wm * 128 + qj * 64, n0 + wn * 128 + qi * 64, patch, lane);
+            }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 128 + j * 32 + fr;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + wn * 128 + i * 32 + 8 * rq + 4 * hi;
+                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
+                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
+            }
+        }
+}
+
+template <int EPI>
+static int launch_w128_t(const GemmArgs& a, hipStream_t st) {
+    const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w128<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WH_NST * WH_STAGE));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_w128<EPI>, dim3(tiles_m * tiles_n), dim3(256), WH_NST * WH_STAGE, st, a, tiles_m, tiles_n);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int EPI>
+static int launch_r32_t(const GemmArgs& a, hipStream_t st) {
+    const int tiles_m = (a.M + RBM - 1) / RBM, tiles_n = (a.N + RBN - 1) / RBN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_r32<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * R32_STAGE));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_r32<EPI>, dim3(tiles_m * tiles_n), dim3(512), 3 * R32_STAGE, st, a, tiles_m, tiles_n);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int EPI>
+static int launch_stag_t(const GemmArgs& a, hipStream_t st) {
+    const int tiles_m = (a.M + RBM - 1) / RBM, tiles_n = (a.N + RBN - 1) / RBN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_stag<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * RSTAGE));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_stag<EPI>, dim3(tiles_m * tiles_n), dim3(512), 3 * RSTAGE, st, a, tiles_m, tiles_n);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int EPI>
+static int launch_ring_t(const GemmArgs& a, hipStream_t st) {
+    const int tiles_m = (a.M + RBM - 1) / RBM, tiles_n = (a.N + RBN - 1) / RBN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_ring<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * RSTAGE));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16_ring<EPI>, dim3(tiles_m * tiles_n), dim3(512), 3 * RSTAGE, st, a, tiles_m, tiles_n);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int g_gemm_ablate = 0;  // diagnostics only (ring kernel): bit0 = no LDS-DMA in the k-loop, bit1 = no ds_read/MFMA
+int g_gemm_impl = 4;  // 4 = 256x256 four-wave (falls back to 2 when N % 256 != 0), 3 = BK32 two-block, 2 = staggered
+                      // 256x128 ring, 1 = lock-step 256x128 ring, 0 = 128x128 double-buffer kernel
+extern "C" int s2v_set_gemm_impl(int impl) { g_gemm_impl = impl & 0xff; g_gemm_ablate = impl >> 8; return 0; }
+
+int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
+    GemmArgs a = a0;
+    a.ablate = g_gemm_ablate;
     S2V_REQUIRE(a.K % BK == 0, "gemm_bf16: K must be a multiple of 64");
+    if (g_gemm_impl == 4 && a.N % WBN == 0 && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+        S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
+        switch (epi) {
+            case EPI_BIAS: return launch_w128_t<EPI_BIAS>(a, st);
+            case EPI_BIAS_GELU: return launch_w128_t<EPI_BIAS_GELU>(a, st);
+            case EPI_BIAS_GATE_RES: return launch_w128_t<EPI_BIAS_GATE_RES>(a, st);
+            case EPI_BIAS_ADD: return launch_w128_t<EPI_BIAS_ADD>(a, st);
+            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
+        }
+    }
+    if (g_gemm_impl == 3 && a.K % K32 == 0 && (a.conv || a.a_rows_padded >= ((a.M + RBM - 1) / RBM) * RBM)) {
+        S2V_REQUIRE((a.conv ? a.cin % 32 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
+        switch (epi) {
+            case EPI_BIAS: return launch_r32_t<EPI_BIAS>(a, st);
+            case EPI_BIAS_GELU: return launch_r32_t<EPI_BIAS_GELU>(a, st);
+            case EPI_BIAS_GATE_RES: return launch_r32_t<EPI_BIAS_GATE_RES>(a, st);
+            case EPI_BIAS_ADD: return launch_r32_t<EPI_BIAS_ADD>(a, st);
+            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
+        }
+    }
+    if ((g_gemm_impl == 2 || g_gemm_impl == 4) && (a.conv || a.a_rows_padded >= ((a.M + RBM - 1) / RBM) * RBM)) {
+        S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
+        switch (epi) {
+            case EPI_BIAS: return launch_stag_t<EPI_BIAS>(a, st);
+            case EPI_BIAS_GELU: return launch_stag_t<EPI_BIAS_GELU>(a, st);
+            case EPI_BIAS_GATE_RES: return launch_stag_t<EPI_BIAS_GATE_RES>(a, st);
+            case EPI_BIAS_ADD: return launch_stag_t<EPI_BIAS_ADD>(a, st);
+            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
+        }
+    }
+    if (g_gemm_impl == 1 && (a.conv || a.a_rows_padded >= ((a.M + RBM - 1) / RBM) * RBM)) {
+        S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
+        switch (epi) {
+            case EPI_BIAS: return launch_ring_t<EPI_BIAS>(a, st);
+            case EPI_BIAS_GELU: return launch_ring_t<EPI_BIAS_GELU>(a, st);
+            case EPI_BIAS_GATE_RES: return launch_ring_t<EPI_BIAS_GATE_RES>(a, st);
+            case EPI_BIAS_ADD: return launch_ring_t<EPI_BIAS_ADD>(a, st);
+            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
+        }
+    }
     S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const int grid = tiles_m * tiles_n;

@@ -155,13 +155,10 @@ __device__ __forceinline__ int zq_frame(int f, int Ff, int Fz) {
 template <typename T>
 __global__ __launch_bounds__(256) void snorm_apply_k(const SNormArgs a) {
     constexpr int VN = V16<T>::N;
-    extern __shared__ __attribute__((aligned(16))) float lds[];  // wy [Cz][C], wb [Cz][C], mean[G], rstd[G]
-    const int C = a.C, Cz = a.Cz, G = a.G, cpg = C / G;
-    float* wy = lds;
-    float* wb = lds + Cz * C;
-    float* mean = wb + Cz * C;
+    extern __shared__ __attribute__((aligned(16))) float lds[];  // mean[G], rstd[G]
+    const int C = a.C, G = a.G, cpg = C / G;
+    float* mean = lds;
     float* rstd = mean + G;
-    for (int i = threadIdx.x; i < Cz * C; i += 256) { wy[i] = a.wy[i]; wb[i] = a.wb[i]; }
     const double cnt = (double)a.F * a.H * a.W * cpg;
     for (int g = threadIdx.x; g < G; g += 256) {
         const double m = a.sums[2 * g] / cnt;
@@ -192,25 +189,19 @@ __global__ __launch_bounds__(256) void snorm_apply_k(const SNormArgs a) {
         V16<T>::ld(gb + c0, g_b);
         const int fz = zq_frame(f, a.F, a.Fz);
         const int yz = (int)(((int64_t)yy * a.hz) / a.H), xz = (int)(((int64_t)xx * a.wz) / a.W);
-        const T* zp = zq + (((int64_t)fz * a.hz + yz) * a.wz + xz) * Cz;
+        // conv_y / conv_b are pointwise, so conv(nearest-upsampled zq) == nearest-upsampled conv(zq): gather the
+        // latent-resolution tables built by snorm_tables_k (L2-resident, each row reused by its whole footprint)
+        const int64_t pz = (((int64_t)fz * a.hz + yz) * a.wz + xz) * C + c0;
         float cy[VN], cb[VN];
-#pragma unroll
-        for (int e = 0; e < VN; ++e) { cy[e] = 0.f; cb[e] = 0.f; }
-        for (int j = 0; j < Cz; ++j) {
-            const float z = ET<T>::ld(zp + j);
-#pragma unroll
-            for (int e = 0; e < VN; ++e) {
-                cy[e] = fmaf(z, wy[j * C + c0 + e], cy[e]);
-                cb[e] = fmaf(z, wb[j * C + c0 + e], cb[e]);
-            }
-        }
+        V16<T>::ld((const T*)a.yt + pz, cy);
+        V16<T>::ld((const T*)a.bt + pz, cb);
         float o[VN];
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
             const int g = (c0 + e) / cpg;
             const float n = ET<T>::rnd((v[e] - mean[g]) * rstd[g] * g_w[e] + g_b[e]);
-            const float y = ET<T>::rnd(cy[e] + a.by[c0 + e]);
-            const float b = ET<T>::rnd(cb[e] + a.bb[c0 + e]);
+            const float y = cy[e];
+            const float b = cb[e];
             float r = ET<T>::rnd(ET<T>::rnd(n * y) + b);
             if (a.silu) r = ET<T>::rnd(silu_f(r));
             o[e] = r;
@@ -218,21 +209,47 @@ __global__ __launch_bounds__(256) void snorm_apply_k(const SNormArgs a) {
         V16<T>::st(out + ((((int64_t)(f + a.f_off)) * Hp + yy + 1) * Wp + xx + 1) * C + c0, o);
     }
 }
+// latent-resolution tables: yt[p][c] = rnd(sum_j zq[p][j] wy[j][c] + by[c]), bt likewise (p over Fz*hz*wz)
+template <typename T>
+__global__ void snorm_tables_k(const SNormArgs a) {
+    constexpr int VN = V16<T>::N;
+    const int C = a.C, Cz = a.Cz, vpp = C / VN;
+    const int64_t total = (int64_t)a.Fz * a.hz * a.wz * vpp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % vpp) * VN;
+        const int64_t p = i / vpp;
+        const T* zp = (const T*)a.zq + p * Cz;
+        float cy[VN], cb[VN];
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { cy[e] = 0.f; cb[e] = 0.f; }
+        for (int j = 0; j < Cz; ++j) {
+            const float z = ET<T>::ld(zp + j);
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                cy[e] = fmaf(z, a.wy[j * C + c0 + e], cy[e]);
+                cb[e] = fmaf(z, a.wb[j * C + c0 + e], cb[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VN; ++e) { cy[e] += a.by[c0 + e]; cb[e] += a.bb[c0 + e]; }
+        V16<T>::st((T*)a.yt + p * C + c0, cy);
+        V16<T>::st((T*)a.bt + p * C + c0, cb);
+    }
+}
+
 int launch_snorm_apply(const SNormArgs& a, int dtype, hipStream_t st) {
     const int VN = dtype == S2V_BF16 ? 8 : 4;
     S2V_REQUIRE(a.C % VN == 0 && a.C % a.G == 0, "snorm_apply: unsupported channel count");
-    const size_t shmem = sizeof(float) * ((size_t)2 * a.Cz * a.C + 2 * a.G);
-    S2V_REQUIRE(shmem <= 160 * 1024, "snorm_apply: weights do not fit LDS");
+    S2V_REQUIRE(a.yt && a.bt, "snorm_apply: table scratch missing");
+    const size_t shmem = sizeof(float) * (size_t)2 * a.G;
+    const int64_t tl = (int64_t)a.Fz * a.hz * a.wz * (a.C / VN);
     const int64_t total = (int64_t)a.F * a.H * a.W * (a.C / VN);
-    const unsigned grid = grid_for(total, 2048);
     if (dtype == S2V_BF16) {
-        if (shmem > 64 * 1024)
-            S2V_CHECK_HIP(hipFuncSetAttribute((const void*)snorm_apply_k<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(snorm_apply_k<bf16_t>, dim3(grid), dim3(256), shmem, st, a);
+        hipLaunchKernelGGL(snorm_tables_k<bf16_t>, dim3(grid_for(tl)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(snorm_apply_k<bf16_t>, dim3(grid_for(total, 16384)), dim3(256), shmem, st, a);
     } else {
-        if (shmem > 64 * 1024)
-            S2V_CHECK_HIP(hipFuncSetAttribute((const void*)snorm_apply_k<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        hipLaunchKernelGGL(snorm_apply_k<float>, dim3(grid), dim3(256), shmem, st, a);
+        hipLaunchKernelGGL(snorm_tables_k<float>, dim3(grid_for(tl)), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(snorm_apply_k<float>, dim3(grid_for(total, 16384)), dim3(256), shmem, st, a);
     }
     S2V_CHECK_HIP(hipGetLastError());
     return 0;

@@ -46,7 +46,7 @@ struct s2v_vae {
     int fmax[8] = {0};
     char* dense[3] = {nullptr, nullptr, nullptr};
     int64_t dense_bytes = 0;
-    char* zq = nullptr;
+    char* zq = nullptr; char* yt = nullptr; char* bt = nullptr;
     double* sums = nullptr;
     std::vector<void*> geo_allocs;
     std::vector<char*> tiles; std::vector<int> tile_h, tile_w;
@@ -273,6 +273,12 @@ static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max) {
     v->dense_bytes = dmax + (int64_t)256 * 1024 * v->esz;  // + one 128-row MFMA tile of slack
     for (int i = 0; i < 3; ++i) S2V_TRY(dmalloc(v, &v->dense[i], v->dense_bytes, true));
     S2V_TRY(dmalloc(v, &v->zq, (int64_t)fz_max * th * tw * v->Cz * v->esz + 64, true));
+    {
+        int cmax = 0;
+        for_each_conv(v, [&](ConvL& c) { cmax = c.cin > cmax ? c.cin : cmax; });
+        S2V_TRY(dmalloc(v, &v->yt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
+        S2V_TRY(dmalloc(v, &v->bt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
+    }
     v->cur_h = v->cur_w = 0;
     return 0;
 }
@@ -302,7 +308,7 @@ static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int e
     g.M = F * H * W; g.N = c.cout; g.K = taps * c.cin;
     g.R = resid; g.ldr = c.cout;
     g.conv = 1; g.cin = c.cin; g.Hp = H + 2; g.Wp = W + 2; g.oH = H; g.oW = W; g.kt = c.kt;
-    if (v->mfma && c.cin % 64 == 0 && c.cout >= 32) S2V_TRY(launch_gemm_bf16(g, epi, st));
+    if (v->mfma && c.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, epi, st));  // cout = 3 (conv_out) runs one padded 128-column tile
     else S2V_TRY(launch_gemm_simple(g, epi, v->dtype, st));
     if (c.kt == 3) {
         S2V_CHECK_HIP(hipMemcpyAsync(c.pad, c.pad + (int64_t)F * fb, fb, hipMemcpyDeviceToDevice, st));
@@ -317,7 +323,7 @@ static int run_snorm(s2v_vae* v, const SNormL& n, const void* x, int F, int H, i
     SNormArgs a{};
     a.x = x; a.F = F; a.H = H; a.W = W; a.C = n.C; a.G = v->G; a.sums = v->sums; a.eps = v->cfg.norm_eps;
     a.gn_w = n.gn_w; a.gn_b = n.gn_b; a.wy = n.wy; a.by = n.by; a.wb = n.wb; a.bb = n.bb;
-    a.zq = v->zq; a.Fz = Fz; a.hz = hz; a.wz = wz; a.Cz = v->Cz; a.out = out_pad; a.f_off = f_off; a.silu = 1;
+    a.zq = v->zq; a.Fz = Fz; a.hz = hz; a.wz = wz; a.Cz = v->Cz; a.out = out_pad; a.f_off = f_off; a.silu = 1; a.yt = v->yt; a.bt = v->bt;
     return launch_snorm_apply(a, v->dtype, st);
 }
 
@@ -337,6 +343,7 @@ static int decode_batch(s2v_vae* v, int Fz, int h, int w, bool first, char* dst,
                 GemmArgs g{};
                 g.A = v->dense[cur]; g.lda = r.cin; g.W = r.sc.w; g.ldw = r.cin; g.bias = r.sc.b;
                 g.C = v->dense[t2]; g.ldc = r.cout; g.M = F * H * W; g.N = r.cout; g.K = r.cin;
+                g.a_rows_padded = (int)rup64(g.M, 256);  // dense buffers carry a 256-row slack
                 if (v->mfma && r.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, EPI_BIAS, st));
                 else S2V_TRY(launch_gemm_simple(g, EPI_BIAS, v->dtype, st));
                 S2V_TRY(run_conv(v, r.c2, F, H, W, first, EPI_BIAS_ADD, v->dense[t2], v->dense[t2], st));

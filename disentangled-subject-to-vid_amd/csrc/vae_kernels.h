@@ -11,6 +11,7 @@ struct SNormArgs {
     const void* zq; int Fz, hz, wz, Cz;     // dense latent frames of this frame batch [Fz][hz][wz][Cz]
     void* out; int f_off;                   // padded [f_off + F][H+2][W+2][C]
     int silu;
+    void* yt; void* bt;                     // scratch [Fz*hz*wz][C] model dtype: conv_y / conv_b at latent resolution
 };
 
 int launch_latent_to_zq(const void* lat, int F, int C, int h, int w, float inv_sf, void* out, int y0, int x0, int th,

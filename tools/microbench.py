@@ -35,8 +35,10 @@ def bench_gemm():
         b = torch.zeros(N, device=DEV, dtype=torch.bfloat16)
         C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         f = lambda: L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, epi, 1, 0, L.stream_ptr()))
-        ms = timeit(f)
-        print(f"gemm {name:9s} M={M} N={N} K={K}: {ms:8.3f} ms  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
+        for impl in (2, 4):
+            L.lib().s2v_set_gemm_impl(impl)
+            ms = timeit(f)
+            print(f"gemm[{('tile128x128','ring256x128','stag256x128','r32-2blk','w128-4wave')[impl]}] {name:9s} M={M} N={N} K={K}: {ms:8.3f} ms  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
         t = timeit(lambda: torch.matmul(A, W.T), iters=5)
         print(f"   (hipBLASLt via torch.matmul: {t:8.3f} ms  {2*M*N*K/t/1e9:8.1f} TFLOP/s)", flush=True)
         del A, W, C
@@ -65,3 +67,28 @@ if __name__ == "__main__":
         bench_gemm()
     if "attn" in what:
         bench_attn()
+
+
+def bench_vae():
+    import time
+    cfg = s2v.VAEConfig(scaling_factor=0.7)
+    sd = s2v.weights.synthetic_vae_state_dict(cfg, seed=1, device=DEV)
+    vae = s2v.HipAutoencoderKLCogVideoX(cfg, torch.bfloat16, DEV)
+    vae.load_state_dict(sd)
+    del sd
+    lat = torch.randn(1, 13, 16, 60, 90, device=DEV).bfloat16()
+    for tiling in (False, True):
+        vae.use_tiling = tiling
+        y = vae.decode_latents(lat)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        y = vae.decode_latents(lat)
+        torch.cuda.synchronize()
+        dt = time.time() - t0
+        fl = 441.04e12 if tiling else 315.03e12
+        print(f"vae decode 13x60x90 -> {tuple(y.shape)} tiling={tiling}: {dt*1e3:8.1f} ms  {fl/dt/1e12:7.1f} TFLOP/s  "
+              f"finite={bool(torch.isfinite(y.float()).all())} mem={torch.cuda.mem_get_info()[0]/2**30:.0f} GiB free", flush=True)
+
+
+if "vae" in sys.argv[1:]:
+    bench_vae()
