@@ -12,8 +12,8 @@ W = (torch.randn(N, K, device=DEV) * 0.02).bfloat16()
 b = torch.zeros(N, device=DEV, dtype=torch.bfloat16)
 C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
 f = lambda: L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, 0, 1, 0, L.stream_ptr()))
-cases = [("w128 full", 4), ("w128 no-DMA", 4 | (1 << 8)), ("w128 DMA-only", 4 | (2 << 8)), ("w128 neither", 4 | (3 << 8)),
-         ("w128 no-wait", 4 | (4 << 8)), ("w128 DMA-only no-wait", 4 | (6 << 8)), ("stag full", 2)]
+cases = [("w128 full", 4), ("w128 no-DMA-wait", 4 | (1 << 8)), ("w128 no-DMA", 4 | (2 << 8)), ("w128 no-ds_read", 4 | (3 << 8)),
+         ("w128 no-MFMA", 4 | (4 << 8)), ("w128 no-barrier", 4 | (5 << 8))]
 for rep in range(2):
     for name, code in cases:
         L.lib().s2v_set_gemm_impl(code)

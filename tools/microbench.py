@@ -35,10 +35,10 @@ def bench_gemm():
         b = torch.zeros(N, device=DEV, dtype=torch.bfloat16)
         C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         f = lambda: L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, epi, 1, 0, L.stream_ptr()))
-        for impl in (2, 4):
+        for impl in (4, 5):
             L.lib().s2v_set_gemm_impl(impl)
             ms = timeit(f)
-            print(f"gemm[{('tile128x128','ring256x128','stag256x128','r32-2blk','w128-4wave')[impl]}] {name:9s} M={M} N={N} K={K}: {ms:8.3f} ms  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
+            print(f"gemm[{('tile128x128','ring256x128','stag256x128','r32-2blk','w128-4wave','w8-8wave')[impl]}] {name:9s} M={M} N={N} K={K}: {ms:8.3f} ms  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
         t = timeit(lambda: torch.matmul(A, W.T), iters=5)
         print(f"   (hipBLASLt via torch.matmul: {t:8.3f} ms  {2*M*N*K/t/1e9:8.1f} TFLOP/s)", flush=True)
         del A, W, C
