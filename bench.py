@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--graph", type=int, default=0, help="replay the step from a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-vae", action="store_true", help="skip the one-off VAE decode timing")
     args = ap.parse_args()
 
     s2v = importlib.import_module("disentangled-subject-to-vid_amd")
@@ -188,6 +189,29 @@ def main():
                     "algorithmic_flops_per_launch": flops[dom], "avg_launch_ms": per_kernel[dom]["avg_ms"],
                     "per_kernel": per_kernel}
 
+    video = None
+    if rank == 0 and not args.no_vae:
+        # wall-clock per video = 50 denoise steps + VAE decode (BASELINE.json metric, second half); decode is timed once
+        # outside the step timing, untiled (288 GB part) and tiled (what src/inference.py:204-207 enables)
+        vcfg = s2v.VAEConfig(scaling_factor=cfg.vae_scaling_factor)
+        vae = s2v.HipAutoencoderKLCogVideoX(vcfg, dt, dev)
+        vae.load_state_dict(s2v.weights.synthetic_vae_state_dict(vcfg, seed=7, device=dev))
+        dec = {}
+        for tiling in (False, True):
+            vae.use_tiling = tiling
+            vae.decode_latents(latents)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            frames = vae.decode_latents(latents)
+            torch.cuda.synchronize()
+            dec["tiled" if tiling else "untiled"] = time.perf_counter() - t1
+        step_s = elapsed / args.steps
+        video = {"denoise_steps": 50, "denoise_s": round(50 * step_s, 2),
+                 "vae_decode_untiled_s": round(dec["untiled"], 3), "vae_decode_tiled_s": round(dec["tiled"], 3),
+                 "s_per_video_untiled": round(50 * step_s + dec["untiled"], 2),
+                 "s_per_video_tiled": round(50 * step_s + dec["tiled"], 2),
+                 "frames": list(frames.shape), "frames_finite": bool(torch.isfinite(frames.float()).all().item())}
+        vae.close()
     if rank == 0:
         out = {
             "metric": "denoise steps/sec (CogVideoX-5B, 49f 720x480; one step = CFG-pair transformer forward + CFG + "
@@ -204,6 +228,7 @@ def main():
                        "weight_load_s": round(t_load, 2), "weight_broadcast_s": None if bcast_s is None else round(bcast_s, 3),
                        "outputs_finite": finite},
             "roofline": roofline,
+            "wall_clock_per_video": video,
         }
         if not args.no_cpu_baseline and args.gpus == 1:
             out["cpu_baseline"] = cpu_baseline(cfg, F, H, W, T)

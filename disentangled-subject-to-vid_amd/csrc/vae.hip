@@ -95,49 +95,66 @@ int launch_dense_to_padded(const void* in, int F, int H, int W, int C, void* out
 // ---------------------------------------------------------------------------------------------------
 // GroupNorm statistics: sums[g] = {sum x, sum x^2} in fp64 over P pixels x (C/G) channels
 #define GN_PIX_PER_BLOCK 512
+// Deterministic (no atomics): per-thread partials -> LDS [pixel lane][channel] -> per-channel sums in lane order ->
+// per-group fp64 block partials part[block][g][2]; gn_finalize_k adds the block partials in block order.
 template <typename T>
-__global__ __launch_bounds__(256) void gn_stats_k(const T* x, int64_t P, int C, int G, double* sums) {
+__global__ __launch_bounds__(256) void gn_stats_k(const T* x, int64_t P, int C, int G, double* part) {
     constexpr int VN = V16<T>::N;
-    __shared__ float s_sum[1024], s_sq[1024];
+    __shared__ float s_sum[256 * VN], s_sq[256 * VN];  // [pl][c] with ppi * C == 256 * VN
+    __shared__ float c_sum[1024], c_sq[1024];
     const int tid = threadIdx.x;
     const int vpp = C / VN;              // 16-byte vectors per pixel
     const int ppi = 256 / vpp;           // pixels per iteration
-    for (int c = tid; c < C; c += 256) { s_sum[c] = 0.f; s_sq[c] = 0.f; }
-    __syncthreads();
     const int vi = tid % vpp, pl = tid / vpp;
     float a[VN], q[VN];
 #pragma unroll
     for (int e = 0; e < VN; ++e) { a[e] = 0.f; q[e] = 0.f; }
     const int64_t p0 = (int64_t)blockIdx.x * GN_PIX_PER_BLOCK;
     const int64_t p1 = min(p0 + GN_PIX_PER_BLOCK, P);
-    if (pl < ppi) {
-        for (int64_t p = p0 + pl; p < p1; p += ppi) {
-            float v[VN];
-            V16<T>::ld(x + p * C + vi * VN, v);
+    for (int64_t p = p0 + pl; p < p1; p += ppi) {
+        float v[VN];
+        V16<T>::ld(x + p * C + vi * VN, v);
 #pragma unroll
-            for (int e = 0; e < VN; ++e) { a[e] += v[e]; q[e] += v[e] * v[e]; }
-        }
+        for (int e = 0; e < VN; ++e) { a[e] += v[e]; q[e] += v[e] * v[e]; }
+    }
 #pragma unroll
-        for (int e = 0; e < VN; ++e) { atomicAdd(&s_sum[vi * VN + e], a[e]); atomicAdd(&s_sq[vi * VN + e], q[e]); }
+    for (int e = 0; e < VN; ++e) { s_sum[pl * C + vi * VN + e] = a[e]; s_sq[pl * C + vi * VN + e] = q[e]; }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float s = 0.f, s2 = 0.f;
+        for (int l = 0; l < ppi; ++l) { s += s_sum[l * C + c]; s2 += s_sq[l * C + c]; }
+        c_sum[c] = s; c_sq[c] = s2;
     }
     __syncthreads();
     const int cpg = C / G;
     for (int g = tid; g < G; g += 256) {
         double s = 0.0, s2 = 0.0;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += (double)s_sum[c]; s2 += (double)s_sq[c]; }
-        atomicAdd(&sums[2 * g], s);
-        atomicAdd(&sums[2 * g + 1], s2);
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += (double)c_sum[c]; s2 += (double)c_sq[c]; }
+        part[((int64_t)blockIdx.x * G + g) * 2] = s;
+        part[((int64_t)blockIdx.x * G + g) * 2 + 1] = s2;
     }
 }
-int launch_gn_stats(const void* x, int64_t P, int C, int G, double* sums, int dtype, hipStream_t st) {
+__global__ void gn_finalize_k(const double* part, int nblocks, int G, double* sums) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G) return;
+    double s = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblocks; ++b) { s += part[((int64_t)b * G + g) * 2]; s2 += part[((int64_t)b * G + g) * 2 + 1]; }
+    sums[2 * g] = s;
+    sums[2 * g + 1] = s2;
+}
+int64_t gn_stats_scratch_bytes(int64_t P, int G) {
+    return ((P + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK) * G * 2 * (int64_t)sizeof(double);
+}
+int launch_gn_stats(const void* x, int64_t P, int C, int G, double* sums, double* part, int dtype, hipStream_t st) {
     const int VN = dtype == S2V_BF16 ? 8 : 4;
     S2V_REQUIRE(C % VN == 0 && C <= 1024 && 256 % (C / VN) == 0 && C % G == 0, "gn_stats: unsupported channel count");
-    S2V_CHECK_HIP(hipMemsetAsync(sums, 0, sizeof(double) * 2 * G, st));
+    S2V_REQUIRE(part != nullptr, "gn_stats: scratch missing");
     const unsigned grid = (unsigned)((P + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK);
     if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(gn_stats_k<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, P, C, G, sums);
+        hipLaunchKernelGGL(gn_stats_k<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, P, C, G, part);
     else
-        hipLaunchKernelGGL(gn_stats_k<float>, dim3(grid), dim3(256), 0, st, (const float*)x, P, C, G, sums);
+        hipLaunchKernelGGL(gn_stats_k<float>, dim3(grid), dim3(256), 0, st, (const float*)x, P, C, G, part);
+    hipLaunchKernelGGL(gn_finalize_k, dim3((G + 63) / 64), dim3(64), 0, st, part, (int)grid, G, sums);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }

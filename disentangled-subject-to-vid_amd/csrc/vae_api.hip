@@ -47,7 +47,7 @@ struct s2v_vae {
     char* dense[3] = {nullptr, nullptr, nullptr};
     int64_t dense_bytes = 0;
     char* zq = nullptr; char* yt = nullptr; char* bt = nullptr;
-    double* sums = nullptr;
+    double* sums = nullptr; double* gn_part = nullptr;
     std::vector<void*> geo_allocs;
     std::vector<char*> tiles; std::vector<int> tile_h, tile_w;
     int tiles_F = 0;
@@ -278,6 +278,12 @@ static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max) {
         for_each_conv(v, [&](ConvL& c) { cmax = c.cin > cmax ? c.cin : cmax; });
         S2V_TRY(dmalloc(v, &v->yt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
         S2V_TRY(dmalloc(v, &v->bt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
+        {
+            int lv = 0;
+            for (size_t s = 1; s < v->stages.size(); ++s) if (v->stages[s].has_up) lv++;
+            const int64_t pmax = (int64_t)v->fmax[lv] * ((int64_t)th << lv) * ((int64_t)tw << lv);
+            S2V_TRY(dmalloc(v, &v->gn_part, gn_stats_scratch_bytes(pmax, v->G) + 64, true));
+        }
     }
     v->cur_h = v->cur_w = 0;
     return 0;
@@ -319,7 +325,7 @@ static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int e
 
 static int run_snorm(s2v_vae* v, const SNormL& n, const void* x, int F, int H, int W, int Fz, int hz, int wz, void* out_pad,
                      int f_off, hipStream_t st) {
-    S2V_TRY(launch_gn_stats(x, (int64_t)F * H * W, n.C, v->G, v->sums, v->dtype, st));
+    S2V_TRY(launch_gn_stats(x, (int64_t)F * H * W, n.C, v->G, v->sums, v->gn_part, v->dtype, st));
     SNormArgs a{};
     a.x = x; a.F = F; a.H = H; a.W = W; a.C = n.C; a.G = v->G; a.sums = v->sums; a.eps = v->cfg.norm_eps;
     a.gn_w = n.gn_w; a.gn_b = n.gn_b; a.wy = n.wy; a.by = n.by; a.wb = n.wb; a.bb = n.bb;

@@ -17,7 +17,8 @@ struct SNormArgs {
 int launch_latent_to_zq(const void* lat, int F, int C, int h, int w, float inv_sf, void* out, int y0, int x0, int th,
                         int tw, int dtype, hipStream_t st);
 int launch_dense_to_padded(const void* in, int F, int H, int W, int C, void* out, int f_off, int dtype, hipStream_t st);
-int launch_gn_stats(const void* x, int64_t P, int C, int G, double* sums, int dtype, hipStream_t st);
+int64_t gn_stats_scratch_bytes(int64_t P, int G);
+int launch_gn_stats(const void* x, int64_t P, int C, int G, double* sums, double* part_scratch, int dtype, hipStream_t st);
 int launch_snorm_apply(const SNormArgs& a, int dtype, hipStream_t st);
 int launch_upsample(const void* x, int F, int H, int W, int C, int compress_time, void* out, int dtype, hipStream_t st);
 int launch_to_ncfhw(const void* y, int F, int H, int W, int Co, void* out, int Ftot, int f0, int dtype, hipStream_t st);

@@ -1,0 +1,133 @@
+"""Size-independent properties at BASELINE.json's full sizes (CogVideoX-5B width, 49x480x720 -> N = 19126 tokens),
+where the CPU oracle would take hours: softmax normalisation, row independence of the GEMM, CFG-pair symmetry,
+determinism, replica weight-arena aliasing."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+N_FULL, H5B = 19126, 48
+
+
+def test_attention_full_size_constant_value_rows(s2v):
+    """softmax rows sum to 1: with V[:, h, d] constant over the keys the output must equal that constant"""
+    B, H, N = 1, H5B, N_FULL
+    D = H * 64
+    g = torch.Generator(device=DEV).manual_seed(0)
+    qkv = torch.randn(B * N + 64, 3 * D, generator=g, device=DEV).bfloat16()
+    const = torch.randn(D, generator=g, device=DEV).bfloat16()
+    qkv[:, 2 * D:] = const
+    out = torch.empty(B * N, D, dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros(B * H * 64 * ((N + 63) // 64 * 64), dtype=torch.bfloat16, device=DEV)
+    L = s2v._lib
+    L.check(L.lib().s2v_op_attention(L.ptr(qkv), L.ptr(vt), L.ptr(out), B, H, N, L.DTYPE_BF16, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    err = (out.float() - const.float()[None, :]).abs().max().item()
+    assert err <= 2e-2 * const.float().abs().max().item() + 1e-3, err
+
+
+def test_gemm_full_size_row_independence(s2v):
+    """C = A W^T: duplicating the rows of A must duplicate the rows of C bit for bit, whatever tile they land in"""
+    M, N, K = 38400, 3072, 3072
+    g = torch.Generator(device=DEV).manual_seed(1)
+    half = (torch.randn(M // 2, K, generator=g, device=DEV) * 0.5).bfloat16()
+    A = torch.cat([half, half]).contiguous()
+    W = (torch.randn(N, K, generator=g, device=DEV) * 0.05).bfloat16()
+    b = torch.randn(N, generator=g, device=DEV).bfloat16()
+    C = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    L = s2v._lib
+    L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, 0, L.DTYPE_BF16, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(C[: M // 2], C[M // 2:])
+    # spot-check 64 rows against fp32 math
+    idx = torch.randint(0, M, (64,), generator=torch.Generator().manual_seed(2))
+    ref = A[idx].float() @ W.float().T + b.float()
+    assert (C[idx].float() - ref).abs().max() <= 2e-2 * ref.abs().max()
+
+
+def test_transformer_full_tokens_cfg_symmetry_and_determinism(s2v):
+    """5B width, 2 layers, the full 226+1350+17550 tokens: identical cond/uncond text => identical halves of the CFG
+    pair (bitwise); a second run reproduces the first bitwise; the hipGraph replay equals the eager launch sequence."""
+    cfg = s2v.cogvideox_5b()
+    cfg.num_layers = 2
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=3, device=DEV, parity=True)
+    m = s2v.HipCogVideoXTransformer3DModel(cfg, torch.bfloat16, DEV)
+    m.load_state_dict(sd)
+    del sd
+    eng = m.engine
+    g = torch.Generator(device=DEV).manual_seed(4)
+    F, H, W, T = 13, 60, 90, 226
+    t1 = torch.randn(1, T, 4096, generator=g, device=DEV)
+    text = torch.cat([t1, t1])
+    ref = torch.randn(1, 1, 16, H, W, generator=g, device=DEV) * 0.7
+    lat = torch.randn(1, F, 16, H, W, generator=g, device=DEV).bfloat16()
+    eng.set_geometry(2, T, F, H, W)
+    eng.prepare_tables(480, 720)
+    eng.set_conditioning(text, ref)
+    ts = torch.tensor([500.0, 500.0])
+    y1 = eng.forward(lat, ts, shared_latent=True)
+    y2 = eng.forward(lat, ts, shared_latent=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y1.float()).all()
+    assert torch.equal(y1[0], y1[1]), "CFG pair with identical conditioning must be symmetric"
+    assert torch.equal(y1, y2), "forward must be deterministic"
+    sch = s2v.CogVideoXDDIMScheduler(snr_shift_scale=1.0)
+    sch.set_timesteps(50)
+    a, b = lat.clone(), lat.clone()
+    for i in range(2):
+        t = sch.timesteps[i]
+        eng.denoise_step(a, float(t), sch.coef(t, torch.bfloat16, 6.0), use_graph=False)
+    for i in range(2):
+        t = sch.timesteps[i]
+        eng.denoise_step(b, float(t), sch.coef(t, torch.bfloat16, 6.0), use_graph=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b), "graph replay must equal the eager launch sequence"
+
+
+def test_weight_arena_view_and_single_rank_broadcast(s2v):
+    """the packed weight arena is exposed as ONE device range (what the RCCL broadcast replicates)"""
+    cfg = s2v.tiny()
+    eng = s2v.S2VEngine(cfg, torch.bfloat16, DEV)
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=5, parity=True)
+    eng.load_state_dict(sd)
+    arena = eng.weight_arena()
+    assert arena.dtype == torch.uint8 and arena.is_cuda and arena.numel() > 1 << 16
+    snap = arena.clone()
+    eng2 = s2v.S2VEngine(cfg, torch.bfloat16, DEV)
+    eng2.weight_arena().copy_(arena)         # what dist.broadcast does on the receiving rank
+    eng2.mark_weights_loaded()
+    for e in (eng, eng2):
+        e.set_geometry(2, 5, 2, 8, 8)
+        e.prepare_tables(64, 64)
+    g = torch.Generator().manual_seed(6)
+    text, ref = torch.randn(2, 5, 64, generator=g), torch.randn(1, 1, 16, 8, 8, generator=g)
+    lat = torch.randn(2, 2, 16, 8, 8, generator=g)
+    outs = []
+    for e in (eng, eng2):
+        e.set_conditioning(text, ref)
+        outs.append(e.forward(lat, torch.tensor([10.0, 10.0])))
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+    assert torch.equal(arena, snap)
+    assert s2v.dist.broadcast_arena(arena) == 0  # not initialised / world size 1: no-op
+
+
+def test_vae_full_size_tiled_decode_is_deterministic_and_finite(s2v):
+    cfg = s2v.VAEConfig(scaling_factor=0.7)
+    sd = s2v.weights.synthetic_vae_state_dict(cfg, seed=7, device=DEV)
+    vae = s2v.HipAutoencoderKLCogVideoX(cfg, torch.bfloat16, DEV)
+    vae.load_state_dict(sd)
+    del sd
+    vae.enable_tiling()
+    lat = torch.randn(1, 13, 16, 60, 90, generator=torch.Generator(device=DEV).manual_seed(8), device=DEV).bfloat16()
+    y1 = vae.decode_latents(lat)
+    y2 = vae.decode_latents(lat)
+    torch.cuda.synchronize()
+    assert tuple(y1.shape) == (1, 3, 49, 480, 720)
+    assert torch.isfinite(y1.float()).all()
+    assert torch.equal(y1, y2)
+    frames = vae.postprocess_video(y1, "pt")
+    assert frames.shape == (1, 49, 3, 480, 720) and frames.min() >= 0 and frames.max() <= 1

@@ -18,7 +18,7 @@ if os.path.exists(db):
     c = sqlite3.connect(db)
     rows = list(c.execute("select name,total_calls,total_duration,average,percentage from top_kernels order by total_duration desc limit 25"))
     with open(f"profiles/{tag}_kernel_stats.csv", "w") as f:
-        f.write("kernel,calls,total_us,avg_us,percent\n")
+        f.write("kernel,calls,total_ms,avg_ms,percent\n")
         for n, calls, tot, avg, pct in rows:
             f.write(f"\"{short(n)}\",{calls},{tot/1e3:.1f},{avg/1e3:.2f},{pct:.2f}\n")
     print("wrote", f"profiles/{tag}_kernel_stats.csv")
