@@ -85,6 +85,35 @@ def cpu_baseline(cfg, F, H, W, T, budget_s=60.0):
                       f"fp32 on {cores} threads: {dt:.1f} s, extrapolated x{2 * cfg.num_layers}"}
 
 
+KERNEL_OF_CLASS = {"attention": "attn_bf16_k", "gemm_qkv": "gemm_bf16_w8<0>", "gemm_ff1_gelu": "gemm_bf16_w8<1>",
+                   "gemm_out": "gemm_bf16_w8<2>", "gemm_ff2": "gemm_bf16_w8<2>"}
+
+
+def pmc_traffic_bytes(kernel_class):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_pmc_*.csv:
+    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  FETCH_SIZE is doubled: on gfx950 it reports
+    half the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM section).  None when no profile is present."""
+    import csv
+    import glob
+
+    name = KERNEL_OF_CLASS.get(kernel_class)
+    fetch = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch.csv")))
+    write = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_write.csv")))
+    if not name or not fetch or not write:
+        return None
+
+    def mean_kb(path):
+        for row in csv.reader(open(path)):
+            if row and row[0] == name:
+                return float(row[2])
+        return None
+
+    f, w = mean_kb(fetch[-1]), mean_kb(write[-1])
+    if f is None or w is None:
+        return None
+    return int((2.0 * f + w) * 1024)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -185,7 +214,8 @@ def main():
         dom = max((n for n in per_kernel if n in flops), key=lambda n: per_kernel[n]["avg_ms"] * per_kernel[n]["launches"])
         ach = per_kernel[dom]["tflops"]
         roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic_bytes(dom),
+                    "traffic_unit": "bytes/launch (profiles/rNN_pmc_{fetch,write}.csv, FETCH_SIZE x2 per MI355X_MICROARCH)",
                     "algorithmic_flops_per_launch": flops[dom], "avg_launch_ms": per_kernel[dom]["avg_ms"],
                     "per_kernel": per_kernel}
 

@@ -67,6 +67,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb)
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) ot[i][e] = 0.f;
+    f32x16 zero16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
     const float c = a.scale * 1.4426950408889634f;
 
@@ -90,10 +93,10 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb)
         f32x16 st[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            // first MFMA of the chain takes the loop-invariant zero block as C: no 32 v_mov per tile
+            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag64(tK, kb * 32 + fr, hi), qf[0], zero16, 0, 0, 0);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) st[kb][e] = 0.f;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 1; kk < 4; ++kk) {
                 bf16x8 kf = frag64(tK, kb * 32 + fr, kk * 2 + hi);
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kb], 0, 0, 0);
             }
@@ -114,7 +117,16 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb)
             for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[kb][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        // exact skip: when no row of the wave raised its running max, alpha == 1 for every lane
+        const bool grew = __any(m_new > m_run);
+        if (grew) {
+            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
+        }
         const float mc = m_new * c;
         m_run = m_new;
         float psum = 0.f;
@@ -126,11 +138,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb)
                 st[kb][e] = p;
                 psum += p;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
+        l_run += psum;
 
         // O^T[d][q] += V^T[d][kv] . P^T[kv][q]; k-step s covers keys 16s..16s+15 of the tile
 #pragma unroll
