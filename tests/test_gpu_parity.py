@@ -256,3 +256,42 @@ def test_medium_model_vs_oracle(s2v, dt_name, use_rope):
           return_dict=False, eval=True, **kw)[0]
     torch.cuda.synchronize()
     assert_close(y, exp, dt_name, "medium transformer")
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[0]
+@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+def test_cogvideox_2b_width_c1_geometry_vs_oracle(s2v, dt_name):
+    """BASELINE.json configs[0] geometry (CogVideoX-2B width D = 1920, non-RoPE, 9 frames 256x256 -> latents 3x32x32,
+    N = 226 + 256 + 768 = 1250 tokens), 2 of the 30 layers, one full denoise step (CFG + DDIM) against the CPU oracle.
+    D = 1920 is not a multiple of 256: exercises the padded-tile GEMM paths."""
+    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    cfg = s2v.cogvideox_2b()
+    cfg.num_layers = 2
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=11, parity=True)
+    g = torch.Generator().manual_seed(12)
+    F, H, W, T = 3, 32, 32, 226
+    lat = torch.randn(1, F, 16, H, W, generator=g).to(dt)
+    text = torch.randn(2, T, 4096, generator=g).to(dt)
+    ref = (torch.randn(1, 1, 16, H, W, generator=g) * 0.7).to(dt)
+    sch = s2v.CogVideoXDDIMScheduler(snr_shift_scale=3.0)
+    sch.set_timesteps(10)
+    t = sch.timesteps[2]
+    ocfg = dict(num_heads=30, num_layers=2, use_rope=False, norm_eps=1e-5)
+    with torch.no_grad():
+        npred = tr.transformer_forward({k: v.to(dt) for k, v in sd.items()}, ocfg, torch.cat([lat] * 2), text, ref,
+                                       torch.tensor([int(t), int(t)]))
+        v = sched_ref.cfg_combine(npred, 6.0)
+        exp, _ = sched_ref.ddim_step(sched_ref.alphas_cumprod(3.0), 10, v, int(t), lat)
+        exp = exp.to(dt).float()
+    m = s2v.HipCogVideoXTransformer3DModel(cfg, dt, DEV)
+    m.load_state_dict(sd)
+    eng = m.engine
+    eng.set_geometry(2, T, F, H, W)
+    eng.prepare_tables(256, 256)
+    eng.set_conditioning(text, ref)
+    x = lat.to(DEV).contiguous().clone()
+    eng.denoise_step(x, float(t), sch.coef(t, dt, 6.0))
+    torch.cuda.synchronize()
+    npred_hip = eng.last_noise_pred()
+    assert_close(npred_hip, npred, dt_name, "2B noise_pred")
+    assert_close(x, exp, dt_name, "2B latents after one step")
