@@ -9,3 +9,4 @@ from .transformer import HipCogVideoXAttnProcessor2_0, HipCogVideoXBlock, HipCog
 from .pipeline import S2VPipeline  # noqa: F401
 from .vae import HipAutoencoderKLCogVideoX  # noqa: F401
 from . import dist  # noqa: F401
+from . import checkpoint  # noqa: F401
