@@ -37,6 +37,7 @@ __device__ __forceinline__ bf16x8 frag64(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + row * 128 + ((cl ^ ((row >> 1) & 7)) << 4));
 }
 
+template <int ABL>
 __global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K tile | VT tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -114,7 +115,8 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb)
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) mx = fmaxf(mx, st[kb][e]);
+            for (int e = 0; e < 16; ++e)
+                if (ABL != 3) mx = fmaxf(mx, st[kb][e]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         // exact skip: when no row of the wave raised its running max, alpha == 1 for every lane
@@ -134,9 +136,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb)
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = __builtin_amdgcn_exp2f(st[kb][e] * c - mc);
+                const float p = (ABL == 1) ? (st[kb][e] * c - mc) : __builtin_amdgcn_exp2f(st[kb][e] * c - mc);
                 st[kb][e] = p;
-                psum += p;
+                if (ABL != 2) psum += p;
             }
         l_run += psum;
 
@@ -173,13 +175,21 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb)
     }
 }
 
+int g_attn_variant = 0;  // diagnostics (tools/microbench.py): timing-only ablations of the softmax VALU work
+extern "C" int s2v_set_attn_variant(int v) { g_attn_variant = v; return 0; }
+
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
     S2V_REQUIRE(a.vt != nullptr, "attn_bf16: V^T buffer missing");
     S2V_REQUIRE(a.ld_qkv % 8 == 0 && a.ntok_pad % 64 == 0, "attn_bf16: bad leading dims");
     S2V_REQUIRE(a.ntok_pad >= ((a.Ntok + 63) / 64) * 64, "attn_bf16: ntok_pad too small");
     const int nqb = (a.Ntok + Q_BLOCK - 1) / Q_BLOCK;
     const int grid = nqb * a.B * a.H;
-    hipLaunchKernelGGL(attn_bf16_k, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb);
+    switch (g_attn_variant) {
+        case 1: hipLaunchKernelGGL(attn_bf16_k<1>, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
+        case 2: hipLaunchKernelGGL(attn_bf16_k<2>, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
+        case 3: hipLaunchKernelGGL(attn_bf16_k<3>, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
+        default: hipLaunchKernelGGL(attn_bf16_k<0>, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
+    }
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }

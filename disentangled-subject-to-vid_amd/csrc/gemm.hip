@@ -1097,6 +1097,600 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_w8(const GemmArgs a, int til
         }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// gemm_bf16_pp: gemm_bf16_w8's tile / wave layout / LDS ring, re-timed as a PING-PONG of the two waves that share a SIMD.
+// Waves 0-3 (group 0, wm = 0) and 4-7 (group 1, wm = 1) run one barrier interval apart; a half-step (K = 32) of a wave is
+//     LOAD segment   : 12 ds_read_b128 (its fragments of half-tile k) + 4 LDS-DMA pieces of a later half-tile
+//     s_barrier
+//     COMPUTE segment: s_setprio 1, 16 MFMA 32x32x16, s_setprio 0
+//     s_barrier
+// so in every barrier interval one wave of each SIMD streams MFMAs while its partner does the LDS / DMA work for its own
+// next cluster: a wave stalled on an ds_read or LDS-DMA issue never holds the matrix pipe's instruction stream.
+// Interval numbering (I_n = n-th barrier interval): group 0 loads half-tile k in I_2k and computes in I_2k+1; group 1 loads
+// in I_2k+1 and computes in I_2k+2.  Ring of four 32-KiB stages, half-tile j in stage j & 3:
+//   RAW  half-tile j must be in LDS when I_2j starts: group 0 waits vmcnt(4) at the end of compute(j-1) (it has issued up
+//        to DMA(j+1)); group 1 waits vmcnt(8) at the end of load(j-1) (issued up to DMA(j+2)); both inside I_2j-1.
+//   WAR  stage j & 3 is last read by group 1 in I_2j+1, whose lgkmcnt(0) sits after the barrier that opens I_2j+2; the DMA
+//        of half-tile j+4 is issued in I_2j+3 (group 1, load(j+1): DMA(k+3)) and I_2j+4 (group 0, load(j+2): DMA(k+2)).
+// Past the end of K the DMA re-loads the last half-tile into the stage it would have used (never read again), so the
+// counts stay constant.  Group 1 executes one extra barrier before its loop, group 0 one after.
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g = wm;  // ping-pong group
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = wg - group * per_group;
+    const int m0 = (first_m + in_g % gsz) * WBM, n0 = (in_g / gsz) * WBN;
+
+    const int srow = tid >> 2;
+    const int scol = ((tid & 3) ^ ((srow >> 2) & 3)) * 8;
+    const bf16_t* pA = (const bf16_t*)a.A + a_row_base(a, m0 + srow) + scol;
+    const bf16_t* pW = (const bf16_t*)a.W + (int64_t)(n0 + srow) * a.ldw + scol;
+    const int dA1 = (int)(a_row_base(a, m0 + srow + 128) - a_row_base(a, m0 + srow));
+    const int64_t dW1 = (int64_t)128 * a.ldw;
+    const int nh = a.K / K32;
+    auto dma = [&](int t) {  // the thread's 4 pieces of half-tile min(t, nh-1) into stage t & 3
+        const int tc = min(t, nh - 1);
+        const int64_t ka = a.conv ? a_k_off(a, tc * K32) : (int64_t)tc * K32;
+        char* base = smem + (t & 3) * WH_STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pA + i * dA1 + ka),
+                                             (__attribute__((address_space(3))) void*)(base + i * 8192), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pW + i * dW1 + tc * K32),
+                                             (__attribute__((address_space(3))) void*)(base + WH_A + i * 8192), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[2][4];  // [n block][m block]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, hi = lane >> 5;
+    dma(0);
+    dma(1);
+    if (g) {
+        dma(2);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();  // opens I_0
+    if (g) __builtin_amdgcn_s_barrier();  // group 1 idles through I_0
+
+    bf16x8 wf[2][2], af[2][4];
+    for (int k = 0; k < nh; ++k) {
+        // ---- LOAD segment
+        const char* tA = smem + (k & 3) * WH_STAGE;
+        const char* tW = tA + WH_A;
+        if (ABL != 2 || k == 0) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) wf[kk][i] = lds_frag32(tW, wn * 64 + i * 32 + fr, kk * 2 + hi);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) af[kk][j] = lds_frag32(tA, wm * 128 + j * 32 + fr, kk * 2 + hi);
+            }
+        }
+        if (ABL != 1) {
+            dma(k + 2 + g);
+            if (g) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        // ---- COMPUTE segment
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ABL != 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
+                    else asm volatile("" ::"v"(wf[kk][i]), "v"(af[kk][j]));
+                }
+        __builtin_amdgcn_s_setprio(0);
+        if (!g && ABL != 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+    }
+    if (!g) __builtin_amdgcn_s_barrier();  // pairs with group 1's last compute segment
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    char* patch = smem + wave * 8192;
+    if (epi_vec_ok(a, EPI)) {
+#pragma unroll
+        for (int qj = 0; qj < 2; ++qj) {
+            f32x16 sub[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) sub[i][j] = acc[i][qj * 2 + j];
+            epilogue_wave64<EPI>(a, sub, m0 + wm * 128 + qj * 64, n0 + wn * 64, patch, lane);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 128 + j * 32 + fr;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
+                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
+                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
+            }
+        }
+}
+
+template <int EPI>
+static int launch_pp_t(const GemmArgs& a, hipStream_t st) {
+    const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WH_NST * WH_STAGE));
+        attr_set = true;
+    }
+    if (EPI == EPI_BIAS && a.ablate) {  // diagnostics only (tools/ablate_gemm.py)
+        const void* fn = a.ablate == 1 ? (const void*)gemm_bf16_pp<EPI_BIAS, 1> : a.ablate == 2 ? (const void*)gemm_bf16_pp<EPI_BIAS, 2> : (const void*)gemm_bf16_pp<EPI_BIAS, 3>;
+        S2V_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WH_NST * WH_STAGE));
+        void* args[] = {(void*)&a, (void*)&tiles_m, (void*)&tiles_n};
+        S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(tiles_m * tiles_n), dim3(512), args, WH_NST * WH_STAGE, st));
+        return 0;
+    }
+    hipLaunchKernelGGL(gemm_bf16_pp<EPI>, dim3(tiles_m * tiles_n), dim3(512), WH_NST * WH_STAGE, st, a, tiles_m, tiles_n);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+__device__ long long g_pp_dbg[64];  // diagnostics (ABL == 4)
+extern "C" int s2v_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
+
+// LDS-DMA of 16 B per lane in the saddr + 32-bit voffset form: global address = sbase (wave-uniform, SGPR pair) + voff
+// (per-lane byte offset), LDS address = M0 + 16 * lane.  hipcc picks the 64-bit vaddr form inside loops; this pins the
+// cheaper one (one address VGPR per lane instead of two).
+__device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, char* lds_dst) {
+    const unsigned m0v = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
+                 :
+                 : "s"(sbase), "v"(voff), "s"(__builtin_amdgcn_readfirstlane(m0v))
+                 : "memory", "m0");
+}
+
+// gemm_bf16_pp64: the ping-pong schedule of gemm_bf16_pp on K-tiles of 64 with 128-byte LDS rows, so every LDS-DMA lane
+// group fetches a FULL 128-B line (gemm_bf16_pp / _w8 fetch 64-B half lines: twice the L2 requests for the same bytes, and
+// the measured DMA-only time of those kernels equals their MFMA-only time).  Two 64-KiB stages; a K-tile is four
+// 16-KiB operand halves  A-lo | A-hi | W-lo | W-hi  (128 rows x 128 B, chunk ^= (row >> 1) & 7).  Group 0 (waves 0-3, A rows
+// 0-127) stages A-lo and W-lo, group 1 (waves 4-7) stages A-hi and W-hi: 4 pieces per thread per half-step, like pp.
+// Barrier intervals: group 0 loads half-step h = 2T + s of K-tile T in I_2h and computes in I_2h+1, group 1 one later.
+//   group 0, tile T:  I_4T   reads(T,0) + DMA A-lo(T+1)      I_4T+1 MFMA
+//                     I_4T+2 reads(T,1) + DMA W-lo(T+1)      I_4T+3 MFMA, vmcnt(0)
+//   group 1, tile T:  I_4T+1 reads(T,0) + DMA W-hi(T+1)      I_4T+2 MFMA
+//                     I_4T+3 reads(T,1) + DMA A-hi(T+1), vmcnt(4)   I_4T+4 MFMA, vmcnt(0)
+//   WAR  stage (T+1)&1 held tile T-1: A-lo(T-1) is last read in I_4T-2 (group 0 only), W-*(T-1) and A-hi(T-1) in I_4T-1;
+//        each read's lgkmcnt(0) sits after the next barrier, and one more barrier precedes the DMA issue above.
+//   RAW  tile T+1 is first read in I_4T+4 (A-lo, W-lo, W-hi) and I_4T+5 (A-hi): the waits above sit in I_4T+3 / I_4T+4.
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int g = wm, w4 = wave & 3;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = wg - group * per_group;
+    const int m0 = (first_m + in_g % gsz) * WBM, n0 = (in_g / gsz) * WBN;
+
+    // staging: piece i (0..3) of this wave covers rows g*128 + i*32 + w4*8 + (lane>>3), 8 chunks of 16 B each
+    const int srow = g * 128 + w4 * 8 + (lane >> 3);
+    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) * 8;
+    // addresses = wave-uniform tile base (SGPR pair) + per-lane 32-bit byte offset (loop-invariant VGPR): the LDS-DMA takes
+    // the saddr + voffset form and the load segment carries no address VALU
+    const int64_t rbase0 = a_row_base(a, m0);
+    const char* Abase = (const char*)a.A + 2 * rbase0;
+    const char* Wbase = (const char*)a.W + 2 * (int64_t)n0 * a.ldw;
+    unsigned offA[4], offW[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        offA[i] = (unsigned)(2 * (a_row_base(a, m0 + srow + i * 32) - rbase0 + scol));
+        offW[i] = (unsigned)(2 * ((int64_t)(srow + i * 32) * a.ldw + scol));
+    }
+    const int nT = a.K / BK;
+    const int ldst = (g * 128 + w4 * 8) * 128;  // byte offset of the wave's piece 0 inside an operand image
+    auto dma_a = [&](int t) {
+        if (ABL == 1 && t > 0) return;
+        const int tc = min(t, nT - 1);
+        const int64_t ka = a.conv ? a_k_off(a, tc * BK) : (int64_t)tc * BK;
+        const char* tb = Abase + 2 * ka;
+        char* base = smem + (t & 1) * 65536 + ldst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            glds16_saddr(tb, offA[i], base + i * 4096);
+    };
+    auto dma_w = [&](int t) {
+        if (ABL == 1 && t > 0) return;
+        const int tc = min(t, nT - 1);
+        const char* tb = Wbase + 2 * (int64_t)tc * BK;
+        char* base = smem + (t & 1) * 65536 + 32768 + ldst;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            glds16_saddr(tb, offW[i], base + i * 4096);
+    };
+
+    f32x16 acc[2][4];  // [n block][m block]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, hi = lane >> 5;
+    dma_a(0);
+    dma_w(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // opens I_0
+    if (g) __builtin_amdgcn_s_barrier();  // group 1 idles through I_0
+
+    bf16x8 wf[2][2], af[2][4];
+    auto reads = [&](int t, int s) {
+        if (ABL == 6 && t > 0) return;
+        const char* tA = smem + (t & 1) * 65536;
+        const char* tW = tA + 32768;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[kk][i] = lds_frag(tW, wn * 64 + i * 32 + fr, s * 4 + kk * 2 + hi);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[kk][j] = lds_frag(tA, wm * 128 + j * 32 + fr, s * 4 + kk * 2 + hi);
+        }
+    };
+    // (ABL >= 4): per-wave stall accounting with s_memtime (diagnostics; totals of block 100 go to g_pp_dbg[8][6])
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> long long { return (ABL >= 4) ? (long long)__builtin_amdgcn_s_memtime() : 0; };
+    auto cluster = [&](bool tile_end) {
+        __builtin_amdgcn_sched_barrier(0);
+        const long long t0 = now();
+        __builtin_amdgcn_s_barrier();
+        const long long t1 = now();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const long long t2 = now();
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL != 7) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (ABL != 3 && ABL != 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
+                    else asm volatile("" ::"v"(wf[kk][i]), "v"(af[kk][j]));
+                }
+        if (ABL != 7) __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        const long long t3 = now();
+        if (tile_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long t4 = now();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        const long long t5 = now();
+        if ((ABL >= 4)) {
+            tacc[0] += t1 - t0;  // barrier after the load segment
+            tacc[1] += t2 - t1;  // lgkmcnt(0)
+            tacc[2] += t3 - t2;  // MFMA cluster issue
+            tacc[3] += t4 - t3;  // vmcnt(0) at the tile end
+            tacc[4] += t5 - t4;  // barrier after the compute segment
+        }
+    };
+    const long long tl0 = now();
+    for (int t = 0; t < nT; ++t) {
+        const long long u0 = now();
+        reads(t, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const long long u1 = now();
+        if (g) dma_w(t + 1);
+        else dma_a(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const long long u2 = now();
+        cluster(false);
+        const long long u3 = now();
+        reads(t, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const long long u4 = now();
+        if (g) {
+            dma_a(t + 1);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            dma_w(t + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const long long u5 = now();
+        cluster(true);
+        if ((ABL >= 4)) {
+            tacc[6] += (u1 - u0) + (u4 - u3);  // ds_read issue
+            tacc[7] += (u2 - u1) + (u5 - u4);  // LDS-DMA issue (+ group 1's vmcnt(4))
+        }
+    }
+    if ((ABL >= 4)) {
+        tacc[5] = now() - tl0;
+        if (blockIdx.x == 100 && lane == 0)
+            for (int e = 0; e < 8; ++e) g_pp_dbg[wave * 8 + e] = tacc[e];
+    }
+    if (!g) __builtin_amdgcn_s_barrier();  // pairs with group 1's last compute segment
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    char* patch = smem + wave * 8192;
+    if (epi_vec_ok(a, EPI)) {
+#pragma unroll
+        for (int qj = 0; qj < 2; ++qj) {
+            f32x16 sub[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) sub[i][j] = acc[i][qj * 2 + j];
+            epilogue_wave64<EPI>(a, sub, m0 + wm * 128 + qj * 64, n0 + wn * 64, patch, lane);
+        }
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + wm * 128 + j * 32 + fr;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
+                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
+                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
+            }
+        }
+}
+
+template <int EPI>
+static int launch_pp64_t(const GemmArgs& a, hipStream_t st) {
+    const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp64<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr_set = true;
+    }
+    if (EPI == EPI_BIAS && a.ablate) {  // diagnostics only (tools/ablate_gemm.py)
+        const void* fn = a.ablate == 1 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 1> : a.ablate == 4 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 4> : a.ablate == 5 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 5> : a.ablate == 6 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 6> : a.ablate == 7 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 7> : (const void*)gemm_bf16_pp64<EPI_BIAS, 3>;
+        S2V_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        void* args[] = {(void*)&a, (void*)&tiles_m, (void*)&tiles_n};
+        S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(tiles_m * tiles_n), dim3(512), args, 131072, st));
+        return 0;
+    }
+    hipLaunchKernelGGL(gemm_bf16_pp64<EPI>, dim3(tiles_m * tiles_n), dim3(512), 131072, st, a, tiles_m, tiles_n);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gemm_bf16_pp16: gemm_bf16_pp64's tile, LDS image and barrier-interval schedule with SIXTEEN waves (4 x 4 wave tiles of
+// 64 x 64, 4 waves per SIMD, <= 128 VGPRs).  Measured on pp64 (s_memtime): one LDS-DMA piece costs the issuing wave ~120
+// cycles and one ds_read_b128 ~15, so an 8-wave half-step needs 180 + 480 cycles of load segment per wave against the
+// 512 MFMA cycles of its SIMD partner, and the computing wave waits ~200 cycles per half-step at the barrier.  Per-wave DMA
+// issue is serial, CU throughput comes from the number of waves issuing.  With 16 waves a load segment is 8 reads + 2
+// pieces (~360 cycles) while the SIMD's other two waves issue 2 x 8 MFMA = 512 cycles.
+// Groups: waves 0-7 (A rows 0-127; stage A-lo, W-lo) and waves 8-15 (A rows 128-255; stage A-hi, W-hi); waves w, w+4, w+8,
+// w+12 share a SIMD, i.e. two of each group.  Interval numbering, RAW / WAR argument: see gemm_bf16_pp64.
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(1024) void gemm_bf16_pp16(const GemmArgs a, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = wave >> 3, r8 = wave & 7;
+    const int wm = g * 2 + (r8 >> 2), wn = r8 & 3;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int GM = 4;
+    const int per_group = GM * tiles_n;
+    const int group = wg / per_group;
+    const int first_m = group * GM;
+    const int gsz = min(tiles_m - first_m, GM);
+    const int in_g = wg - group * per_group;
+    const int m0 = (first_m + in_g % gsz) * WBM, n0 = (in_g / gsz) * WBN;
+
+    // staging: piece i (0..1) of this wave covers rows g*128 + i*64 + r8*8 + (lane>>3), 8 chunks of 16 B each
+    const int srow = g * 128 + r8 * 8 + (lane >> 3);
+    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) * 8;
+    const int64_t rbase0 = a_row_base(a, m0);
+    const char* Abase = (const char*)a.A + 2 * rbase0;
+    const char* Wbase = (const char*)a.W + 2 * (int64_t)n0 * a.ldw;
+    unsigned offA[2], offW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offA[i] = (unsigned)(2 * (a_row_base(a, m0 + srow + i * 64) - rbase0 + scol));
+        offW[i] = (unsigned)(2 * ((int64_t)(srow + i * 64) * a.ldw + scol));
+    }
+    const int nT = a.K / BK;
+    const int ldst = (g * 128 + r8 * 8) * 128;
+    auto dma_a = [&](int t) {
+        const int tc = min(t, nT - 1);
+        const int64_t ka = a.conv ? a_k_off(a, tc * BK) : (int64_t)tc * BK;
+        const char* tb = Abase + 2 * ka;
+        char* base = smem + (t & 1) * 65536 + ldst;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_saddr(tb, offA[i], base + i * 8192);
+    };
+    auto dma_w = [&](int t) {
+        const int tc = min(t, nT - 1);
+        const char* tb = Wbase + 2 * (int64_t)tc * BK;
+        char* base = smem + (t & 1) * 65536 + 32768 + ldst;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_saddr(tb, offW[i], base + i * 8192);
+    };
+
+    f32x16 acc[2][2];  // [n block][m block]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, hi = lane >> 5;
+    dma_a(0);
+    dma_w(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // opens I_0
+    if (g) __builtin_amdgcn_s_barrier();  // group 1 idles through I_0
+
+    bf16x8 wf[2][2], af[2][2];
+    auto reads = [&](int t, int s) {
+        const char* tA = smem + (t & 1) * 65536;
+        const char* tW = tA + 32768;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[kk][i] = lds_frag(tW, wn * 64 + i * 32 + fr, s * 4 + kk * 2 + hi);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) af[kk][j] = lds_frag(tA, wm * 64 + j * 32 + fr, s * 4 + kk * 2 + hi);
+        }
+    };
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> long long { return ABL == 4 ? (long long)__builtin_amdgcn_s_memtime() : 0; };
+    auto cluster = [&](bool tile_end) {
+        __builtin_amdgcn_sched_barrier(0);
+        const long long t0 = now();
+        __builtin_amdgcn_s_barrier();
+        const long long t1 = now();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const long long t2 = now();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        const long long t3 = now();
+        if (tile_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long t4 = now();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        const long long t5 = now();
+        if (ABL == 4) {
+            tacc[0] += t1 - t0;
+            tacc[1] += t2 - t1;
+            tacc[2] += t3 - t2;
+            tacc[3] += t4 - t3;
+            tacc[4] += t5 - t4;
+        }
+    };
+    const long long tl0 = now();
+    for (int t = 0; t < nT; ++t) {
+        const long long u0 = now();
+        reads(t, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const long long u1 = now();
+        if (g) dma_w(t + 1);
+        else dma_a(t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const long long u2 = now();
+        cluster(false);
+        const long long u3 = now();
+        reads(t, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        const long long u4 = now();
+        if (g) {
+            dma_a(t + 1);
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            dma_w(t + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const long long u5 = now();
+        cluster(true);
+        if (ABL == 4) {
+            tacc[6] += (u1 - u0) + (u4 - u3);
+            tacc[7] += (u2 - u1) + (u5 - u4);
+        }
+    }
+    if (ABL == 4) {
+        tacc[5] = now() - tl0;
+        if (blockIdx.x == 100 && lane == 0 && (wave & 1) == 0)
+            for (int e = 0; e < 8; ++e) g_pp_dbg[(wave >> 1) * 8 + e] = tacc[e];
+    }
+    if (!g) __builtin_amdgcn_s_barrier();  // pairs with group 1's last compute segment
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    char* patch = smem + wave * 8192;
+    if (epi_vec_ok(a, EPI)) {
+        epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, patch, lane);
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = m0 + wm * 64 + j * 32 + fr;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
+                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
+                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
+            }
+        }
+}
+
+template <int EPI>
+static int launch_pp16_t(const GemmArgs& a, hipStream_t st) {
+    const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
+    static bool attr_set = false;
+    if (!attr_set) {
+        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr_set = true;
+    }
+    if (EPI == EPI_BIAS && a.ablate) {  // diagnostics only
+        const void* fn = (const void*)gemm_bf16_pp16<EPI_BIAS, 4>;
+        S2V_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        void* args[] = {(void*)&a, (void*)&tiles_m, (void*)&tiles_n};
+        S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(tiles_m * tiles_n), dim3(1024), args, 131072, st));
+        return 0;
+    }
+    hipLaunchKernelGGL(gemm_bf16_pp16<EPI>, dim3(tiles_m * tiles_n), dim3(1024), 131072, st, a, tiles_m, tiles_n);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int EPI>
 static int launch_w8_t(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
@@ -1177,7 +1771,7 @@ static int launch_ring_t(const GemmArgs& a, hipStream_t st) {
 }
 
 int g_gemm_ablate = 0;  // diagnostics only (ring kernel): bit0 = no LDS-DMA in the k-loop, bit1 = no ds_read/MFMA
-int g_gemm_impl = 5;  // 5 = 256x256 eight-wave, 4 = 256x256 four-wave (both fall back to 2 when N % 256 != 0), 3 = BK32 two-block, 2 = staggered
+int g_gemm_impl = 7;  // 7 = 256x256x64 eight-wave ping-pong (default), 8 = its 16-wave form, 6 = ping-pong on K32 stages, 5 = 256x256 eight-wave lock-step, 4 = 256x256 four-wave (both fall back to 2 when N % 256 != 0), 3 = BK32 two-block, 2 = staggered
                       // 256x128 ring, 1 = lock-step 256x128 ring, 0 = 128x128 double-buffer kernel
 extern "C" int s2v_set_gemm_impl(int impl) { g_gemm_impl = impl & 0xff; g_gemm_ablate = impl >> 8; return 0; }
 
@@ -1185,6 +1779,36 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     GemmArgs a = a0;
     a.ablate = g_gemm_ablate;
     S2V_REQUIRE(a.K % BK == 0, "gemm_bf16: K must be a multiple of 64");
+    if (g_gemm_impl == 8 && a.N % WBN == 0 && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+        S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
+        switch (epi) {
+            case EPI_BIAS: return launch_pp16_t<EPI_BIAS>(a, st);
+            case EPI_BIAS_GELU: return launch_pp16_t<EPI_BIAS_GELU>(a, st);
+            case EPI_BIAS_GATE_RES: return launch_pp16_t<EPI_BIAS_GATE_RES>(a, st);
+            case EPI_BIAS_ADD: return launch_pp16_t<EPI_BIAS_ADD>(a, st);
+            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
+        }
+    }
+    if (g_gemm_impl == 7 && a.N % WBN == 0 && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+        S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
+        switch (epi) {
+            case EPI_BIAS: return launch_pp64_t<EPI_BIAS>(a, st);
+            case EPI_BIAS_GELU: return launch_pp64_t<EPI_BIAS_GELU>(a, st);
+            case EPI_BIAS_GATE_RES: return launch_pp64_t<EPI_BIAS_GATE_RES>(a, st);
+            case EPI_BIAS_ADD: return launch_pp64_t<EPI_BIAS_ADD>(a, st);
+            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
+        }
+    }
+    if (g_gemm_impl == 6 && a.N % WBN == 0 && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+        S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
+        switch (epi) {
+            case EPI_BIAS: return launch_pp_t<EPI_BIAS>(a, st);
+            case EPI_BIAS_GELU: return launch_pp_t<EPI_BIAS_GELU>(a, st);
+            case EPI_BIAS_GATE_RES: return launch_pp_t<EPI_BIAS_GATE_RES>(a, st);
+            case EPI_BIAS_ADD: return launch_pp_t<EPI_BIAS_ADD>(a, st);
+            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
+        }
+    }
     if (g_gemm_impl == 5 && a.N % WBN == 0 && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {

@@ -12,6 +12,7 @@ sys.path.insert(0, ROOT)
 s2v = importlib.import_module("disentangled-subject-to-vid_amd")
 L = s2v._lib
 DEV = "cuda:0"
+IMPLS = [int(x) for x in os.environ.get("S2V_IMPLS", "5,7,8").split(",")]
 
 
 def timeit(fn, iters=10, warm=3):
@@ -35,12 +36,21 @@ def bench_gemm():
         b = torch.zeros(N, device=DEV, dtype=torch.bfloat16)
         C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
         f = lambda: L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, epi, 1, 0, L.stream_ptr()))
-        for impl in (4, 5):
+        ref = None
+        for impl in IMPLS:
             L.lib().s2v_set_gemm_impl(impl)
+            C.zero_()
+            f()
+            torch.cuda.synchronize()
+            if ref is None:
+                ref = C.clone()
+            elif not torch.equal(ref, C):
+                print(f"   !! impl {impl} differs from impl {IMPLS[0]}: max abs {(ref.float() - C.float()).abs().max().item():.4g}", flush=True)
             ms = timeit(f)
-            print(f"gemm[{('tile128x128','ring256x128','stag256x128','r32-2blk','w128-4wave','w8-8wave')[impl]}] {name:9s} M={M} N={N} K={K}: {ms:8.3f} ms  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
+            print(f"gemm[{('tile128x128','ring256x128','stag256x128','r32-2blk','w128-4wave','w8-8wave','pp-8wave','pp64-8wave','pp16-16wave')[impl]}] {name:9s} M={M} N={N} K={K}: {ms:8.3f} ms  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
         t = timeit(lambda: torch.matmul(A, W.T), iters=5)
         print(f"   (hipBLASLt via torch.matmul: {t:8.3f} ms  {2*M*N*K/t/1e9:8.1f} TFLOP/s)", flush=True)
+        L.lib().s2v_set_gemm_impl(5)
         del A, W, C
 
 
