@@ -60,6 +60,17 @@ __device__ __forceinline__ float gelu_tanh_fast(float x) {
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 
+// LDS-DMA of 16 B per lane in the saddr + 32-bit voffset form: global address = sbase (wave-uniform, SGPR pair) + voff
+// (per-lane byte offset), LDS address = M0 + 16 * lane.  hipcc picks the 64-bit vaddr form inside loops; this pins the
+// cheaper one (one address VGPR per lane instead of two).
+__device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, char* lds_dst) {
+    const unsigned m0v = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
+                 :
+                 : "s"(sbase), "v"(voff), "s"(__builtin_amdgcn_readfirstlane(m0v))
+                 : "memory", "m0");
+}
+
 // ---- host side ------------------------------------------------------------
 #ifdef S2V_HOST
 #include <string>

@@ -134,24 +134,36 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int cl) {
 // 128 B, 16-B chunks XOR-swizzled by row&7) -> read back row-major, 16 B per lane, 8 lanes per 128-B line -> gate /
 // residual in that layout -> full-line global stores.  A row-per-lane epilogue (8-B stores at a row stride) was
 // store-issue bound: ~0.7 ms of a 3.4 ms FF1 launch.
-template <int EPI>
-__device__ __forceinline__ void epilogue_wave64(const GemmArgs& a, const f32x16 (&acc)[2][2], int mw, int nw, char* patch,
-                                                int lane) {
+template <int EPI, int MB>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x16 (&acc)[2][MB], int mw, int nw, char* patch, int lane) {
+    // MB 32-row blocks: the patch holds MB*32 rows of 128 B (8 KiB for MB = 2, 16 KiB for MB = 4); all accumulator blocks are
+    // written first, then read back, so the LDS round trip and the bias loads are paid once per wave tile
     const int fr = lane & 31, hi = lane >> 5;
     const bf16_t* bias = (const bf16_t*)a.bias;
+    u32x2 bvec[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int nl = (q >> 2) * 32 + 8 * (q & 3) + 4 * hi;
+        bvec[q] = u32x2{0u, 0u};
+        if (bias && nw + nl + 3 < a.N) bvec[q] = *(const u32x2*)(bias + nw + nl);  // 8-byte aligned: nw % 64 == 0, nl % 4 == 0
+        else if (bias) {
+            unsigned short t[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (nw + nl + e < a.N) t[e] = ((const unsigned short*)bias)[nw + nl + e];
+            bvec[q] = u32x2{(unsigned)t[0] | ((unsigned)t[1] << 16), (unsigned)t[2] | ((unsigned)t[3] << 16)};
+        }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             const int nl = i * 32 + 8 * rq + 4 * hi;  // local column of 4 consecutive outputs
-            float bv[4] = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
+            const u32x2 bq = bvec[i * 4 + rq];
+            const float bv[4] = {__uint_as_float(bq.x << 16), __uint_as_float(bq.x & 0xffff0000u), __uint_as_float(bq.y << 16),
+                                 __uint_as_float(bq.y & 0xffff0000u)};
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (nw + nl + e < a.N) bv[e] = bf2f(bias[nw + nl + e]);
-            }
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < MB; ++j) {
                 float y[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -169,7 +181,7 @@ __device__ __forceinline__ void epilogue_wave64(const GemmArgs& a, const f32x16 
     const int c16 = lane & 7;
     const int n = nw + c16 * 8;
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
+    for (int it = 0; it < MB * 4; ++it) {
         const int row = it * 8 + (lane >> 3);
         const int m = mw + row;
         u32x4 v = *(const u32x4*)(patch + row * 128 + ((c16 ^ (row & 7)) << 4));
@@ -200,6 +212,11 @@ __device__ __forceinline__ void epilogue_wave64(const GemmArgs& a, const f32x16 
             *(u32x4*)((bf16_t*)a.C + (size_t)m * a.ldc + n) = v;
         }
     }
+}
+template <int EPI>
+__device__ __forceinline__ void epilogue_wave64(const GemmArgs& a, const f32x16 (&acc)[2][2], int mw, int nw, char* patch,
+                                                int lane) {
+    epilogue_wave<EPI, 2>(a, acc, mw, nw, patch, lane);
 }
 // vectorised epilogue is usable when whole 8-column groups exist and rows are 16-byte aligned
 __device__ __forceinline__ bool epi_vec_ok(const GemmArgs& a, int epi) {
@@ -1266,17 +1283,6 @@ static int launch_pp_t(const GemmArgs& a, hipStream_t st) {
 __device__ long long g_pp_dbg[64];  // diagnostics (ABL == 4)
 extern "C" int s2v_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
 
-// LDS-DMA of 16 B per lane in the saddr + 32-bit voffset form: global address = sbase (wave-uniform, SGPR pair) + voff
-// (per-lane byte offset), LDS address = M0 + 16 * lane.  hipcc picks the 64-bit vaddr form inside loops; this pins the
-// cheaper one (one address VGPR per lane instead of two).
-__device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, char* lds_dst) {
-    const unsigned m0v = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_dst;
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
-                 :
-                 : "s"(sbase), "v"(voff), "s"(__builtin_amdgcn_readfirstlane(m0v))
-                 : "memory", "m0");
-}
-
 // gemm_bf16_pp64: the ping-pong schedule of gemm_bf16_pp on K-tiles of 64 with 128-byte LDS rows, so every LDS-DMA lane
 // group fetches a FULL 128-B line (gemm_bf16_pp / _w8 fetch 64-B half lines: twice the L2 requests for the same bytes, and
 // the measured DMA-only time of those kernels equals their MFMA-only time).  Two 64-KiB stages; a K-tile is four
@@ -1293,6 +1299,7 @@ __device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, c
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    const long long tk0 = (ABL >= 4) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -1441,23 +1448,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
     }
     if ((ABL >= 4)) {
         tacc[5] = now() - tl0;
-        if (blockIdx.x == 100 && lane == 0)
-            for (int e = 0; e < 8; ++e) g_pp_dbg[wave * 8 + e] = tacc[e];
+        tacc[1] = tl0 - tk0;  // prologue (replaces the lgkmcnt slot)
     }
+    const long long te0 = now();
     if (!g) __builtin_amdgcn_s_barrier();  // pairs with group 1's last compute segment
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    char* patch = smem + wave * 8192;
+    char* patch = smem + wave * 16384;
     if (epi_vec_ok(a, EPI)) {
-#pragma unroll
-        for (int qj = 0; qj < 2; ++qj) {
-            f32x16 sub[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) sub[i][j] = acc[i][qj * 2 + j];
-            epilogue_wave64<EPI>(a, sub, m0 + wm * 128 + qj * 64, n0 + wn * 64, patch, lane);
+        epilogue_wave<EPI, 4>(a, acc, m0 + wm * 128, n0 + wn * 64, patch, lane);
+        if ((ABL >= 4)) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tacc[3] = now() - te0;  // epilogue incl. store drain (replaces the vmcnt slot)
+            if (blockIdx.x == 100 && lane == 0)
+                for (int e = 0; e < 8; ++e) g_pp_dbg[wave * 8 + e] = tacc[e];
         }
         return;
     }

@@ -1,0 +1,68 @@
+// How much independent VALU work hides under back-to-back v_mfma_f32_32x32x16_bf16 on gfx950?
+// One block per CU; WAVES waves per SIMD; per iteration 8 independent MFMAs, each followed by NV VALU ops (fma or exp2).
+// Build: hipcc --offload-arch=gfx950 -O3 -o tools/probes/mfma_valu tools/probes/mfma_valu.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NV, int EXP>
+__global__ __launch_bounds__(512) void probe(float* out, int iters, long long* cyc) {
+    const int lane = threadIdx.x & 63;
+    bf16x8 a, b;
+    for (int e = 0; e < 8; ++e) { a[e] = (__bf16)(0.001f * (lane + e)); b[e] = (__bf16)(0.002f * (lane - e)); }
+    f32x16 acc[8];
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    float v[16];
+    for (int e = 0; e < 16; ++e) v[e] = 0.01f * (lane + e);
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int r = (i * NV + k) & 15;
+                if (EXP && (k & 1)) v[r] = __builtin_amdgcn_exp2f(v[r]);
+                else v[r] = v[r] * 0.999f + 0.001f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (NV) __builtin_amdgcn_sched_group_barrier(0x002, NV, 0);
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    float s = 0.f;
+    for (int i = 0; i < 8; ++i) for (int e = 0; e < 16; ++e) s += acc[i][e];
+    for (int e = 0; e < 16; ++e) s += v[e];
+    if (s == 12345.678f) out[0] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
+}
+
+template <int NV, int EXP>
+static void run(int waves_per_simd) {
+    float* out; long long* cyc;
+    hipMalloc(&out, 64); hipMalloc(&cyc, 64);
+    const int iters = 2000;
+    probe<NV, EXP><<<256, 256 * waves_per_simd>>>(out, 10, cyc);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    probe<NV, EXP><<<256, 256 * waves_per_simd>>>(out, iters, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+    const double per_mfma_wave = (double)c / iters / 8;
+    printf("waves/SIMD=%d NV=%2d %s: %7.1f ticks per MFMA group per wave -> %6.1f per SIMD-MFMA; %7.3f ms (%.0f TFLOP/s equiv)\n", waves_per_simd, NV,
+           EXP ? "fma+exp" : "fma    ", per_mfma_wave, per_mfma_wave / waves_per_simd, ms,
+           256.0 * 4 * waves_per_simd * iters * 8 * 32768.0 / ms / 1e9);
+}
+
+int main() {
+    for (int w : {1, 2}) {
+        run<0, 0>(w); run<2, 0>(w); run<4, 0>(w); run<6, 0>(w); run<8, 0>(w); run<14, 0>(w);
+        run<4, 1>(w); run<8, 1>(w); run<14, 1>(w);
+    }
+    return 0;
+}

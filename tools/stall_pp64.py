@@ -17,7 +17,7 @@ torch.cuda.synchronize()
 buf = (ctypes.c_longlong * 64)()
 L.lib().s2v_debug_read.argtypes = [ctypes.c_void_p]
 assert L.lib().s2v_debug_read(buf) == 0
-names = ["bar(load)", "lgkmcnt", "mfma issue", "vmcnt(0)", "bar(comp)", "loop total", "ds_read issue", "dma issue"]
+names = ["bar(load)", "PROLOGUE/nh", "mfma issue", "EPILOGUE/nh", "bar(comp)", "loop total", "ds_read issue", "dma issue"]
 nh = K // 32
 print("cycles per half-step (s_memtime ticks / %d half-steps); %s" % (nh, ", ".join(names)))
 for w in range(8):
