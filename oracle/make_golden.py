@@ -248,6 +248,36 @@ def gen_vae():
     np.savez_compressed(os.path.join(OUT, "vae_tiny.npz"), **out)
 
 
+def gen_vae_enc():
+    """Reference-image encode (src/video_generate.py:26-38): AutoencoderKLCogVideoX.encode of ONE frame, untiled and tiled,
+    the posterior sample with captured noise, times scaling_factor."""
+    from diffusers import AutoencoderKLCogVideoX
+
+    vae = AutoencoderKLCogVideoX(**VAE_TINY).float().eval()
+    randomize(vae.encoder, torch.Generator().manual_seed(5), std=0.08)
+    sd = {k: v for k, v in vae.state_dict().items() if k.startswith("encoder.")}
+    gen = torch.Generator().manual_seed(6)
+    img = torch.rand(1, 3, 1, 96, 160, generator=gen) * 2.0 - 1.0  # [B,C,F,H,W] in [-1,1] like the normalised PNG
+    out = npsd(sd)
+    out["image"] = img.numpy()
+    with torch.no_grad():
+        for name, tiling in (("untiled", False), ("tiled", True)):
+            (vae.enable_tiling if tiling else vae.disable_tiling)()
+            post = vae.encode(img).latent_dist
+            out[f"moments_{name}"] = post.parameters.numpy()
+            g = torch.Generator().manual_seed(7)
+            noise = torch.randn(post.mean.shape, generator=g)
+            g = torch.Generator().manual_seed(7)
+            smp = post.sample(generator=g) * vae.config.scaling_factor
+            out[f"noise_{name}"] = noise.numpy()
+            out[f"latent_{name}"] = smp.permute(0, 2, 1, 3, 4).numpy()  # [B,F,C,h,w] as handed to the pipeline
+            assert torch.equal(post.mean + post.std * noise, post.sample(generator=torch.Generator().manual_seed(7)))
+        vae.disable_tiling()
+        out["moments_small"] = vae.encode(img[..., :40, :56]).latent_dist.parameters.numpy()
+    np.savez_compressed(os.path.join(OUT, "vae_enc_tiny.npz"), **out)
+    return sorted(sd)
+
+
 def gen_pipeline():
     """Full CustomCogVideoXPipeline.__call__ (src/custom_cogvideox_pipe.py:125-326) with tiny modules, 480x720
     (the only geometry the shipped harness supports: 1350 tokens per frame), 3 steps, DDIM and DPM."""
@@ -292,7 +322,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     import_reference()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tables", "sched", "transformer", "vae", "pipeline"]
+    which = sys.argv[1:] or ["tables", "sched", "transformer", "vae", "vae_enc", "pipeline"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

@@ -180,3 +180,109 @@ def postprocess_np(video):
         v = (v / 2 + 0.5).clamp(0, 1)
         out.append(v.cpu().permute(0, 2, 3, 1).float().numpy())
     return np.stack(out)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Reference-image ENCODE: one frame through CogVideoXEncoder3D, DiagonalGaussianDistribution.sample
+# Reference: autoencoder_kl_cogvideox.py  ResnetBlock3D with plain GroupNorm :225-319 (spatial_norm_dim None),
+#   DownBlock3D :322-421, Encoder3D :755-814, _encode :1177-1203, tiled_encode :1300-1372;
+#   downsampling.py:322-353 (CogVideoXDownsample3D); autoencoders/vae.py:767-790; src/video_generate.py:26-38.
+def resnet_gn(sd, p, x, groups, cache, key, new_cache):
+    h = F.silu(F.group_norm(x, groups, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6))
+    h = causal_conv3d(sd, p + "conv1.conv.", h, cache, key + "conv1", new_cache)
+    h = F.silu(F.group_norm(h, groups, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6))
+    h = causal_conv3d(sd, p + "conv2.conv.", h, cache, key + "conv2", new_cache)
+    if (p + "conv_shortcut.weight") in sd:
+        x = F.conv3d(x, sd[p + "conv_shortcut.weight"], sd[p + "conv_shortcut.bias"])
+    return h + x
+
+
+def downsample3d(sd, p, x, compress_time):
+    """downsampling.py:322-353: temporal average pool (first frame kept when the count is odd), then a per-frame
+    3x3 stride-2 conv on the input zero-padded at the right / bottom only."""
+    if compress_time:
+        B, C, Fr, H, W = x.shape
+        t = x.permute(0, 3, 4, 1, 2).reshape(B * H * W, C, Fr)
+        if Fr % 2 == 1:
+            first, rest = t[..., 0], t[..., 1:]
+            if rest.shape[-1] > 0:
+                rest = F.avg_pool1d(rest, kernel_size=2, stride=2)
+            t = torch.cat([first[..., None], rest], dim=-1)
+        else:
+            t = F.avg_pool1d(t, kernel_size=2, stride=2)
+        x = t.reshape(B, H, W, C, t.shape[-1]).permute(0, 3, 4, 1, 2)
+    x = F.pad(x, (0, 1, 0, 1))
+    B, C, Fr, H, W = x.shape
+    y = F.conv2d(x.permute(0, 2, 1, 3, 4).reshape(B * Fr, C, H, W), sd[p + "conv.weight"], sd[p + "conv.bias"], stride=2)
+    return y.reshape(B, Fr, y.shape[1], y.shape[2], y.shape[3]).permute(0, 2, 1, 3, 4)
+
+
+def encoder_forward(sd, cfg, x, cache=None):
+    groups = cfg["norm_num_groups"]
+    nb = len(cfg["block_out_channels"])
+    tlevel = int(np.log2(cfg["temporal_compression_ratio"]))
+    nc = {}
+    h = causal_conv3d(sd, "encoder.conv_in.conv.", x, cache, "conv_in", nc)
+    for b in range(nb):
+        for i in range(cfg["layers_per_block"]):
+            p = f"encoder.down_blocks.{b}.resnets.{i}."
+            h = resnet_gn(sd, p, h, groups, cache, p, nc)
+        if b != nb - 1:
+            h = downsample3d(sd, f"encoder.down_blocks.{b}.downsamplers.0.", h, b < tlevel)
+    for i in range(2):
+        p = f"encoder.mid_block.resnets.{i}."
+        h = resnet_gn(sd, p, h, groups, cache, p, nc)
+    h = F.silu(F.group_norm(h, groups, sd["encoder.norm_out.weight"], sd["encoder.norm_out.bias"], 1e-6))
+    h = causal_conv3d(sd, "encoder.conv_out.conv.", h, cache, "conv_out", nc)
+    return h, nc
+
+
+def encode_untiled(sd, cfg, x):
+    assert x.shape[2] == 1, "the path encodes one reference frame; video encode is outside it"
+    return encoder_forward(sd, cfg, x)[0]
+
+
+def encode_tile_geometry(cfg):
+    """:1102-1114, 1317-1323 with the int() truncations (sample-space tiles, latent-space blends)."""
+    nlev = len(cfg["block_out_channels"]) - 1
+    ts_h, ts_w = cfg["sample_height"] // 2, cfg["sample_width"] // 2
+    tl_h, tl_w = int(ts_h / 2**nlev), int(ts_w / 2**nlev)
+    fh, fw = 1 / 6, 1 / 5
+    return dict(ts_h=ts_h, ts_w=ts_w, ov_h=int(ts_h * (1 - fh)), ov_w=int(ts_w * (1 - fw)), bl_h=int(tl_h * fh),
+                bl_w=int(tl_w * fw), lim_h=tl_h - int(tl_h * fh), lim_w=tl_w - int(tl_w * fw))
+
+
+def encode_tiled(sd, cfg, x):
+    tg = encode_tile_geometry(cfg)
+    H, W = x.shape[3], x.shape[4]
+    rows = []
+    for i in range(0, H, tg["ov_h"]):
+        rows.append([encode_untiled(sd, cfg, x[:, :, :, i : i + tg["ts_h"], j : j + tg["ts_w"]]) for j in range(0, W, tg["ov_w"])])
+    res_rows = []
+    for i, row in enumerate(rows):
+        res = []
+        for j, tile in enumerate(row):
+            if i > 0:
+                tile = _blend_v(rows[i - 1][j], tile, tg["bl_h"])
+            if j > 0:
+                tile = _blend_h(row[j - 1], tile, tg["bl_w"])
+            res.append(tile[:, :, :, : tg["lim_h"], : tg["lim_w"]])
+        res_rows.append(torch.cat(res, dim=4))
+    return torch.cat(res_rows, dim=3)
+
+
+def encode_moments(sd, cfg, x, tiling):
+    tg = encode_tile_geometry(cfg)
+    if tiling and (x.shape[4] > tg["ts_w"] or x.shape[3] > tg["ts_h"]):
+        return encode_tiled(sd, cfg, x)
+    return encode_untiled(sd, cfg, x)
+
+
+def encode_image(sd, cfg, x, noise, tiling):
+    """x [1,3,1,H,W] in [-1,1], noise [1,C,1,h,w] (the randn the caller draws) -> ref latents [1,1,C,h,w] (src/video_generate.py:35-38)."""
+    mom = encode_moments(sd, cfg, x, tiling)
+    mean, logvar = torch.chunk(mom, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    std = torch.exp(0.5 * logvar)
+    z = (mean + std * noise) * cfg["scaling_factor"]
+    return z.permute(0, 2, 1, 3, 4)

@@ -220,3 +220,33 @@ def test_vae_decode_even_and_single_frame_branches_and_postprocess():
     np.testing.assert_allclose(y2.numpy(), g["dec_2f"], atol=2e-5, rtol=1e-4)
     np.testing.assert_allclose(y1.numpy(), g["dec_1f"], atol=2e-5, rtol=1e-4)
     np.testing.assert_allclose(vae_ref.postprocess_np(t(g["dec_2f"])), g["post_np"], atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# reference-image encode
+@pytest.mark.parametrize("tiling", [False, True])
+def test_vae_encode_oracle_vs_reference(tiling):
+    from oracle import vae_ref
+    g = load_golden("vae_enc_tiny.npz")
+    sd = weights_of(g)
+    name = "tiled" if tiling else "untiled"
+    x = torch.from_numpy(g["image"])
+    with torch.no_grad():
+        mom = vae_ref.encode_moments(sd, VAE_CFG, x, tiling)
+        lat = vae_ref.encode_image(sd, VAE_CFG, x, torch.from_numpy(g[f"noise_{name}"]), tiling)
+    assert torch.allclose(mom, torch.from_numpy(g[f"moments_{name}"]), atol=2e-5, rtol=1e-5)
+    assert torch.allclose(lat, torch.from_numpy(g[f"latent_{name}"]), atol=2e-5, rtol=1e-5)
+
+
+def test_vae_encode_oracle_small_window():
+    from oracle import vae_ref
+    g = load_golden("vae_enc_tiny.npz")
+    x = torch.from_numpy(g["image"])[..., :40, :56]
+    with torch.no_grad():
+        mom = vae_ref.encode_moments(weights_of(g), VAE_CFG, x, False)
+    assert torch.allclose(mom, torch.from_numpy(g["moments_small"]), atol=2e-5, rtol=1e-5)
+
+
+def test_vae_encode_tile_geometry_of_the_real_config():
+    tg = vae_ref.encode_tile_geometry(dict(block_out_channels=(128, 256, 256, 512), sample_height=480, sample_width=720))
+    assert tg == dict(ts_h=240, ts_w=360, ov_h=200, ov_w=288, bl_h=5, bl_w=9, lim_h=25, lim_w=36)
