@@ -235,8 +235,22 @@ def main():
             frames = vae.decode_latents(latents)
             torch.cuda.synchronize()
             dec["tiled" if tiling else "untiled"] = time.perf_counter() - t1
+        # reference-image encode (src/video_generate.py:26-38), reported beside the metric, not inside it
+        vae.load_state_dict(s2v.weights.synthetic_vae_encoder_state_dict(vcfg, seed=8, device=dev, dtype=dt))
+        img = (torch.rand(1, 3, 1, H * 8, W * 8, generator=torch.Generator().manual_seed(9)) * 2 - 1).to(dev, dt)
+        enc = {}
+        for tiling in (False, True):
+            vae.use_tiling = tiling
+            vae.encode(img).latent_dist.sample(generator=torch.Generator().manual_seed(1))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ref_lat = vae.encode(img).latent_dist.sample(generator=torch.Generator().manual_seed(1)) * vcfg.scaling_factor
+            torch.cuda.synchronize()
+            enc["tiled" if tiling else "untiled"] = time.perf_counter() - t1
         step_s = elapsed / args.steps
         video = {"denoise_steps": 50, "denoise_s": round(50 * step_s, 2),
+                 "ref_image_encode_untiled_s": round(enc["untiled"], 4), "ref_image_encode_tiled_s": round(enc["tiled"], 4),
+                 "ref_latent_finite": bool(torch.isfinite(ref_lat.float()).all().item()),
                  "vae_decode_untiled_s": round(dec["untiled"], 3), "vae_decode_tiled_s": round(dec["tiled"], 3),
                  "s_per_video_untiled": round(50 * step_s + dec["untiled"], 2),
                  "s_per_video_tiled": round(50 * step_s + dec["tiled"], 2),

@@ -79,7 +79,8 @@ __device__ __forceinline__ int64_t a_row_base(const GemmArgs& a, int m) {
     const int hw = a.oH * a.oW;
     const int f = m / hw, rem = m - f * hw;
     const int y = rem / a.oW, x = rem - y * a.oW;
-    return (((int64_t)f * a.Hp + y) * a.Wp + x) * a.cin;
+    const int cs = a.cstride > 1 ? a.cstride : 1;
+    return (((int64_t)f * a.Hp + y * cs) * a.Wp + x * cs) * a.cin;
 }
 // element offset added for column k (plain: k; conv: tap displacement + channel)
 __device__ __forceinline__ int64_t a_k_off(const GemmArgs& a, int k) {

@@ -29,6 +29,7 @@ struct GemmArgs {
     // dt in [0,kt), dy,dx in [0,3): A[m][k] = in[f + dt][y + dy][x + dx][ci].  kt = 3: causal conv (frames 0,1 of the
     // buffer hold the conv cache); kt = 1: per-frame 3x3 conv.  (CogVideoXCausalConv3d, autoencoder_kl_cogvideox.py:120-137)
     int conv, cin, Hp, Wp, oH, oW, kt;
+    int cstride;        // conv mode: spatial stride of the output grid (0 or 1 = dense; 2 = CogVideoXDownsample3D, downsampling.py:322-353)
     int ablate;         // diagnostics only
     int a_rows_padded;  // plain mode: rows physically present behind A (>= M); the 256-row kernel needs ceil256(M)
 };

@@ -92,6 +92,52 @@ int launch_dense_to_padded(const void* in, int F, int H, int W, int C, void* out
     return 0;
 }
 
+// window (y0, x0, th, tw) of an image [C][F][H][W] -> zero-bordered channels-last operand [f_off + F][th+2][tw+2][C]
+template <typename T>
+__global__ void image_to_padded_k(const T* img, int C, int F, int H, int W, int y0, int x0, int th, int tw, T* out, int f_off) {
+    const int64_t total = (int64_t)F * th * tw * C;
+    const int Hp = th + 2, Wp = tw + 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int x = (int)((i / C) % tw);
+        const int y = (int)((i / ((int64_t)C * tw)) % th);
+        const int f = (int)(i / ((int64_t)C * tw * th));
+        out[((((int64_t)(f + f_off)) * Hp + y + 1) * Wp + x + 1) * C + c] = img[(((int64_t)c * F + f) * H + y0 + y) * W + x0 + x];
+    }
+}
+int launch_image_to_padded(const void* img, int C, int F, int H, int W, int y0, int x0, int th, int tw, void* out, int f_off,
+                           int dtype, hipStream_t st) {
+    const int64_t total = (int64_t)F * th * tw * C;
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(image_to_padded_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)img, C, F, H, W, y0, x0,
+                           th, tw, (bf16_t*)out, f_off);
+    else
+        hipLaunchKernelGGL(image_to_padded_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)img, C, F, H, W, y0, x0, th,
+                           tw, (float*)out, f_off);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+// DiagonalGaussianDistribution(moments).sample() with the caller's noise (autoencoders/vae.py:767-790): moments [2*Cz][n],
+// mean = first half, logvar = clamp(second half, -30, 20), out = mean + exp(0.5 * logvar) * noise; every op rounds to T
+template <typename T>
+__global__ void gaussian_sample_k(const T* mom, const T* noise, int64_t n, T* out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float mean = ET<T>::ld(mom + i);
+        const float lv = fminf(fmaxf(ET<T>::ld(mom + n + i), -30.0f), 20.0f);
+        const float sd = ET<T>::rnd(expf(ET<T>::rnd(0.5f * lv)));
+        ET<T>::st(out + i, ET<T>::rnd(mean + ET<T>::rnd(sd * ET<T>::ld(noise + i))));
+    }
+}
+int launch_gaussian_sample(const void* mom, const void* noise, int64_t n, void* out, int dtype, hipStream_t st) {
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(gaussian_sample_k<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)mom, (const bf16_t*)noise, n, (bf16_t*)out);
+    else
+        hipLaunchKernelGGL(gaussian_sample_k<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)mom, (const float*)noise, n, (float*)out);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------
 // GroupNorm statistics: sums[g] = {sum x, sum x^2} in fp64 over P pixels x (C/G) channels
 #define GN_PIX_PER_BLOCK 512
@@ -210,16 +256,17 @@ __global__ __launch_bounds__(256) void snorm_apply_k(const SNormArgs a) {
         // latent-resolution tables built by snorm_tables_k (L2-resident, each row reused by its whole footprint)
         const int64_t pz = (((int64_t)fz * a.hz + yz) * a.wz + xz) * C + c0;
         float cy[VN], cb[VN];
-        V16<T>::ld((const T*)a.yt + pz, cy);
-        V16<T>::ld((const T*)a.bt + pz, cb);
+        if (a.yt != nullptr) {
+            V16<T>::ld((const T*)a.yt + pz, cy);
+            V16<T>::ld((const T*)a.bt + pz, cb);
+        }
         float o[VN];
 #pragma unroll
         for (int e = 0; e < VN; ++e) {
             const int g = (c0 + e) / cpg;
             const float n = ET<T>::rnd((v[e] - mean[g]) * rstd[g] * g_w[e] + g_b[e]);
-            const float y = cy[e];
-            const float b = cb[e];
-            float r = ET<T>::rnd(ET<T>::rnd(n * y) + b);
+            float r = n;  // plain nn.GroupNorm (encoder resnets, yt == nullptr)
+            if (a.yt != nullptr) r = ET<T>::rnd(ET<T>::rnd(n * cy[e]) + cb[e]);
             if (a.silu) r = ET<T>::rnd(silu_f(r));
             o[e] = r;
         }
@@ -257,15 +304,16 @@ __global__ void snorm_tables_k(const SNormArgs a) {
 int launch_snorm_apply(const SNormArgs& a, int dtype, hipStream_t st) {
     const int VN = dtype == S2V_BF16 ? 8 : 4;
     S2V_REQUIRE(a.C % VN == 0 && a.C % a.G == 0, "snorm_apply: unsupported channel count");
-    S2V_REQUIRE(a.yt && a.bt, "snorm_apply: table scratch missing");
+    const bool plain = a.yt == nullptr;  // nn.GroupNorm (+ SiLU) without the zq modulation: the encoder's resnets / norm_out
+    S2V_REQUIRE(plain || a.bt, "snorm_apply: table scratch missing");
     const size_t shmem = sizeof(float) * (size_t)2 * a.G;
     const int64_t tl = (int64_t)a.Fz * a.hz * a.wz * (a.C / VN);
     const int64_t total = (int64_t)a.F * a.H * a.W * (a.C / VN);
     if (dtype == S2V_BF16) {
-        hipLaunchKernelGGL(snorm_tables_k<bf16_t>, dim3(grid_for(tl)), dim3(256), 0, st, a);
+        if (!plain) hipLaunchKernelGGL(snorm_tables_k<bf16_t>, dim3(grid_for(tl)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(snorm_apply_k<bf16_t>, dim3(grid_for(total, 16384)), dim3(256), shmem, st, a);
     } else {
-        hipLaunchKernelGGL(snorm_tables_k<float>, dim3(grid_for(tl)), dim3(256), 0, st, a);
+        if (!plain) hipLaunchKernelGGL(snorm_tables_k<float>, dim3(grid_for(tl)), dim3(256), 0, st, a);
         hipLaunchKernelGGL(snorm_apply_k<float>, dim3(grid_for(total, 16384)), dim3(256), shmem, st, a);
     }
     S2V_CHECK_HIP(hipGetLastError());

@@ -35,6 +35,7 @@ struct s2v_vae {
     s2v_vae_config cfg;
     int dtype = 0, esz = 0, G = 0, Cz = 0;
     bool mfma = false, finalized = false;
+    bool encoder = false;  // plan built by s2v_vae_enc_create (reference-image encode) instead of the decoder
     ConvL conv_in, conv_out;
     SNormL norm_out;
     std::vector<StageL> stages;
@@ -443,6 +444,7 @@ static int decode_window(s2v_vae* v, const char* lat, int F, int h, int w, int y
 extern "C" int s2v_vae_decode(s2v_vae* v, const void* latents, int32_t F, int32_t h, int32_t w, int32_t tiling,
                               int32_t scaled, void* out, s2v_stream stream) {
     S2V_REQUIRE(v && latents && out, "s2v_vae_decode: null argument");
+    S2V_REQUIRE(!v->encoder, "s2v_vae_decode: this handle holds the encoder");
     S2V_REQUIRE(v->finalized, "s2v_vae_decode: weights not finalized");
     S2V_REQUIRE(F >= 1 && h >= 1 && w >= 1, "s2v_vae_decode: bad geometry");
     hipStream_t st = (hipStream_t)stream;
@@ -516,4 +518,262 @@ extern "C" int s2v_vae_postprocess(const void* video, int32_t C, int32_t F, int3
                                    s2v_stream stream) {
     S2V_REQUIRE(video && out, "s2v_vae_postprocess: null argument");
     return launch_postprocess(video, C, F, H, W, out, dtype, (hipStream_t)stream);
+}
+
+// =====================================================================================================================
+// Reference-image ENCODE (src/video_generate.py:26-38): one frame through CogVideoXEncoder3D
+// (autoencoder_kl_cogvideox.py:755-814: conv_in, DownBlock3D x4 of plain-GroupNorm resnets + CogVideoXDownsample3D,
+// MidBlock3D, norm_out, conv_out), untiled or tiled (:1177-1203, 1300-1372), moments out; the posterior sample is
+// s2v_vae_gaussian_sample.  The handle is an s2v_vae whose plan was built by s2v_vae_enc_create: weights load through
+// s2v_vae_load_weight under the reference's "encoder.*" names and it is destroyed by s2v_vae_destroy.
+// Plan layout: stages[0 .. nb-1] = down blocks (StageL::up is the stride-2 downsampler conv), stages[nb] = mid block;
+// ConvL::level l works at (tile height >> l) x (tile width >> l).
+static int make_gn(s2v_vae* v, SNormL& n, const std::string& name, int C) {
+    n.C = C;
+    S2V_TRY(dmalloc(v, &n.gn_w, (int64_t)C * v->esz));
+    S2V_TRY(dmalloc(v, &n.gn_b, (int64_t)C * v->esz));
+    v->slots[name + ".weight"] = VSlot{0, n.gn_w, C, 1, 1, false};
+    v->slots[name + ".bias"] = VSlot{0, n.gn_b, C, 1, 1, false};
+    return 0;
+}
+static int make_resnet_gn(s2v_vae* v, ResnetL& r, const std::string& name, int cin, int cout, int level) {
+    r.cin = cin; r.cout = cout; r.has_sc = cin != cout;
+    S2V_TRY(make_gn(v, r.n1, name + ".norm1", cin));
+    S2V_TRY(make_conv(v, r.c1, name + ".conv1.conv", cin, cout, 3, level));
+    S2V_TRY(make_gn(v, r.n2, name + ".norm2", cout));
+    S2V_TRY(make_conv(v, r.c2, name + ".conv2.conv", cout, cout, 3, level));
+    if (r.has_sc) S2V_TRY(make_conv(v, r.sc, name + ".conv_shortcut", cin, cout, 0, level));
+    return 0;
+}
+
+extern "C" int s2v_vae_enc_create(const s2v_vae_config* cfg, s2v_vae** out) {
+    S2V_REQUIRE(cfg && out, "s2v_vae_enc_create: null argument");
+    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_vae_enc_create: unsupported dtype");
+    S2V_REQUIRE(cfg->num_blocks >= 1 && cfg->num_blocks <= 6, "s2v_vae_enc_create: 1..6 blocks");
+    s2v_vae* v = new s2v_vae();
+    v->cfg = *cfg;
+    v->dtype = cfg->dtype;
+    v->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
+    v->G = cfg->norm_num_groups;
+    v->Cz = cfg->latent_channels;
+    v->mfma = cfg->dtype == S2V_DTYPE_BF16 && !cfg->force_simple;
+    v->encoder = true;
+    const int nb = cfg->num_blocks;
+    const int tlevel = (int)std::lround(std::log2((double)cfg->temporal_compression_ratio));
+    int r = make_conv(v, v->conv_in, "encoder.conv_in.conv", cfg->out_channels, cfg->block_out_channels[0], 3, 0);
+    v->stages.resize(nb + 1);
+    char nm[128];
+    int prev = cfg->block_out_channels[0], level = 0;
+    for (int b = 0; b < nb && !r; ++b) {
+        StageL& s = v->stages[b];
+        const int co = cfg->block_out_channels[b];
+        s.res.resize(cfg->layers_per_block);
+        for (int i = 0; i < cfg->layers_per_block && !r; ++i) {
+            snprintf(nm, sizeof(nm), "encoder.down_blocks.%d.resnets.%d", b, i);
+            r = make_resnet_gn(v, s.res[i], nm, i == 0 ? prev : co, co, level);
+        }
+        prev = co;
+        s.has_up = b != nb - 1;  // here: has a downsampler
+        s.compress_time = b < tlevel;
+        if (s.has_up && !r) {
+            snprintf(nm, sizeof(nm), "encoder.down_blocks.%d.downsamplers.0.conv", b);
+            r = make_conv(v, s.up, nm, co, co, 1, level);  // operand at the level it reads; output one level down
+            level++;
+        }
+    }
+    if (!r) {
+        v->stages[nb].res.resize(2);
+        for (int i = 0; i < 2 && !r; ++i) {
+            snprintf(nm, sizeof(nm), "encoder.mid_block.resnets.%d", i);
+            r = make_resnet_gn(v, v->stages[nb].res[i], nm, prev, prev, level);
+        }
+    }
+    if (!r) r = make_gn(v, v->norm_out, "encoder.norm_out", prev);
+    if (!r) r = make_conv(v, v->conv_out, "encoder.conv_out.conv", prev, 2 * v->Cz, 3, level);
+    if (!r) r = dmalloc(v, &v->sums, sizeof(double) * 2 * v->G);
+    if (r) { s2v_vae_destroy(v); return r; }
+    *out = v;
+    return 0;
+}
+
+static int enc_prepare(s2v_vae* v, int TH, int TW) {
+    if (v->th >= TH && v->tw >= TW) return 0;
+    S2V_CHECK_HIP(hipDeviceSynchronize());
+    for (void* p : v->geo_allocs) (void)hipFree(p);
+    v->geo_allocs.clear();
+    TH = std::max(TH, v->th); TW = std::max(TW, v->tw);
+    v->th = TH; v->tw = TW;
+    int rc = 0;
+    int64_t dmax = 0;
+    for_each_conv(v, [&](ConvL& c) {
+        const int64_t H = TH >> c.level, W = TW >> c.level;
+        const int F = c.kt == 3 ? 3 : 1;
+        c.pad_bytes = (int64_t)F * (H + 2) * (W + 2) * c.cin * v->esz + 1024;
+        if (!rc) rc = dmalloc(v, &c.pad, c.pad_bytes, true);
+        dmax = std::max(dmax, H * W * std::max(c.cin, c.cout) * v->esz);
+    });
+    if (rc) return rc;
+    v->dense_bytes = dmax + (int64_t)256 * 1024 * v->esz;
+    for (int i = 0; i < 3; ++i) S2V_TRY(dmalloc(v, &v->dense[i], v->dense_bytes, true));
+    S2V_TRY(dmalloc(v, &v->gn_part, gn_stats_scratch_bytes((int64_t)TH * TW, v->G) + 64, true));
+    v->cur_h = v->cur_w = 0;
+    return 0;
+}
+
+static int run_gn_plain(s2v_vae* v, const SNormL& n, const void* x, int H, int W, void* out_pad, int f_off, hipStream_t st) {
+    S2V_TRY(launch_gn_stats(x, (int64_t)H * W, n.C, v->G, v->sums, v->gn_part, v->dtype, st));
+    SNormArgs a{};
+    a.x = x; a.F = 1; a.H = H; a.W = W; a.C = n.C; a.G = v->G; a.sums = v->sums; a.eps = v->cfg.norm_eps;
+    a.gn_w = n.gn_w; a.gn_b = n.gn_b; a.Fz = 1; a.hz = 1; a.wz = 1; a.Cz = v->Cz;
+    a.out = out_pad; a.f_off = f_off; a.silu = 1;  // yt == nullptr: plain GroupNorm
+    return launch_snorm_apply(a, v->dtype, st);
+}
+
+// CogVideoXDownsample3D for one frame: F.pad(x, (0,1,0,1)) then Conv2d(3x3, stride 2): the operand sits at (1,1) of its
+// zero-bordered buffer, so reading from (1,1) with stride 2 sees the zero column / row on the right / bottom only
+static int run_conv_down(s2v_vae* v, ConvL& c, int H, int W, void* out, hipStream_t st) {
+    GemmArgs g{};
+    g.A = c.pad + ((int64_t)(W + 2) + 1) * c.cin * v->esz; g.W = c.w; g.ldw = 9 * c.cin; g.bias = c.b; g.C = out; g.ldc = c.cout;
+    g.M = (H / 2) * (W / 2); g.N = c.cout; g.K = 9 * c.cin;
+    g.conv = 1; g.cin = c.cin; g.Hp = H + 2; g.Wp = W + 2; g.oH = H / 2; g.oW = W / 2; g.kt = 1; g.cstride = 2;
+    if (v->mfma && c.cin % 64 == 0) return launch_gemm_bf16(g, EPI_BIAS, st);
+    return launch_gemm_simple(g, EPI_BIAS, v->dtype, st);
+}
+
+// encoder pass over the (th x tw) pixel window at (y0, x0) of image [3][1][H][W]; dst = moments [2Cz][1][th/s][tw/s]
+static int encode_window(s2v_vae* v, const void* image, int Himg, int Wimg, int y0, int x0, int th, int tw, char* dst,
+                         hipStream_t st) {
+    S2V_TRY(set_layout(v, th, tw, st));
+    int cur = 0, t1 = 1, t2 = 2;
+    int H = th, W = tw;
+    S2V_TRY(launch_image_to_padded(image, v->cfg.out_channels, 1, Himg, Wimg, y0, x0, th, tw, v->conv_in.pad, 2, v->dtype, st));
+    S2V_TRY(run_conv(v, v->conv_in, 1, H, W, true, EPI_BIAS, nullptr, v->dense[cur], st));
+    for (auto& s : v->stages) {
+        for (auto& r : s.res) {
+            S2V_TRY(run_gn_plain(v, r.n1, v->dense[cur], H, W, r.c1.pad, 2, st));
+            S2V_TRY(run_conv(v, r.c1, 1, H, W, true, EPI_BIAS, nullptr, v->dense[t1], st));
+            S2V_TRY(run_gn_plain(v, r.n2, v->dense[t1], H, W, r.c2.pad, 2, st));
+            if (r.has_sc) {
+                GemmArgs g{};
+                g.A = v->dense[cur]; g.lda = r.cin; g.W = r.sc.w; g.ldw = r.cin; g.bias = r.sc.b;
+                g.C = v->dense[t2]; g.ldc = r.cout; g.M = H * W; g.N = r.cout; g.K = r.cin;
+                g.a_rows_padded = (int)rup64(g.M, 256);
+                if (v->mfma && r.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, EPI_BIAS, st));
+                else S2V_TRY(launch_gemm_simple(g, EPI_BIAS, v->dtype, st));
+                S2V_TRY(run_conv(v, r.c2, 1, H, W, true, EPI_BIAS_ADD, v->dense[t2], v->dense[t2], st));
+                std::swap(cur, t2);
+            } else {
+                S2V_TRY(run_conv(v, r.c2, 1, H, W, true, EPI_BIAS_ADD, v->dense[cur], v->dense[cur], st));
+            }
+        }
+        if (s.has_up) {  // downsampler (one frame: the temporal average pool of compress_time keeps the frame as it is)
+            S2V_TRY(launch_dense_to_padded(v->dense[cur], 1, H, W, s.up.cin, s.up.pad, 0, v->dtype, st));
+            S2V_TRY(run_conv_down(v, s.up, H, W, v->dense[t1], st));
+            std::swap(cur, t1);
+            H /= 2; W /= 2;
+        }
+    }
+    S2V_TRY(run_gn_plain(v, v->norm_out, v->dense[cur], H, W, v->conv_out.pad, 2, st));
+    S2V_TRY(run_conv(v, v->conv_out, 1, H, W, true, EPI_BIAS, nullptr, v->dense[t1], st));
+    return launch_to_ncfhw(v->dense[t1], 1, H, W, 2 * v->Cz, dst, 1, 0, v->dtype, st);
+}
+
+struct EncTileGeo { int ts_h, ts_w, ov_h, ov_w, bl_h, bl_w, lim_h, lim_w; };
+static EncTileGeo enc_tile_geo(s2v_vae* v) {  // :1102-1114, 1317-1323 incl. the int() truncations
+    EncTileGeo t;
+    const int sc = spatial_scale(v);
+    t.ts_h = v->cfg.sample_height / 2; t.ts_w = v->cfg.sample_width / 2;
+    const int tl_h = (int)((double)t.ts_h / sc), tl_w = (int)((double)t.ts_w / sc);
+    t.ov_h = (int)(t.ts_h * (1.0 - 1.0 / 6.0)); t.ov_w = (int)(t.ts_w * (1.0 - 1.0 / 5.0));
+    t.bl_h = (int)(tl_h * (1.0 / 6.0)); t.bl_w = (int)(tl_w * (1.0 / 5.0));
+    t.lim_h = tl_h - t.bl_h; t.lim_w = tl_w - t.bl_w;
+    return t;
+}
+
+extern "C" int s2v_vae_encode_shape(s2v_vae* v, int32_t H, int32_t W, int32_t tiling, int32_t* ho, int32_t* wo) {
+    S2V_REQUIRE(v && v->encoder && ho && wo && H >= 1 && W >= 1, "s2v_vae_encode_shape: bad argument");
+    const int sc = spatial_scale(v);
+    EncTileGeo t = enc_tile_geo(v);
+    if (!(tiling && (W > t.ts_w || H > t.ts_h))) { *ho = H / sc; *wo = W / sc; return 0; }
+    S2V_REQUIRE(t.ov_h > 0 && t.ov_w > 0, "s2v_vae_encode_shape: degenerate tile overlap");
+    int h = 0, w = 0;
+    for (int i = 0; i < H; i += t.ov_h) h += std::min(std::min(t.ts_h, H - i) / sc, t.lim_h);
+    for (int j = 0; j < W; j += t.ov_w) w += std::min(std::min(t.ts_w, W - j) / sc, t.lim_w);
+    *ho = h; *wo = w;
+    return 0;
+}
+
+extern "C" int s2v_vae_encode(s2v_vae* v, const void* image, int32_t H, int32_t W, int32_t tiling, void* moments,
+                              s2v_stream stream) {
+    S2V_REQUIRE(v && image && moments, "s2v_vae_encode: null argument");
+    S2V_REQUIRE(v->encoder, "s2v_vae_encode: this handle holds the decoder (use s2v_vae_enc_create)");
+    S2V_REQUIRE(v->finalized, "s2v_vae_encode: weights not finalized");
+    const int sc = spatial_scale(v);
+    hipStream_t st = (hipStream_t)stream;
+    EncTileGeo t = enc_tile_geo(v);
+    const bool tiled = tiling && (W > t.ts_w || H > t.ts_h);
+    if (!tiled) {
+        S2V_REQUIRE(H % sc == 0 && W % sc == 0, "s2v_vae_encode: image sides must be multiples of the spatial compression");
+        S2V_TRY(enc_prepare(v, H, W));
+        return encode_window(v, image, H, W, 0, 0, H, W, (char*)moments, st);
+    }
+    S2V_REQUIRE(t.ov_h > 0 && t.ov_w > 0, "s2v_vae_encode: degenerate tile overlap");
+    std::vector<int> is, js;
+    for (int i = 0; i < H; i += t.ov_h) is.push_back(i);
+    for (int j = 0; j < W; j += t.ov_w) js.push_back(j);
+    for (int i : is) S2V_REQUIRE(std::min(t.ts_h, H - i) % sc == 0, "s2v_vae_encode: tile height not a multiple of the spatial compression");
+    for (int j : js) S2V_REQUIRE(std::min(t.ts_w, W - j) % sc == 0, "s2v_vae_encode: tile width not a multiple of the spatial compression");
+    S2V_TRY(enc_prepare(v, std::min(t.ts_h, H), std::min(t.ts_w, W)));
+    const size_t nt = is.size() * js.size();
+    const int C = 2 * v->Cz;
+    bool realloc_tiles = v->tiles.size() != nt;
+    for (size_t k = 0; !realloc_tiles && k < nt; ++k) {
+        const int th = std::min(t.ts_h, H - is[k / js.size()]) / sc, tw = std::min(t.ts_w, W - js[k % js.size()]) / sc;
+        if (v->tile_h[k] != th || v->tile_w[k] != tw) realloc_tiles = true;
+    }
+    if (realloc_tiles) {
+        S2V_CHECK_HIP(hipDeviceSynchronize());
+        for (char* p : v->tiles) (void)hipFree(p);
+        v->tiles.assign(nt, nullptr); v->tile_h.assign(nt, 0); v->tile_w.assign(nt, 0);
+        for (size_t k = 0; k < nt; ++k) {
+            const int th = std::min(t.ts_h, H - is[k / js.size()]) / sc, tw = std::min(t.ts_w, W - js[k % js.size()]) / sc;
+            v->tile_h[k] = th; v->tile_w[k] = tw;
+            S2V_CHECK_HIP(hipMalloc((void**)&v->tiles[k], (size_t)C * th * tw * v->esz + 16));
+        }
+    }
+    for (size_t k = 0; k < nt; ++k)
+        S2V_TRY(encode_window(v, image, H, W, is[k / js.size()], js[k % js.size()], v->tile_h[k] * sc, v->tile_w[k] * sc, v->tiles[k], st));
+    int32_t ho, wo;
+    S2V_TRY(s2v_vae_encode_shape(v, H, W, 1, &ho, &wo));
+    int y0 = 0;
+    for (size_t r = 0; r < is.size(); ++r) {
+        int x0 = 0, ch = 0;
+        for (size_t c = 0; c < js.size(); ++c) {
+            const size_t k = r * js.size() + c;
+            const int Ht = v->tile_h[k], Wt = v->tile_w[k];
+            if (r > 0) {
+                const size_t ka = (r - 1) * js.size() + c;
+                const int E = std::min(std::min(v->tile_h[ka], Ht), t.bl_h);
+                S2V_TRY(launch_blend(v->tiles[ka], v->tile_h[ka], v->tile_w[ka], v->tiles[k], Ht, Wt, C, E, 1, v->dtype, st));
+            }
+            if (c > 0) {
+                const size_t ka = k - 1;
+                const int E = std::min(std::min(v->tile_w[ka], Wt), t.bl_w);
+                S2V_TRY(launch_blend(v->tiles[ka], v->tile_h[ka], v->tile_w[ka], v->tiles[k], Ht, Wt, C, E, 0, v->dtype, st));
+            }
+            ch = std::min(Ht, t.lim_h);
+            const int cw = std::min(Wt, t.lim_w);
+            S2V_TRY(launch_paste(v->tiles[k], Ht, Wt, ch, cw, moments, ho, wo, y0, x0, C, v->dtype, st));
+            x0 += cw;
+        }
+        y0 += ch;
+    }
+    return 0;
+}
+
+extern "C" int s2v_vae_gaussian_sample(const void* moments, const void* noise, int32_t latent_channels, int64_t n_spatial, void* out,
+                                       int32_t dtype, s2v_stream stream) {
+    S2V_REQUIRE(moments && noise && out && latent_channels > 0 && n_spatial > 0, "s2v_vae_gaussian_sample: bad argument");
+    S2V_REQUIRE(dtype == S2V_DTYPE_F32 || dtype == S2V_DTYPE_BF16, "s2v_vae_gaussian_sample: unsupported dtype");
+    return launch_gaussian_sample(moments, noise, (int64_t)latent_channels * n_spatial, out, dtype, (hipStream_t)stream);
 }

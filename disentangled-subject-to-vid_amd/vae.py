@@ -2,8 +2,8 @@
 `.config.{block_out_channels, temporal_compression_ratio, scaling_factor}`, `.decode(z).sample`,
 `enable_tiling / disable_tiling / enable_slicing`, `.eval()` as used by
 pipelines/cogvideo/pipeline_cogvideox.py:185-193,346-351 and src/inference.py:201-207.  Decode runs in
-libs2v_hip.so (csrc/vae.hip, vae_api.hip).  `encode` is a caller-side step outside this path and
-raises."""
+libs2v_hip.so (csrc/vae.hip, vae_api.hip).  `encode(x).latent_dist.sample()` of ONE reference frame
+(src/video_generate.py:26-38) runs there too once `encoder.*` weights were loaded; video encode raises."""
 import ctypes
 from types import SimpleNamespace
 
@@ -30,7 +30,34 @@ _lib.register_sigs({
     "s2v_vae_out_shape": [_P, _I32, _I32, _I32, _I32, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)],
     "s2v_vae_decode": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "s2v_vae_postprocess": [_P, _I32, _I32, _I32, _I32, _P, _I32, _P],
+    "s2v_vae_enc_create": [ctypes.POINTER(VaeConfigC), ctypes.POINTER(_P)],
+    "s2v_vae_encode_shape": [_P, _I32, _I32, _I32, ctypes.POINTER(_I32), ctypes.POINTER(_I32)],
+    "s2v_vae_encode": [_P, _P, _I32, _I32, _I32, _P, _P],
+    "s2v_vae_gaussian_sample": [_P, _P, _I32, _I64, _P, _I32, _P],
 })
+
+
+class HipDiagonalGaussianDistribution:
+    """DiagonalGaussianDistribution (autoencoders/vae.py:767-790) over device-resident moments [1,2C,1,h,w]."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+
+    def sample(self, generator=None):
+        # randn_tensor (utils/torch_utils.py): a CPU generator draws on the CPU and the draw is moved to the device
+        p = self.parameters
+        shape = self.mean.shape
+        gdev = generator.device if generator is not None else p.device
+        noise = torch.randn(shape, generator=generator, device=gdev, dtype=p.dtype).to(p.device).contiguous()
+        out = torch.empty(shape, dtype=p.dtype, device=p.device)
+        n_sp = shape[2] * shape[3] * shape[4]
+        _lib.check(_lib.lib().s2v_vae_gaussian_sample(_lib.ptr(p), _lib.ptr(noise), shape[1], n_sp, _lib.ptr(out),
+                                                      _lib.DTYPE_OF[p.dtype], _lib.stream_ptr()))
+        return out
+
+    def mode(self):
+        return self.mean
 
 
 class HipAutoencoderKLCogVideoX:
@@ -58,14 +85,18 @@ class HipAutoencoderKLCogVideoX:
         c.scaling_factor, c.norm_eps = cfg.scaling_factor, 1e-6
         self._h = ctypes.c_void_p()
         _lib.check(_lib.lib().s2v_vae_create(ctypes.byref(c), ctypes.byref(self._h)))
+        self._cfg_c = c
+        self._enc = ctypes.c_void_p()  # encoder handle, created when `encoder.*` weights arrive
 
     def close(self):
-        if self._h:
-            lib = _lib.lib()
-            lib.s2v_vae_destroy.argtypes = [_P]
-            lib.s2v_vae_destroy.restype = None
-            lib.s2v_vae_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        lib = _lib.lib()
+        lib.s2v_vae_destroy.argtypes = [_P]
+        lib.s2v_vae_destroy.restype = None
+        for name in ("_h", "_enc"):
+            h = getattr(self, name, None)
+            if h:
+                lib.s2v_vae_destroy(h)
+                setattr(self, name, ctypes.c_void_p())
 
     def __del__(self):
         try:
@@ -95,24 +126,49 @@ class HipAutoencoderKLCogVideoX:
         self.use_slicing = False
 
     def load_state_dict(self, sd, strict=True):
-        """sd: reference state dict; only `decoder.*` tensors are consumed (the encoder is outside this path)."""
+        """sd: reference state dict.  `decoder.*` tensors feed the decode path; `encoder.*` tensors, when present, the
+        reference-image encode (either half may be loaded on its own)."""
         keep = []
+        halves = {"decoder.": self._h}
+        if any(k.startswith("encoder.") for k in sd):
+            if not self._enc:
+                _lib.check(_lib.lib().s2v_vae_enc_create(ctypes.byref(self._cfg_c), ctypes.byref(self._enc)))
+            halves["encoder."] = self._enc
+        loaded = set()
         for k, t in sd.items():
-            if not k.startswith("decoder."):
+            h = next((hh for pre, hh in halves.items() if k.startswith(pre)), None)
+            if h is None:
                 continue
             t = t.to(self.device)
             if t.dtype not in _lib.DTYPE_OF:
                 t = t.float()
             t = t.contiguous()
             shape = (_I64 * t.ndim)(*t.shape)
-            _lib.check(_lib.lib().s2v_vae_load_weight(self._h, k.encode(), _lib.ptr(t), shape, t.ndim,
+            _lib.check(_lib.lib().s2v_vae_load_weight(h, k.encode(), _lib.ptr(t), shape, t.ndim,
                                                       _lib.DTYPE_OF[t.dtype], _lib.stream_ptr()))
             keep.append(t)
+            loaded.add(k.split(".", 1)[0] + ".")
         torch.cuda.synchronize(self.device)
-        _lib.check(_lib.lib().s2v_vae_finalize(self._h))
+        for pre in loaded:
+            _lib.check(_lib.lib().s2v_vae_finalize(halves[pre]))
 
-    def encode(self, x):
-        raise NotImplementedError("VAE encode of the reference image is a caller-side step (src/video_generate.py:26-38)")
+    def encode(self, x, return_dict=True):
+        """AutoencoderKLCogVideoX.encode (:1205-1229) for the reference image: x [1,3,1,H,W] in [-1,1] ->
+        `.latent_dist` whose `.sample(generator)` is the [1,C,1,h,w] draw (src/video_generate.py:35-37)."""
+        if not self._enc:
+            raise _lib.S2VError("encode: no `encoder.*` weights were loaded into this VAE")
+        if x.ndim != 5 or x.shape[0] != 1 or x.shape[2] != 1:
+            raise NotImplementedError("encode takes ONE frame [1,3,1,H,W]: video encode is outside the path")
+        x = x.to(self.device, self.dtype).contiguous()
+        H, W = x.shape[3], x.shape[4]
+        ho, wo = _I32(), _I32()
+        _lib.check(_lib.lib().s2v_vae_encode_shape(self._enc, H, W, int(self.use_tiling), ctypes.byref(ho), ctypes.byref(wo)))
+        mom = torch.empty((1, 2 * self.cfg.latent_channels, 1, ho.value, wo.value), dtype=self.dtype, device=self.device)
+        _lib.check(_lib.lib().s2v_vae_encode(self._enc, _lib.ptr(x), H, W, int(self.use_tiling), _lib.ptr(mom), _lib.stream_ptr()))
+        post = HipDiagonalGaussianDistribution(mom)
+        if not return_dict:
+            return (post,)
+        return SimpleNamespace(latent_dist=post)
 
     def _out_shape(self, F, h, w):
         fo, ho, wo = _I32(), _I32(), _I32()

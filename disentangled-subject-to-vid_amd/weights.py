@@ -152,3 +152,51 @@ def synthetic_vae_state_dict(cfg, seed=4321, device="cpu", dtype=torch.float32):
             t = 0.05 * torch.randn(shape, generator=gen, device=device)
         sd[k] = t.to(dtype)
     return sd
+
+
+def vae_encoder_shapes(cfg):
+    """state-dict keys / shapes of CogVideoXEncoder3D (autoencoder_kl_cogvideox.py:689-750) for a VAEConfig"""
+    bo, out = list(cfg.block_out_channels), {}
+
+    def conv(name, cin, cout, k):
+        out[name + ".weight"] = (cout, cin) + k
+        out[name + ".bias"] = (cout,)
+
+    def resnet(name, cin, cout):
+        out[name + ".norm1.weight"] = (cin,); out[name + ".norm1.bias"] = (cin,)
+        out[name + ".norm2.weight"] = (cout,); out[name + ".norm2.bias"] = (cout,)
+        conv(name + ".conv1.conv", cin, cout, (3, 3, 3))
+        conv(name + ".conv2.conv", cout, cout, (3, 3, 3))
+        if cin != cout:
+            conv(name + ".conv_shortcut", cin, cout, (1, 1, 1))
+
+    conv("encoder.conv_in.conv", cfg.out_channels, bo[0], (3, 3, 3))
+    prev = bo[0]
+    for b, co in enumerate(bo):
+        for i in range(cfg.layers_per_block):
+            resnet(f"encoder.down_blocks.{b}.resnets.{i}", prev if i == 0 else co, co)
+        prev = co
+        if b != len(bo) - 1:
+            conv(f"encoder.down_blocks.{b}.downsamplers.0.conv", co, co, (3, 3))
+    for i in range(2):
+        resnet(f"encoder.mid_block.resnets.{i}", prev, prev)
+    out["encoder.norm_out.weight"] = (prev,); out["encoder.norm_out.bias"] = (prev,)
+    conv("encoder.conv_out.conv", prev, 2 * cfg.latent_channels, (3, 3, 3))
+    return out
+
+
+def synthetic_vae_encoder_state_dict(cfg, seed=8765, device="cpu", dtype=torch.float32):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    sd = {}
+    for k, shp in vae_encoder_shapes(cfg).items():
+        if "norm" in k and k.endswith("weight"):
+            v = 1.0 + 0.2 * torch.randn(shp, generator=g)
+        elif len(shp) == 1:
+            v = 0.1 * torch.randn(shp, generator=g)
+        else:
+            fan_in = 1
+            for d in shp[1:]:
+                fan_in *= d
+            v = torch.randn(shp, generator=g) * (1.0 / fan_in) ** 0.5
+        sd[k] = v.to(dtype).to(device)
+    return sd

@@ -178,6 +178,26 @@ int s2v_vae_decode(s2v_vae* vae, const void* latents, int32_t F, int32_t h, int3
 int s2v_vae_postprocess(const void* video, int32_t C, int32_t F, int32_t H, int32_t W, float* out, int32_t dtype,
                         s2v_stream stream);
 
+/* ---- reference-image encode (the step in front of the denoise loop) ------------------------------------------
+ * Replaces pipe.vae.encode(ref_image).latent_dist.sample() of src/video_generate.py:35-37
+ * (AutoencoderKLCogVideoX.encode / _encode / tiled_encode, autoencoder_kl_cogvideox.py:1177-1229,1300-1372;
+ * CogVideoXEncoder3D :755-814; CogVideoXDownsample3D downsampling.py:322-353; DiagonalGaussianDistribution
+ * autoencoders/vae.py:767-790).  ONE frame: video encode is outside the path.
+ * s2v_vae_enc_create builds an s2v_vae handle that holds the ENCODER; its weights are loaded with s2v_vae_load_weight
+ * under the reference's "encoder.*" state-dict keys, then s2v_vae_finalize; s2v_vae_destroy frees it.
+ * cfg: same struct as the decoder (out_channels = image channels 3, latent_channels = 16). */
+int s2v_vae_enc_create(const s2v_vae_config* cfg, s2v_vae** out);
+/* latent extent of s2v_vae_encode for an H x W image */
+int s2v_vae_encode_shape(s2v_vae* enc, int32_t H, int32_t W, int32_t tiling, int32_t* h, int32_t* w);
+/* image [3,1,H,W] (model dtype, values in [-1,1]) -> moments [2*latent_channels,1,h,w] = the `parameters` of the
+ * reference's DiagonalGaussianDistribution (mean | logvar); tiling != 0 follows tiled_encode when the image exceeds
+ * (sample_height/2, sample_width/2). */
+int s2v_vae_encode(s2v_vae* enc, const void* image, int32_t H, int32_t W, int32_t tiling, void* moments, s2v_stream stream);
+/* DiagonalGaussianDistribution.sample with the caller's randn: out[c,i] = mean + exp(0.5 * clamp(logvar, -30, 20)) * noise,
+ * every operation rounded to `dtype` like the reference's tensor ops; moments [2*C, n_spatial], noise / out [C, n_spatial] */
+int s2v_vae_gaussian_sample(const void* moments, const void* noise, int32_t latent_channels, int64_t n_spatial, void* out,
+                            int32_t dtype, s2v_stream stream);
+
 /* ---- operator-level entry points (used by the parity tests and micro-benchmarks) ------------------------- */
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic */
 int s2v_op_linear(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
