@@ -1008,23 +1008,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_w8(const GemmArgs a, int til
     // staging: 1024 chunks per operand per half-step, 2 per thread: gi = i*512 + tid -> row = i*128 + (tid>>2)
     const int srow = tid >> 2;
     const int scol = ((tid & 3) ^ ((srow >> 2) & 3)) * 8;
-    const bf16_t* pA = (const bf16_t*)a.A + a_row_base(a, m0 + srow) + scol;
-    const bf16_t* pW = (const bf16_t*)a.W + (int64_t)(n0 + srow) * a.ldw + scol;
-    const int dA1 = (int)(a_row_base(a, m0 + srow + 128) - a_row_base(a, m0 + srow));
-    const int64_t dW1 = (int64_t)128 * a.ldw;
+    // saddr-form LDS-DMA (see glds16_saddr): wave-uniform half-tile base + loop-invariant 32-bit lane offsets
+    const int64_t rbase0 = a_row_base(a, m0);
+    const char* Abase = (const char*)a.A + 2 * rbase0;
+    const char* Wbase = (const char*)a.W + 2 * (int64_t)n0 * a.ldw;
+    unsigned offA[2], offW[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        offA[i] = (unsigned)(2 * (a_row_base(a, m0 + srow + i * 128) - rbase0 + scol));
+        offW[i] = (unsigned)(2 * ((int64_t)(srow + i * 128) * a.ldw + scol));
+    }
     int64_t ka_cur = 0;
     auto glds_one = [&](int t, int s, int idx4) {  // 0,1 -> A pieces, 2,3 -> W pieces
         char* base = smem + s * WH_STAGE;
         const int i = idx4 & 1;
-        if (idx4 < 2) {
-            char* dst = base + (i * 512 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pA + i * dA1 + ka_cur),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        } else {
-            char* dst = base + WH_A + (i * 512 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pW + i * dW1 + t * K32),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
+        if (idx4 < 2) glds16_saddr(Abase + 2 * ka_cur, offA[i], base + (i * 512 + wave * 64) * 16);
+        else glds16_saddr(Wbase + 2 * (int64_t)t * K32, offW[i], base + WH_A + (i * 512 + wave * 64) * 16);
     };
 
     f32x16 acc[2][4];  // [n block][m block]
