@@ -104,7 +104,7 @@ def pmc_traffic_bytes(kernel_class):
 
     def mean_kb(path):
         for row in csv.reader(open(path)):
-            if row and row[0] == name:
+            if row and row[0].split("<")[0] == name:  # template arguments are part of the profiled name
                 return float(row[2])
         return None
 
