@@ -2,7 +2,7 @@
 // (replaces F.scaled_dot_product_attention at attention_processor.py:2083-2087).
 //
 //  attn_bf16_k : flash-attention forward on v_mfma_f32_32x32x16_bf16.
-//     block = 4 waves x 32 query rows; KV tile = 64 keys; K tile [64 kv][64 d] and V^T tile [64 d][64 kv] are
+//     block = NW (8; 4 as diagnostic) waves x 32 query rows; KV tile = 64 keys; K tile [64 kv][64 d] and V^T tile [64 d][64 kv] are
 //     staged with global_load_lds into double-buffered, XOR-swizzled LDS (same image as gemm.hip).
 //     QK^T is issued swapped (S^T = K . Q^T) so every lane owns ONE query row: row max / row sum / rescale are
 //     lane-local (one cross-half exchange per tile).  P^T feeds the PV MFMA straight from the S^T accumulator
@@ -18,27 +18,34 @@
 #define Q_BLOCK 128
 #define ATT_TILE_BYTES (64 * 64 * 2)  // 8 KiB
 
+template <int NT>
 __device__ __forceinline__ void stage64(const bf16_t* __restrict__ g, size_t ld, char* lds, int tid) {
-    // 64 rows x 128 B; 512 chunks of 16 B; 2 rounds of 256 threads
+    // 64 rows x 128 B; 512 chunks of 16 B; 512 / NT rounds of NT threads
     const int wave = tid >> 6;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int gi = i * 256 + tid;
+    for (int i = 0; i < 512 / NT; ++i) {
+        const int gi = i * NT + tid;
         const int row = gi >> 3;
         const int cp = gi & 7;
         const int c = cp ^ ((row >> 1) & 7);
         const bf16_t* src = g + (size_t)row * ld + c * 8;
-        char* dst = lds + (i * 256 + wave * 64) * 16;
+        char* dst = lds + (i * NT + wave * 64) * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     }
+}
+template <int NW>
+__device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ kg, size_t ldk, const bf16_t* __restrict__ vg, size_t ldv,
+                                         char* lds, int tid) {
+    stage64<NW * 64>(kg, ldk, lds, tid);
+    stage64<NW * 64>(vg, ldv, lds + ATT_TILE_BYTES, tid);
 }
 __device__ __forceinline__ bf16x8 frag64(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + row * 128 + ((cl ^ ((row >> 1) & 7)) << 4));
 }
 
-template <int ABL>
-__global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb) {
+template <int ABL, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_bf16_k(const AttnArgs a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K tile | VT tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, hi = lane >> 5;
@@ -56,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb)
     const bf16_t* VTg = (const bf16_t*)a.vt + (size_t)(b * a.H + h) * 64 * a.ntok_pad;
 
     // Q fragments (B operand of S^T = K.Q^T): lane (q = fr, hi) holds Q[q][16kk + 8hi .. +8]
-    const int q_row = qb * Q_BLOCK + wave * 32 + fr;
+    const int q_row = qb * (NW * 32) + wave * 32 + fr;
     const int q_ld = min(q_row, a.Ntok - 1);
     bf16x8 qf[4];
 #pragma unroll
@@ -75,8 +82,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb)
     const float c = a.scale * 1.4426950408889634f;
 
     const int nt = (a.Ntok + KV_TILE - 1) / KV_TILE;
-    stage64(Kg, a.ld_qkv, smem, tid);
-    stage64(VTg, a.ntok_pad, smem + ATT_TILE_BYTES, tid);
+    stage_kv<NW>(Kg, a.ld_qkv, VTg, a.ntok_pad, smem, tid);
     __syncthreads();
 
     for (int t = 0; t < nt; ++t) {
@@ -84,8 +90,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_k(const AttnArgs a, int nqb)
         const int kv0 = t * KV_TILE;
         if (t + 1 < nt) {
             char* nb = smem + (cur ^ 1) * 2 * ATT_TILE_BYTES;
-            stage64(Kg + (size_t)(kv0 + KV_TILE) * a.ld_qkv, a.ld_qkv, nb, tid);
-            stage64(VTg + kv0 + KV_TILE, a.ntok_pad, nb + ATT_TILE_BYTES, tid);
+            stage_kv<NW>(Kg + (size_t)(kv0 + KV_TILE) * a.ld_qkv, a.ld_qkv, VTg + kv0 + KV_TILE, a.ntok_pad, nb, tid);
         }
         const char* tK = smem + cur * 2 * ATT_TILE_BYTES;
         const char* tV = tK + ATT_TILE_BYTES;
@@ -184,11 +189,15 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
     S2V_REQUIRE(a.ntok_pad >= ((a.Ntok + 63) / 64) * 64, "attn_bf16: ntok_pad too small");
     const int nqb = (a.Ntok + Q_BLOCK - 1) / Q_BLOCK;
     const int grid = nqb * a.B * a.H;
+    // default: eight waves (256 query rows) per block -- each thread moves one K and one V^T piece per KV tile, half the
+    // LDS-DMA issue work per wave of the four-wave form (measured +2 % at C3); variants are diagnostics (tools/ablate_attn.py)
+    const int nqb8 = (a.Ntok + 255) / 256;
     switch (g_attn_variant) {
         case 1: hipLaunchKernelGGL(attn_bf16_k<1>, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
         case 2: hipLaunchKernelGGL(attn_bf16_k<2>, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
         case 3: hipLaunchKernelGGL(attn_bf16_k<3>, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
-        default: hipLaunchKernelGGL(attn_bf16_k<0>, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
+        case 4: hipLaunchKernelGGL((attn_bf16_k<0, 4>), dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
+        default: hipLaunchKernelGGL((attn_bf16_k<0, 8>), dim3(nqb8 * a.B * a.H), dim3(512), 4 * ATT_TILE_BYTES, st, a, nqb8); break;
     }
     S2V_CHECK_HIP(hipGetLastError());
     return 0;

@@ -22,8 +22,17 @@ vt = torch.zeros(B * H * 64 * ((N + 63) // 64 * 64), dtype=torch.bfloat16, devic
 f = lambda: L.check(L.lib().s2v_op_attention(L.ptr(qkv), L.ptr(vt), L.ptr(out), B, H, N, 1, 0, L.stream_ptr()))
 fl = 4 * B * H * N * N * 64
 names = {9: "online-max kernel only", 0: "bounded q64 kernel (default)", 1: "no exp", 2: "no row-sum adds", 3: "no max", 4: "variant 4", 5: "variant 5", 6: "variant 6", 7: "variant 7"}
+ref = None
 for v in [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3]:
     L.lib().s2v_set_attn_variant(v)
+    out.zero_()
+    f()
+    torch.cuda.synchronize()
+    if v == 0 and ref is None:
+        ref = out.float().clone()
+    elif ref is not None:
+        d = out.float() - ref
+        print(f"   variant {v} vs 0: max abs {d.abs().max().item():.3e}  rel L2 {(d.norm() / ref.norm()).item():.3e}", flush=True)
     ms = timeit(f, iters=5, warm=2)
     print(f"attn variant {v} ({names.get(v, '?')}): {ms:8.3f} ms  {fl/ms/1e9:8.1f} TFLOP/s", flush=True)
 L.lib().s2v_set_attn_variant(0)
