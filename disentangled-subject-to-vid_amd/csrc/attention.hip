@@ -20,7 +20,8 @@
 
 template <int NT>
 __device__ __forceinline__ void stage64(const bf16_t* __restrict__ g, size_t ld, char* lds, int tid) {
-    // 64 rows x 128 B; 512 chunks of 16 B; 512 / NT rounds of NT threads
+    // 64 rows x 128 B; 512 chunks of 16 B; 512 / NT rounds of NT threads.  The address is written as
+    // (wave-uniform tile base) + zext(32-bit lane offset) so the LDS-DMA can take the saddr + voffset form
     const int wave = tid >> 6;
 #pragma unroll
     for (int i = 0; i < 512 / NT; ++i) {
@@ -28,7 +29,8 @@ __device__ __forceinline__ void stage64(const bf16_t* __restrict__ g, size_t ld,
         const int row = gi >> 3;
         const int cp = gi & 7;
         const int c = cp ^ ((row >> 1) & 7);
-        const bf16_t* src = g + (size_t)row * ld + c * 8;
+        const unsigned off = (unsigned)(2 * ((unsigned)row * (unsigned)ld + c * 8));
+        const char* src = (const char*)g + (size_t)off;
         char* dst = lds + (i * NT + wave * 64) * 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
