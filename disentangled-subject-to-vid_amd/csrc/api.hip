@@ -135,21 +135,21 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     auto carve = [&](int64_t elems) { int64_t o = off; off += rup(elems * E, 256); return o; };
     struct Offs { int64_t ln1_w, ln1_b, ln2_w, ln2_b, wqkv, bqkv, nq_w, nq_b, nk_w, nk_b, wo, bo, w1, b1, w2, b2; };
     std::vector<Offs> lo(L);
-    const int64_t Dp = rup(D, 128);
+    const int64_t Dp = rup(D, 256);  // weight rows are padded to the 256-column GEMM tile (zero rows)
     for (int l = 0; l < L; ++l) {
         Offs& o = lo[l];
         o.ln1_w = carve(D); o.ln1_b = carve(D); o.ln2_w = carve(D); o.ln2_b = carve(D);
-        o.wqkv = carve(rup(3 * D, 128) * D); o.bqkv = carve(3 * D);
+        o.wqkv = carve(rup(3 * D, 256) * D); o.bqkv = carve(3 * D);
         o.nq_w = carve(64); o.nq_b = carve(64); o.nk_w = carve(64); o.nk_b = carve(64);
         o.wo = carve(Dp * D); o.bo = carve(D);
-        o.w1 = carve(rup(4 * D, 128) * D); o.b1 = carve(4 * D);
+        o.w1 = carve(rup(4 * D, 256) * D); o.b1 = carve(4 * D);
         o.w2 = carve(Dp * 4 * D); o.b2 = carve(D);
     }
     const int64_t o_patch_w = carve(Dp * Kp), o_patch_b = carve(D);
     const int64_t o_text_w = carve(Dp * TX), o_text_b = carve(D);
     const int64_t o_te1_w = carve(TE * D), o_te1_b = carve(TE), o_te2_w = carve(TE * TE), o_te2_b = carve(TE);
     const int64_t o_nf_w = carve(D), o_nf_b = carve(D), o_no_w = carve(D), o_no_b = carve(D);
-    const int64_t o_po_w = carve(rup(Cout, 128) * D), o_po_b = carve(Cout);
+    const int64_t o_po_w = carve(rup(Cout, 256) * D), o_po_b = carve(Cout);
     c->mod_rows = 2 * L * 6 * D + 2 * D;
     const int64_t o_mod_w = carve(c->mod_rows * TE), o_mod_b = carve(c->mod_rows);
     c->arena_bytes = off;
@@ -373,6 +373,7 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
     GemmArgs g = g0;
     // every GEMM operand of the transformer lives in a workspace buffer with >= 256 rows of slack behind it
     g.a_rows_padded = (int)(rup(g.M, 256));
+    g.w_rows_padded = (int)(rup(g.N, 256));  // every weight of the arena is carved with its rows padded to 256
     if (c->mfma && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0) return launch_gemm_bf16(g, epi, st);
     return launch_gemm_simple(g, epi, c->dtype, st);
 }

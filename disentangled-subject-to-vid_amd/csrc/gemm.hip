@@ -1780,11 +1780,18 @@ int g_gemm_impl = 7;  // 7 = 256x256x64 eight-wave ping-pong (default), 8 = its 
                       // 256x128 ring, 1 = lock-step 256x128 ring, 0 = 128x128 double-buffer kernel
 extern "C" int s2v_set_gemm_impl(int impl) { g_gemm_impl = impl & 0xff; g_gemm_ablate = impl >> 8; return 0; }
 
+// the 256-column kernels take N that is not a multiple of 256 when the weight buffer physically holds the padded rows and
+// the last tile is at least half full (N = 1920 / 5760 of the 2B model); narrower outputs go to the 128-column kernels
+static bool w_tile_ok(const GemmArgs& a) {
+    if (a.N % WBN == 0) return true;
+    return a.w_rows_padded >= ((a.N + WBN - 1) / WBN) * WBN && (a.N % WBN) >= WBN / 2;
+}
+
 int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     GemmArgs a = a0;
     a.ablate = g_gemm_ablate;
     S2V_REQUIRE(a.K % BK == 0, "gemm_bf16: K must be a multiple of 64");
-    if (g_gemm_impl == 8 && a.N % WBN == 0 && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+    if (g_gemm_impl == 8 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
             case EPI_BIAS: return launch_pp16_t<EPI_BIAS>(a, st);
@@ -1794,7 +1801,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }
-    if (g_gemm_impl == 7 && a.N % WBN == 0 && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+    if (g_gemm_impl == 7 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
             case EPI_BIAS: return launch_pp64_t<EPI_BIAS>(a, st);
@@ -1804,7 +1811,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }
-    if (g_gemm_impl == 6 && a.N % WBN == 0 && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+    if (g_gemm_impl == 6 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
             case EPI_BIAS: return launch_pp_t<EPI_BIAS>(a, st);
@@ -1814,7 +1821,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }
-    if (g_gemm_impl == 5 && a.N % WBN == 0 && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+    if (g_gemm_impl == 5 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
             case EPI_BIAS: return launch_w8_t<EPI_BIAS>(a, st);
@@ -1824,7 +1831,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }
-    if (g_gemm_impl == 4 && a.N % WBN == 0 && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+    if (g_gemm_impl == 4 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
             case EPI_BIAS: return launch_w128_t<EPI_BIAS>(a, st);

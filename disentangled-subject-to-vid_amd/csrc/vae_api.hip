@@ -69,7 +69,7 @@ static int dmalloc(s2v_vae* v, T** p, int64_t bytes, bool geo = false) {
 static int make_conv(s2v_vae* v, ConvL& c, const std::string& name, int cin, int cout, int kt, int level) {
     c.cin = cin; c.cout = cout; c.kt = kt; c.level = level;
     const int taps = kt == 3 ? 27 : (kt == 1 ? 9 : 1);
-    S2V_TRY(dmalloc(v, &c.w, rup64(cout, 128) * taps * cin * v->esz));
+    S2V_TRY(dmalloc(v, &c.w, rup64(cout, 256) * taps * cin * v->esz));
     S2V_TRY(dmalloc(v, &c.b, (int64_t)cout * v->esz));
     v->slots[name + ".weight"] = VSlot{1, c.w, cout, cin, taps, false};
     v->slots[name + ".bias"] = VSlot{0, c.b, cout, 1, 1, false};
@@ -315,6 +315,7 @@ static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int e
     g.M = F * H * W; g.N = c.cout; g.K = taps * c.cin;
     g.R = resid; g.ldr = c.cout;
     g.conv = 1; g.cin = c.cin; g.Hp = H + 2; g.Wp = W + 2; g.oH = H; g.oW = W; g.kt = c.kt;
+    g.w_rows_padded = (int)rup64(c.cout, 256);
     if (v->mfma && c.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, epi, st));  // cout = 3 (conv_out) runs one padded 128-column tile
     else S2V_TRY(launch_gemm_simple(g, epi, v->dtype, st));
     if (c.kt == 3) {
@@ -636,6 +637,7 @@ static int run_conv_down(s2v_vae* v, ConvL& c, int H, int W, void* out, hipStrea
     g.A = c.pad + ((int64_t)(W + 2) + 1) * c.cin * v->esz; g.W = c.w; g.ldw = 9 * c.cin; g.bias = c.b; g.C = out; g.ldc = c.cout;
     g.M = (H / 2) * (W / 2); g.N = c.cout; g.K = 9 * c.cin;
     g.conv = 1; g.cin = c.cin; g.Hp = H + 2; g.Wp = W + 2; g.oH = H / 2; g.oW = W / 2; g.kt = 1; g.cstride = 2;
+    g.w_rows_padded = (int)rup64(c.cout, 256);
     if (v->mfma && c.cin % 64 == 0) return launch_gemm_bf16(g, EPI_BIAS, st);
     return launch_gemm_simple(g, EPI_BIAS, v->dtype, st);
 }
