@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 s2v = importlib.import_module("disentangled-subject-to-vid_amd")
 L = s2v._lib
 DEV = "cuda:0"
-IMPLS = [int(x) for x in os.environ.get("S2V_IMPLS", "5,7,8").split(",")]
+IMPLS = [int(x) for x in os.environ.get("S2V_IMPLS", "7").split(",")]
 
 
 def timeit(fn, iters=10, warm=3):
