@@ -865,25 +865,22 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16_w128(const GemmArgs a, int t
     // chunk gi = i*256 + tid -> row = gi>>2 = i*64 + (tid>>2), physical chunk = tid&3, source chunk = phys ^ ((row>>2)&3)
     const int srow = tid >> 2;
     const int scol = ((tid & 3) ^ ((srow >> 2) & 3)) * 8;  // (row>>2)&3 does not depend on i (i*64 >> 2 = 16 i)
-    const bf16_t* pA = (const bf16_t*)a.A + a_row_base(a, m0 + srow) + scol;
-    const bf16_t* pW = (const bf16_t*)a.W + (int64_t)(n0 + srow) * a.ldw + scol;
-    int dA[4];
+    // saddr-form LDS-DMA: wave-uniform half-tile base + loop-invariant 32-bit lane offsets
+    const int64_t rbase0 = a_row_base(a, m0);
+    const char* Abase = (const char*)a.A + 2 * rbase0;
+    const char* Wbase = (const char*)a.W + 2 * (int64_t)n0 * a.ldw;
+    unsigned offA[4], offW[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dA[i] = (int)(a_row_base(a, m0 + srow + i * 64) - a_row_base(a, m0 + srow));
-    const int64_t dW = (int64_t)64 * a.ldw;
+    for (int i = 0; i < 4; ++i) {
+        offA[i] = (unsigned)(2 * (a_row_base(a, m0 + srow + i * 64) - rbase0 + scol));
+        offW[i] = (unsigned)(2 * ((int64_t)(srow + i * 64) * a.ldw + scol));
+    }
     int64_t ka_cur = 0;  // A-operand displacement of the half-tile being staged (one evaluation per half-step)
     auto glds_one = [&](int h, int s, int idx8) {  // idx8 0..3 -> A piece, 4..7 -> W piece
         char* base = smem + s * WH_STAGE;
         const int i = idx8 & 3;
-        if (idx8 < 4) {
-            char* dst = base + (i * 256 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pA + dA[i] + ka_cur),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        } else {
-            char* dst = base + WH_A + (i * 256 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pW + i * dW + h * K32),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
+        if (idx8 < 4) glds16_saddr(Abase + 2 * ka_cur, offA[i], base + (i * 256 + wave * 64) * 16);
+        else glds16_saddr(Wbase + 2 * (int64_t)h * K32, offW[i], base + WH_A + (i * 256 + wave * 64) * 16);
     };
 
     f32x16 acc[4][4];
