@@ -44,6 +44,9 @@ struct s2v_ctx {
     bool mfma = false;
     bool finalized = false;
     // weights
+    int num_cus = 256;
+    hipStream_t side = nullptr;              // fork/join stream for the row-tail launches of split GEMMs
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     char* arena = nullptr;
     int64_t arena_bytes = 0;
     std::unordered_map<std::string, Slot> slots;
@@ -124,6 +127,17 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     c->dtype = cfg->dtype;
     c->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
     c->temb = cfg->time_embed_dim;
+    {
+        int dev = 0, ncu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
+            c->num_cus = ncu;
+    }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        return s2v_fail(__FILE__, __LINE__, "s2v_create: stream / event creation failed", -2);
+    }
     c->mfma = (cfg->dtype == S2V_DTYPE_BF16) && !cfg->force_simple;
     if (c->D > 4096) { delete c; return s2v_fail(__FILE__, __LINE__, "s2v_create: D > 4096 unsupported", -1); }
     if (c->temb % 8 != 0 || c->D % 8 != 0) { delete c; return s2v_fail(__FILE__, __LINE__, "bad dims", -1); }
@@ -231,6 +245,9 @@ extern "C" void s2v_destroy(s2v_ctx* c) {
     if (!c) return;
     if (c->gexec) hipGraphExecDestroy(c->gexec);
     if (c->cap_stream) hipStreamDestroy(c->cap_stream);
+    if (c->side) hipStreamDestroy(c->side);
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->ring) hipHostFree(c->ring);
     if (c->coef_dev) hipFree(c->coef_dev);
     if (c->t_dev) hipFree(c->t_dev);
@@ -374,7 +391,28 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
     // every GEMM operand of the transformer lives in a workspace buffer with >= 256 rows of slack behind it
     g.a_rows_padded = (int)(rup(g.M, 256));
     g.w_rows_padded = (int)(rup(g.N, 256));  // every weight of the arena is carved with its rows padded to 256
-    if (c->mfma && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0) return launch_gemm_bf16(g, epi, st);
+    if (c->mfma && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0) {
+        // Tile-count quantisation: the 256 x 256 kernel runs one tile per CU, so a grid that spills a few tiles into an extra
+        // round pays a whole round (C3: 150 x 12 = 1800 tiles = 7.03 rounds of 256 CUs for the out-proj / FF2).  When the
+        // last row tile is partial and dropping it saves a round, the full row tiles run on the big kernel and the row tail
+        // (108 rows at C3) on the 128 x 128 kernel.
+        const int64_t tn = (g.N + 255) / 256, tm = (g.M + 255) / 256, ncu = c->num_cus;
+        const int rem = (int)(g.M % 256);
+        if (rem > 0 && tm > 1 && g.N >= 256 && (tm * tn + ncu - 1) / ncu > ((tm - 1) * tn + ncu - 1) / ncu) {
+            GemmArgs gm = g, gt = g;
+            gm.M = (int)((tm - 1) * 256);
+            gt.m_begin = gm.M;
+            // fork: the tail runs on the side stream beside the main launch (event fork/join, valid under stream capture)
+            S2V_CHECK_HIP(hipEventRecord(c->ev_fork, st));
+            S2V_CHECK_HIP(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+            S2V_TRY(launch_gemm_bf16(gt, epi, c->side));
+            S2V_CHECK_HIP(hipEventRecord(c->ev_join, c->side));
+            S2V_TRY(launch_gemm_bf16(gm, epi, st));
+            S2V_CHECK_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+            return 0;
+        }
+        return launch_gemm_bf16(g, epi, st);
+    }
     return launch_gemm_simple(g, epi, c->dtype, st);
 }
 

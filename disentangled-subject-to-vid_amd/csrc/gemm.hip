@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int ti
     const int in_g = wg - group * per_group;
     const int tile_m = first_m + in_g % gsz;
     const int tile_n = in_g / gsz;
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int m0 = a.m_begin + tile_m * BM, n0 = tile_n * BN;
 
     const bf16_t* A = (const bf16_t*)a.A;
     const bf16_t* W = (const bf16_t*)a.W;
@@ -1787,6 +1787,21 @@ static bool w_tile_ok(const GemmArgs& a) {
 int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     GemmArgs a = a0;
     a.ablate = g_gemm_ablate;
+    if (a.m_begin > 0) {  // row tail of a split GEMM: the 128 x 128 kernel on rows [m_begin, M)
+        S2V_REQUIRE(!a.conv && a.K % BK == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm_bf16: bad tail launch");
+        const int tiles_m = (a.M - a.m_begin + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+        const size_t shmem = 4 * TILE_BYTES;
+        const dim3 grid(tiles_m * tiles_n);
+        switch (epi) {
+            case EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
+            case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_GELU>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
+            case EPI_BIAS_GATE_RES: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_GATE_RES>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
+            case EPI_BIAS_ADD: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_ADD>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
+            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
+        }
+        S2V_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     S2V_REQUIRE(a.K % BK == 0, "gemm_bf16: K must be a multiple of 64");
     if (g_gemm_impl == 8 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");

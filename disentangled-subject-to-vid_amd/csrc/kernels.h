@@ -32,6 +32,7 @@ struct GemmArgs {
     int cstride;        // conv mode: spatial stride of the output grid (0 or 1 = dense; 2 = CogVideoXDownsample3D, downsampling.py:322-353)
     int ablate;         // diagnostics only
     int a_rows_padded;  // plain mode: rows physically present behind A (>= M); the 256-row kernel needs ceil256(M)
+    int m_begin;        // first output row of this launch (row-tail launches of a split GEMM; 128-row kernel only)
     int w_rows_padded;  // rows physically present behind W (>= N, zero or don't-care beyond N); 0 = exactly N
 };
 enum { EPI_BIAS_ADD = 3 };
