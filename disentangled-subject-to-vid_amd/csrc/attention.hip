@@ -9,6 +9,8 @@
 //     registers: the MFMA k-slot <-> key assignment is free, so V^T is stored in HBM with the keys of every
 //     16-group permuted [0-3, 8-11, 4-7, 12-15] (done by qk_norm_rope) and no lane exchange is needed.
 //     O^T = V^T . P^T accumulates with the query again on the lane axis.
+//     Softmax in the exp2 domain: Q is pre-multiplied by scale * log2(e) and the S^T accumulators start at -m_run (a
+//     loop-carried register block), so p = exp2(MFMA result) with no per-score fma (measured +3.5 % at C3).
 //  attn_simple_k<T> : one wave per query row, fp32 math, any dtype (CPU-reference-parity mode / cross-check).
 #define S2V_HOST
 #include "common.h"
@@ -46,8 +48,9 @@ __device__ __forceinline__ bf16x8 frag64(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + row * 128 + ((cl ^ ((row >> 1) & 7)) << 4));
 }
 
-template <int ABL, int NW = 4>
-__global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_bf16_k(const AttnArgs a, int nqb) {
+// ABL (diagnostics, tools/ablate_attn.py; results are wrong on purpose): 1 = no exp2, 2 = no row-sum adds, 3 = no row max
+template <int ABL, int NW = 8>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K tile | VT tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, hi = lane >> 5;
@@ -64,24 +67,31 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_bf16_k(const At
     const bf16_t* Kg = qkv + D + h * 64;
     const bf16_t* VTg = (const bf16_t*)a.vt + (size_t)(b * a.H + h) * 64 * a.ntok_pad;
 
-    // Q fragments (B operand of S^T = K.Q^T): lane (q = fr, hi) holds Q[q][16kk + 8hi .. +8]
+    // Q fragments (B operand of S^T = K.Q^T): lane (q = fr, hi) holds Q[q][16kk + 8hi .. +8], pre-multiplied by
+    // scale * log2(e) and rounded to bf16 once (the reference's math path rounds its scaled q and k to bf16 as well), so the
+    // MFMA result is already the exp2 argument
     const int q_row = qb * (NW * 32) + wave * 32 + fr;
     const int q_ld = min(q_row, a.Ntok - 1);
+    const float c0 = a.scale * 1.4426950408889634f;
     bf16x8 qf[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+    for (int kk = 0; kk < 4; ++kk) {
         qf[kk] = *(const bf16x8*)(qkv + (size_t)q_ld * a.ld_qkv + h * 64 + kk * 16 + hi * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[kk][e] = (__bf16)((float)qf[kk][e] * c0);
+    }
 
     f32x16 ot[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) ot[i][e] = 0.f;
-    f32x16 zero16;
+    // the S^T accumulators START at -m_run: this 16-register block is loop-carried and only rewritten when a row maximum
+    // grows, so in the steady state a score costs exp2 + add (+ half a cvt_pk) and no fma
+    f32x16 negm16;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) zero16[e] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-    const float c = a.scale * 1.4426950408889634f;
+    for (int e = 0; e < 16; ++e) negm16[e] = 0.f;
+    float m_run = 0.f, l_run = 0.f;
 
     const int nt = (a.Ntok + KV_TILE - 1) / KV_TILE;
     stage_kv<NW>(Kg, a.ld_qkv, VTg, a.ntok_pad, smem, tid);
@@ -97,17 +107,14 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_bf16_k(const At
         const char* tK = smem + cur * 2 * ATT_TILE_BYTES;
         const char* tV = tK + ATT_TILE_BYTES;
 
-        // S^T[kv][q] for two 32-key blocks
+        // S^T[kv][q] - m_run for two 32-key blocks
         f32x16 st[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            // first MFMA of the chain takes the loop-invariant zero block as C: no 32 v_mov per tile
-            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag64(tK, kb * 32 + fr, hi), qf[0], zero16, 0, 0, 0);
+            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag64(tK, kb * 32 + fr, hi), qf[0], negm16, 0, 0, 0);
 #pragma unroll
-            for (int kk = 1; kk < 4; ++kk) {
-                bf16x8 kf = frag64(tK, kb * 32 + fr, kk * 2 + hi);
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], st[kb], 0, 0, 0);
-            }
+            for (int kk = 1; kk < 4; ++kk)
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag64(tK, kb * 32 + fr, kk * 2 + hi), qf[kk], st[kb], 0, 0, 0);
         }
         if (kv0 + KV_TILE > a.Ntok) {  // tail tile: mask keys >= Ntok
 #pragma unroll
@@ -124,26 +131,31 @@ __global__ __launch_bounds__(NW * 64, NW >= 8 ? 1 : 2) void attn_bf16_k(const At
 #pragma unroll
             for (int e = 0; e < 16; ++e)
                 if (ABL != 3) mx = fmaxf(mx, st[kb][e]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        // exact skip: when no row of the wave raised its running max, alpha == 1 for every lane
-        const bool grew = __any(m_new > m_run);
-        if (grew) {
-            const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));  // (row max of this tile) - m_run
+        // The first tile adopts its own maximum (m_run starts at 0); later tiles only raise it, and the branch is skipped
+        // exactly when no row of the wave grew (alpha == 1 for every lane).
+        if (t == 0 || __any(mx > 0.f)) {
+            const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
+            const float alpha = __builtin_amdgcn_exp2f(-d);
+            m_run += d;
             l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) st[kb][e] -= d;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) negm16[e] = -m_run;
         }
-        const float mc = m_new * c;
-        m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const float p = (ABL == 1) ? (st[kb][e] * c - mc) : __builtin_amdgcn_exp2f(st[kb][e] * c - mc);
+                const float p = (ABL == 1) ? st[kb][e] : __builtin_amdgcn_exp2f(st[kb][e]);
                 st[kb][e] = p;
                 if (ABL != 2) psum += p;
             }
@@ -194,12 +206,13 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
     // default: eight waves (256 query rows) per block -- each thread moves one K and one V^T piece per KV tile, half the
     // LDS-DMA issue work per wave of the four-wave form (measured +2 % at C3); variants are diagnostics (tools/ablate_attn.py)
     const int nqb8 = (a.Ntok + 255) / 256;
+    const dim3 g8(nqb8 * a.B * a.H), b8(512);
     switch (g_attn_variant) {
-        case 1: hipLaunchKernelGGL(attn_bf16_k<1>, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
-        case 2: hipLaunchKernelGGL(attn_bf16_k<2>, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
-        case 3: hipLaunchKernelGGL(attn_bf16_k<3>, dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
+        case 1: hipLaunchKernelGGL((attn_bf16_k<1, 8>), g8, b8, 4 * ATT_TILE_BYTES, st, a, nqb8); break;
+        case 2: hipLaunchKernelGGL((attn_bf16_k<2, 8>), g8, b8, 4 * ATT_TILE_BYTES, st, a, nqb8); break;
+        case 3: hipLaunchKernelGGL((attn_bf16_k<3, 8>), g8, b8, 4 * ATT_TILE_BYTES, st, a, nqb8); break;
         case 4: hipLaunchKernelGGL((attn_bf16_k<0, 4>), dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
-        default: hipLaunchKernelGGL((attn_bf16_k<0, 8>), dim3(nqb8 * a.B * a.H), dim3(512), 4 * ATT_TILE_BYTES, st, a, nqb8); break;
+        default: hipLaunchKernelGGL((attn_bf16_k<0, 8>), g8, b8, 4 * ATT_TILE_BYTES, st, a, nqb8); break;
     }
     S2V_CHECK_HIP(hipGetLastError());
     return 0;

@@ -23,7 +23,15 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters, long long* c
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int r = (i * NV + k) & 15;
-                if (EXP && (k & 1)) v[r] = __builtin_amdgcn_exp2f(v[r]);
+                if (EXP == 2 && (k & 1)) {
+                    _Float16 hh = (_Float16)v[r];
+                    asm volatile("v_exp_f16 %0, %1" : "=v"(hh) : "v"(hh));
+                    v[r] = (float)hh;
+                } else if (EXP == 3 && (k & 1)) {
+                    asm volatile("v_exp_f16 %0, %1" : "=v"(v[r]) : "v"(v[r]));   // raw issue cost, registers reinterpreted
+                } else if (EXP == 4 && (k & 1)) {
+                    asm volatile("v_exp_f32 %0, %1" : "=v"(v[r]) : "v"(v[r]));
+                } else if (EXP == 1 && (k & 1)) v[r] = __builtin_amdgcn_exp2f(v[r]);
                 else v[r] = v[r] * 0.999f + 0.001f;
             }
         }
@@ -55,14 +63,15 @@ static void run(int waves_per_simd) {
     long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
     const double per_mfma_wave = (double)c / iters / 8;
     printf("waves/SIMD=%d NV=%2d %s: %7.1f ticks per MFMA group per wave -> %6.1f per SIMD-MFMA; %7.3f ms (%.0f TFLOP/s equiv)\n", waves_per_simd, NV,
-           EXP ? "fma+exp" : "fma    ", per_mfma_wave, per_mfma_wave / waves_per_simd, ms,
+           EXP == 0 ? "fma        " : EXP == 1 ? "fma+exp    " : EXP == 3 ? "fma+exp_f16" : "fma+exp_f32", per_mfma_wave, per_mfma_wave / waves_per_simd, ms,
            256.0 * 4 * waves_per_simd * iters * 8 * 32768.0 / ms / 1e9);
 }
 
 int main() {
-    for (int w : {1, 2}) {
+    for (int w : {1}) {
         run<0, 0>(w); run<2, 0>(w); run<4, 0>(w); run<6, 0>(w); run<8, 0>(w); run<14, 0>(w);
         run<4, 1>(w); run<8, 1>(w); run<14, 1>(w);
+        run<8, 3>(w); run<8, 4>(w); run<14, 3>(w); run<14, 4>(w);
     }
     return 0;
 }
