@@ -247,15 +247,30 @@ def main():
             ref_lat = vae.encode(img).latent_dist.sample(generator=torch.Generator().manual_seed(1)) * vcfg.scaling_factor
             torch.cuda.synchronize()
             enc["tiled" if tiling else "untiled"] = time.perf_counter() - t1
+        vae.close()
+        vae = None
+        # prompt embeddings: T5-v1.1-XXL encoder, prompt + negative prompt, 226 tokens (pipeline_cogvideox.py:197-237)
+        tcfg = s2v.T5Config()
+        t5 = s2v.HipT5EncoderModel(tcfg, dt, dev)
+        t5.load_state_dict(s2v.weights.synthetic_t5_state_dict(tcfg, seed=10, device=dev, dtype=dt, gain=0.5))
+        ids = torch.randint(0, tcfg.vocab_size, (2, 226), generator=torch.Generator().manual_seed(11)).to(dev)
+        t5(ids)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        emb = t5(ids)[0]
+        torch.cuda.synchronize()
+        t5_s = time.perf_counter() - t1
+        t5_ok = bool(torch.isfinite(emb.float()).all().item())
+        t5.close()
         step_s = elapsed / args.steps
         video = {"denoise_steps": 50, "denoise_s": round(50 * step_s, 2),
+                 "text_encode_t5xxl_s": round(t5_s, 4), "text_embeds_finite": t5_ok,
                  "ref_image_encode_untiled_s": round(enc["untiled"], 4), "ref_image_encode_tiled_s": round(enc["tiled"], 4),
                  "ref_latent_finite": bool(torch.isfinite(ref_lat.float()).all().item()),
                  "vae_decode_untiled_s": round(dec["untiled"], 3), "vae_decode_tiled_s": round(dec["tiled"], 3),
                  "s_per_video_untiled": round(50 * step_s + dec["untiled"], 2),
                  "s_per_video_tiled": round(50 * step_s + dec["tiled"], 2),
                  "frames": list(frames.shape), "frames_finite": bool(torch.isfinite(frames.float()).all().item())}
-        vae.close()
     if rank == 0:
         out = {
             "metric": "denoise steps/sec (CogVideoX-5B, 49f 720x480; one step = CFG-pair transformer forward + CFG + "

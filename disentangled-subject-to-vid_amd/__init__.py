@@ -10,3 +10,4 @@ from .pipeline import S2VPipeline  # noqa: F401
 from .vae import HipAutoencoderKLCogVideoX  # noqa: F401
 from . import dist  # noqa: F401
 from . import checkpoint  # noqa: F401
+from .t5 import HipT5EncoderModel, T5Config  # noqa: F401

@@ -1,0 +1,357 @@
+// T5 v1.1 ENCODER stack: the prompt embeddings of the pipeline.
+// Replaces `self.text_encoder(text_input_ids.to(device))[0]` of pipelines/cogvideo/pipeline_cogvideox.py:227 for the model
+// src/inference.py:183-187 loads (T5EncoderModel, T5-v1.1-XXL: 24 blocks, d_model 4096, 64 heads x 64, gated-GELU d_ff 10240).
+// The arithmetic is transformers' (third party, not in the reference tree): models/t5/modeling_t5.py T5LayerNorm, T5Attention
+// (no 1/sqrt(d), additive relative-position bias shared from block 0, softmax in fp32), T5DenseGatedActDense (gelu_new), T5Block.
+// No attention mask (the pipeline passes none).  Rounding points follow the bf16 tensor ops of that implementation.
+//
+// GEMMs run on the kernels of gemm.hip (weights fused: [q|k|v] and [wi_0|wi_1]); new here: embedding gather, RMS norm,
+// gated GELU, and a small attention kernel with the additive bias (226 tokens: one wave per query row is enough).
+#define S2V_HOST
+#include "common.h"
+#include "kernels.h"
+#include "../../include/s2v_hip.h"
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+template <typename T>
+__global__ void t5_embed_k(const long long* ids, const T* table, int M, int d, int vocab, T* out) {
+    const int64_t total = (int64_t)M * d;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / d), c = (int)(i - (int64_t)m * d);
+        long long id = ids[m];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        out[i] = table[(size_t)id * d + c];
+    }
+}
+
+// T5LayerNorm: y = w * cast(x * rsqrt(mean(x^2) + eps)); one wave per row
+template <typename T>
+__global__ __launch_bounds__(256) void t5_rms_norm_k(const T* x, const T* w, int M, int d, float eps, T* out) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const T* xr = x + (size_t)m * d;
+    float ss = 0.f;
+    for (int c = lane; c < d; c += 64) {
+        const float v = ET<T>::ld(xr + c);
+        ss += v * v;
+    }
+    ss = wave_sum(ss);
+    const float r = 1.0f / sqrtf(ss / (float)d + eps);
+    T* o = out + (size_t)m * d;
+    for (int c = lane; c < d; c += 64) ET<T>::st(o + c, ET<T>::rnd(ET<T>::ld(w + c) * ET<T>::rnd(ET<T>::ld(xr + c) * r)));
+}
+
+// T5DenseGatedActDense: out = gelu_new(a[:, :F]) * a[:, F:]   (both factors and the product rounded to T)
+template <typename T>
+__global__ void t5_gate_k(const T* a, int M, int F, T* out) {
+    const int64_t total = (int64_t)M * F;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i / F), c = (int)(i - (int64_t)m * F);
+        // NewGELUActivation is a chain of tensor ops, each rounding to T:
+        //   0.5 * x * (1 + tanh(sqrt(2/pi) * (x + 0.044715 * pow(x, 3))))
+        const float x = ET<T>::ld(a + (size_t)m * 2 * F + c);
+        const float x3 = ET<T>::rnd(x * x * x);
+        const float t1 = ET<T>::rnd(0.044715f * x3);
+        const float t2 = ET<T>::rnd(x + t1);
+        const float t3 = ET<T>::rnd(0.7978845608028654f * t2);
+        const float t4 = ET<T>::rnd(tanhf(t3));
+        const float t5 = ET<T>::rnd(1.0f + t4);
+        const float t6 = ET<T>::rnd(0.5f * x);
+        const float g = ET<T>::rnd(t6 * t5);
+        const float u = ET<T>::ld(a + (size_t)m * 2 * F + F + c);
+        ET<T>::st(out + i, ET<T>::rnd(g * u));
+    }
+}
+
+// one wave per (b, h, query): scores = round(q . k) (no scale), + bias[h][q][k] (rounded), softmax in fp32, weights rounded
+// to T, o = sum w_k v_k.  qkv [B*T][3*H*64] (q | k | v), head_dim 64.
+template <typename T>
+__global__ __launch_bounds__(256) void t5_attn_k(const T* qkv, const T* bias, int B, int H, int Tn, T* out) {
+    __shared__ float sq[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + wave, h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64, ld = 3 * D;
+    const bool active = q < Tn;
+    const int ql = active ? q : Tn - 1;
+    const T* base = qkv + (size_t)b * Tn * ld;
+    sq[wave][lane] = ET<T>::ld(base + (size_t)ql * ld + h * 64 + lane);
+    __syncthreads();
+    const T* brow = bias + ((size_t)h * Tn + ql) * Tn;
+    // pass 1: row maximum of the rounded, biased scores
+    float m = -INFINITY;
+    for (int kv0 = 0; kv0 < Tn; kv0 += 64) {
+        const int kv = kv0 + lane;
+        float s = -INFINITY;
+        if (kv < Tn) {
+            const T* kp = base + (size_t)kv * ld + D + h * 64;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int d = 0; d < 64; ++d) acc = fmaf(sq[wave][d], ET<T>::ld(kp + d), acc);
+            s = ET<T>::rnd(ET<T>::rnd(acc) + ET<T>::ld(brow + kv));
+        }
+        m = fmaxf(m, wave_max(s));
+    }
+    // pass 2: exp, sum, weighted values (scores recomputed: T is small)
+    float l = 0.f;
+    for (int kv0 = 0; kv0 < Tn; kv0 += 64) {
+        const int kv = kv0 + lane;
+        float p = 0.f;
+        if (kv < Tn) {
+            const T* kp = base + (size_t)kv * ld + D + h * 64;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int d = 0; d < 64; ++d) acc = fmaf(sq[wave][d], ET<T>::ld(kp + d), acc);
+            p = expf(ET<T>::rnd(ET<T>::rnd(acc) + ET<T>::ld(brow + kv)) - m);
+        }
+        l += wave_sum(p);
+    }
+    const float inv = 1.0f / l;
+    float o = 0.f;
+    for (int kv0 = 0; kv0 < Tn; kv0 += 64) {
+        const int kv = kv0 + lane;
+        float p = 0.f;
+        if (kv < Tn) {
+            const T* kp = base + (size_t)kv * ld + D + h * 64;
+            float acc = 0.f;
+#pragma unroll 8
+            for (int d = 0; d < 64; ++d) acc = fmaf(sq[wave][d], ET<T>::ld(kp + d), acc);
+            p = ET<T>::rnd(expf(ET<T>::rnd(ET<T>::rnd(acc) + ET<T>::ld(brow + kv)) - m) * inv);
+        }
+        const int nv = min(64, Tn - kv0);
+        for (int j = 0; j < nv; ++j) {
+            const float pj = __shfl(p, j, 64);
+            o = fmaf(pj, ET<T>::ld(base + (size_t)(kv0 + j) * ld + 2 * D + h * 64 + lane), o);
+        }
+    }
+    if (active) ET<T>::st(out + (size_t)(b * Tn + q) * D + h * 64 + lane, o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct T5Layer { char *ln0, *wqkv, *wo, *ln1, *wi, *wff; };
+struct T5Slot { char* dst; int64_t rows, cols; bool loaded; };
+
+struct s2v_t5 {
+    s2v_t5_config cfg;
+    int dtype = 0, esz = 0, inner = 0;
+    bool mfma = false, finalized = false, have_bias = false;
+    std::vector<T5Layer> layers;
+    char *shared = nullptr, *final_ln = nullptr, *rel_table = nullptr;
+    std::unordered_map<std::string, T5Slot> slots;
+    std::vector<void*> allocs;
+    // workspace for (B, T)
+    int B = 0, T = 0;
+    int64_t Mpad = 0;
+    char *X = nullptr, *Xn = nullptr, *QKV = nullptr, *AO = nullptr, *FF = nullptr, *G = nullptr, *bias = nullptr;
+    std::vector<void*> ws_allocs;
+};
+
+static int64_t rup_(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+static int t5_alloc(s2v_t5* t, char** p, int64_t bytes, bool ws = false) {
+    void* q = nullptr;
+    S2V_CHECK_HIP(hipMalloc(&q, (size_t)(bytes > 0 ? bytes : 16)));
+    S2V_CHECK_HIP(hipMemset(q, 0, (size_t)(bytes > 0 ? bytes : 16)));
+    (ws ? t->ws_allocs : t->allocs).push_back(q);
+    *p = (char*)q;
+    return 0;
+}
+
+extern "C" void s2v_t5_destroy(s2v_t5* t) {
+    if (!t) return;
+    (void)hipDeviceSynchronize();
+    for (void* p : t->allocs) (void)hipFree(p);
+    for (void* p : t->ws_allocs) (void)hipFree(p);
+    delete t;
+}
+
+extern "C" int s2v_t5_create(const s2v_t5_config* cfg, s2v_t5** out) {
+    S2V_REQUIRE(cfg && out, "s2v_t5_create: null argument");
+    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_t5_create: unsupported dtype");
+    S2V_REQUIRE(cfg->d_kv == 64, "s2v_t5_create: head dimension must be 64 (T5 v1.1 XXL)");
+    S2V_REQUIRE(cfg->num_layers > 0 && cfg->num_heads > 0 && cfg->d_model > 0 && cfg->d_ff > 0 && cfg->vocab_size > 0,
+                "s2v_t5_create: bad model size");
+    S2V_REQUIRE(cfg->d_model % 8 == 0 && cfg->d_ff % 8 == 0, "s2v_t5_create: d_model and d_ff must be multiples of 8");
+    s2v_t5* t = new s2v_t5();
+    t->cfg = *cfg;
+    t->dtype = cfg->dtype;
+    t->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
+    t->inner = cfg->num_heads * cfg->d_kv;
+    t->mfma = cfg->dtype == S2V_DTYPE_BF16 && !cfg->force_simple && cfg->d_model % 64 == 0 && cfg->d_ff % 64 == 0;
+    const int64_t d = cfg->d_model, in = t->inner, F = cfg->d_ff, E = t->esz;
+    int r = t5_alloc(t, &t->shared, (int64_t)cfg->vocab_size * d * E);
+    if (!r) r = t5_alloc(t, &t->final_ln, d * E);
+    if (!r) r = t5_alloc(t, &t->rel_table, (int64_t)cfg->relative_attention_num_buckets * cfg->num_heads * E);
+    t->slots["shared.weight"] = T5Slot{t->shared, cfg->vocab_size, d, false};
+    t->slots["encoder.final_layer_norm.weight"] = T5Slot{t->final_ln, d, 1, false};
+    t->slots["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] =
+        T5Slot{t->rel_table, cfg->relative_attention_num_buckets, cfg->num_heads, false};
+    t->layers.resize(cfg->num_layers);
+    char nm[160];
+    for (int i = 0; i < cfg->num_layers && !r; ++i) {
+        T5Layer& L = t->layers[i];
+        // weight rows padded to the 256-column GEMM tile (zero rows)
+        if (!r) r = t5_alloc(t, &L.ln0, d * E);
+        if (!r) r = t5_alloc(t, &L.wqkv, rup_(3 * in, 256) * d * E);
+        if (!r) r = t5_alloc(t, &L.wo, rup_(d, 256) * in * E);
+        if (!r) r = t5_alloc(t, &L.ln1, d * E);
+        if (!r) r = t5_alloc(t, &L.wi, rup_(2 * F, 256) * d * E);
+        if (!r) r = t5_alloc(t, &L.wff, rup_(d, 256) * F * E);
+        if (r) break;
+        const char* qkvn[3] = {"q", "k", "v"};
+        for (int j = 0; j < 3; ++j) {
+            snprintf(nm, sizeof(nm), "encoder.block.%d.layer.0.SelfAttention.%s.weight", i, qkvn[j]);
+            t->slots[nm] = T5Slot{L.wqkv + (int64_t)j * in * d * E, in, d, false};
+        }
+        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.0.SelfAttention.o.weight", i);
+        t->slots[nm] = T5Slot{L.wo, d, in, false};
+        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.0.layer_norm.weight", i);
+        t->slots[nm] = T5Slot{L.ln0, d, 1, false};
+        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.layer_norm.weight", i);
+        t->slots[nm] = T5Slot{L.ln1, d, 1, false};
+        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.DenseReluDense.wi_0.weight", i);
+        t->slots[nm] = T5Slot{L.wi, F, d, false};
+        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.DenseReluDense.wi_1.weight", i);
+        t->slots[nm] = T5Slot{L.wi + F * d * E, F, d, false};
+        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.DenseReluDense.wo.weight", i);
+        t->slots[nm] = T5Slot{L.wff, d, F, false};
+    }
+    if (r) { s2v_t5_destroy(t); return r; }
+    *out = t;
+    return 0;
+}
+
+extern "C" int s2v_t5_load_weight(s2v_t5* t, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
+                                  int32_t src_dtype, s2v_stream stream) {
+    S2V_REQUIRE(t && name && dev_ptr && shape, "s2v_t5_load_weight: null argument");
+    S2V_REQUIRE(src_dtype == S2V_DTYPE_F32 || src_dtype == S2V_DTYPE_BF16, "s2v_t5_load_weight: unsupported dtype");
+    std::string key = name;
+    if (key == "encoder.embed_tokens.weight") key = "shared.weight";  // tied
+    auto it = t->slots.find(key);
+    if (it == t->slots.end()) {
+        std::string m = std::string("s2v_t5_load_weight: unknown tensor name: ") + name;
+        return s2v_fail(__FILE__, __LINE__, m.c_str(), -3);
+    }
+    T5Slot& s = it->second;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) n *= shape[i];
+    if (n != s.rows * s.cols || shape[0] != s.rows) {
+        std::string m = std::string("s2v_t5_load_weight: shape mismatch for ") + name;
+        return s2v_fail(__FILE__, __LINE__, m.c_str(), -3);
+    }
+    S2V_TRY(launch_convert(dev_ptr, src_dtype, s.dst, t->dtype, n, (hipStream_t)stream));
+    s.loaded = true;
+    return 0;
+}
+
+extern "C" int s2v_t5_finalize(s2v_t5* t) {
+    S2V_REQUIRE(t, "null t5");
+    for (auto& kv : t->slots)
+        if (!kv.second.loaded) {
+            std::string m = std::string("s2v_t5_finalize: tensor was never loaded: ") + kv.first;
+            return s2v_fail(__FILE__, __LINE__, m.c_str(), -3);
+        }
+    t->finalized = true;
+    return 0;
+}
+
+static int t5_workspace(s2v_t5* t, int B, int T) {
+    if (t->B == B && t->T == T) return 0;
+    S2V_CHECK_HIP(hipDeviceSynchronize());
+    for (void* p : t->ws_allocs) (void)hipFree(p);
+    t->ws_allocs.clear();
+    t->have_bias = false;
+    const int64_t M = (int64_t)B * T, E = t->esz, d = t->cfg.d_model, in = t->inner, F = t->cfg.d_ff;
+    t->Mpad = rup_(M, 256) + 256;
+    S2V_TRY(t5_alloc(t, &t->X, t->Mpad * d * E, true));
+    S2V_TRY(t5_alloc(t, &t->Xn, t->Mpad * d * E, true));
+    S2V_TRY(t5_alloc(t, &t->QKV, t->Mpad * 3 * in * E, true));
+    S2V_TRY(t5_alloc(t, &t->AO, t->Mpad * in * E, true));
+    S2V_TRY(t5_alloc(t, &t->FF, t->Mpad * 2 * F * E, true));
+    S2V_TRY(t5_alloc(t, &t->G, t->Mpad * F * E, true));
+    S2V_TRY(t5_alloc(t, &t->bias, (int64_t)t->cfg.num_heads * T * T * E, true));
+    t->B = B; t->T = T;
+    return 0;
+}
+
+// position_bias [H][T][T] in the model dtype (compute_bias of block 0, built on the host with the implementation's own
+// torch ops: tables.t5_position_bias); valid until the token count changes
+extern "C" int s2v_t5_set_position_bias(s2v_t5* t, const void* bias_dev, int32_t B, int32_t T, s2v_stream stream) {
+    S2V_REQUIRE(t && bias_dev && B > 0 && T > 0, "s2v_t5_set_position_bias: bad argument");
+    S2V_TRY(t5_workspace(t, B, T));
+    S2V_CHECK_HIP(hipMemcpyAsync(t->bias, bias_dev, (size_t)t->cfg.num_heads * T * T * t->esz, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+    t->have_bias = true;
+    return 0;
+}
+
+static int t5_linear(s2v_t5* t, const void* A, int lda, const void* W, void* C, int M, int N, int K, int epi, const void* R,
+                     hipStream_t st) {
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.ldw = K; g.bias = nullptr; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    g.R = R; g.ldr = N;
+    g.a_rows_padded = (int)rup_(M, 256);
+    g.w_rows_padded = (int)rup_(N, 256);
+    if (t->mfma && K % 64 == 0) return launch_gemm_bf16(g, epi, st);
+    return launch_gemm_simple(g, epi, t->dtype, st);
+}
+
+static inline unsigned grid1d(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 65535 * 16); }
+
+extern "C" int s2v_t5_encode(s2v_t5* t, const int64_t* input_ids_dev, int32_t B, int32_t T, void* out, s2v_stream stream) {
+    S2V_REQUIRE(t && input_ids_dev && out, "s2v_t5_encode: null argument");
+    S2V_REQUIRE(t->finalized, "s2v_t5_encode: weights not finalized");
+    S2V_REQUIRE(t->have_bias && t->B == B && t->T == T, "s2v_t5_encode: call s2v_t5_set_position_bias for this (B, T) first");
+    hipStream_t st = (hipStream_t)stream;
+    const int M = B * T, d = t->cfg.d_model, in = t->inner, F = t->cfg.d_ff, H = t->cfg.num_heads;
+    const float eps = t->cfg.layer_norm_epsilon;
+    const bool bf = t->dtype == S2V_DTYPE_BF16;
+#define T5_LAUNCH(kern, grid, block, ...)                                                          \
+    do {                                                                                           \
+        if (bf) hipLaunchKernelGGL(kern<bf16_t>, grid, block, 0, st, __VA_ARGS__);                 \
+        else hipLaunchKernelGGL(kern<float>, grid, block, 0, st, __VA_ARGS__);                     \
+        S2V_CHECK_HIP(hipGetLastError());                                                          \
+    } while (0)
+    if (bf) hipLaunchKernelGGL(t5_embed_k<bf16_t>, dim3(grid1d((int64_t)M * d)), dim3(256), 0, st, (const long long*)input_ids_dev,
+                               (const bf16_t*)t->shared, M, d, t->cfg.vocab_size, (bf16_t*)t->X);
+    else hipLaunchKernelGGL(t5_embed_k<float>, dim3(grid1d((int64_t)M * d)), dim3(256), 0, st, (const long long*)input_ids_dev,
+                            (const float*)t->shared, M, d, t->cfg.vocab_size, (float*)t->X);
+    S2V_CHECK_HIP(hipGetLastError());
+    const dim3 rows((M + 3) / 4), attn_grid((T + 3) / 4, H, B);
+    for (auto& L : t->layers) {
+        if (bf) {
+            hipLaunchKernelGGL(t5_rms_norm_k<bf16_t>, rows, dim3(256), 0, st, (const bf16_t*)t->X, (const bf16_t*)L.ln0, M, d, eps, (bf16_t*)t->Xn);
+        } else {
+            hipLaunchKernelGGL(t5_rms_norm_k<float>, rows, dim3(256), 0, st, (const float*)t->X, (const float*)L.ln0, M, d, eps, (float*)t->Xn);
+        }
+        S2V_CHECK_HIP(hipGetLastError());
+        S2V_TRY(t5_linear(t, t->Xn, d, L.wqkv, t->QKV, M, 3 * in, d, EPI_BIAS, nullptr, st));
+        if (bf) hipLaunchKernelGGL(t5_attn_k<bf16_t>, attn_grid, dim3(256), 0, st, (const bf16_t*)t->QKV, (const bf16_t*)t->bias, B, H, T, (bf16_t*)t->AO);
+        else hipLaunchKernelGGL(t5_attn_k<float>, attn_grid, dim3(256), 0, st, (const float*)t->QKV, (const float*)t->bias, B, H, T, (float*)t->AO);
+        S2V_CHECK_HIP(hipGetLastError());
+        S2V_TRY(t5_linear(t, t->AO, in, L.wo, t->X, M, d, in, EPI_BIAS_ADD, t->X, st));  // x = x + o(...)
+        if (bf) hipLaunchKernelGGL(t5_rms_norm_k<bf16_t>, rows, dim3(256), 0, st, (const bf16_t*)t->X, (const bf16_t*)L.ln1, M, d, eps, (bf16_t*)t->Xn);
+        else hipLaunchKernelGGL(t5_rms_norm_k<float>, rows, dim3(256), 0, st, (const float*)t->X, (const float*)L.ln1, M, d, eps, (float*)t->Xn);
+        S2V_CHECK_HIP(hipGetLastError());
+        S2V_TRY(t5_linear(t, t->Xn, d, L.wi, t->FF, M, 2 * F, d, EPI_BIAS, nullptr, st));
+        if (bf) hipLaunchKernelGGL(t5_gate_k<bf16_t>, dim3(grid1d((int64_t)M * F)), dim3(256), 0, st, (const bf16_t*)t->FF, M, F, (bf16_t*)t->G);
+        else hipLaunchKernelGGL(t5_gate_k<float>, dim3(grid1d((int64_t)M * F)), dim3(256), 0, st, (const float*)t->FF, M, F, (float*)t->G);
+        S2V_CHECK_HIP(hipGetLastError());
+        S2V_TRY(t5_linear(t, t->G, F, L.wff, t->X, M, d, F, EPI_BIAS_ADD, t->X, st));  // x = x + wo(g * u)
+    }
+    if (bf) hipLaunchKernelGGL(t5_rms_norm_k<bf16_t>, rows, dim3(256), 0, st, (const bf16_t*)t->X, (const bf16_t*)t->final_ln, M, d, eps, (bf16_t*)out);
+    else hipLaunchKernelGGL(t5_rms_norm_k<float>, rows, dim3(256), 0, st, (const float*)t->X, (const float*)t->final_ln, M, d, eps, (float*)out);
+    S2V_CHECK_HIP(hipGetLastError());
+#undef T5_LAUNCH
+    return 0;
+}
+
+// the block-0 relative attention bias table [num_buckets][H] in the model dtype (the host gathers it into [H][T][T])
+extern "C" int s2v_t5_rel_table(s2v_t5* t, void** dev_ptr) {
+    S2V_REQUIRE(t && dev_ptr, "s2v_t5_rel_table: null argument");
+    *dev_ptr = t->rel_table;
+    return 0;
+}

@@ -200,3 +200,40 @@ def synthetic_vae_encoder_state_dict(cfg, seed=8765, device="cpu", dtype=torch.f
             v = torch.randn(shp, generator=g) * (1.0 / fan_in) ** 0.5
         sd[k] = v.to(dtype).to(device)
     return sd
+
+
+def t5_encoder_shapes(cfg):
+    """HF state-dict keys / shapes of T5EncoderModel (v1.1, gated-gelu) for a t5.T5Config"""
+    d, inner, F = cfg.d_model, cfg.num_heads * cfg.d_kv, cfg.d_ff
+    out = {"shared.weight": (cfg.vocab_size, d), "encoder.final_layer_norm.weight": (d,),
+           "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight": (cfg.relative_attention_num_buckets, cfg.num_heads)}
+    for i in range(cfg.num_layers):
+        p = f"encoder.block.{i}."
+        for n in "qkv":
+            out[p + f"layer.0.SelfAttention.{n}.weight"] = (inner, d)
+        out[p + "layer.0.SelfAttention.o.weight"] = (d, inner)
+        out[p + "layer.0.layer_norm.weight"] = (d,)
+        out[p + "layer.1.DenseReluDense.wi_0.weight"] = (F, d)
+        out[p + "layer.1.DenseReluDense.wi_1.weight"] = (F, d)
+        out[p + "layer.1.DenseReluDense.wo.weight"] = (d, F)
+        out[p + "layer.1.layer_norm.weight"] = (d,)
+    return out
+
+
+def synthetic_t5_state_dict(cfg, seed=2468, device="cpu", dtype=torch.float32, gain=0.7):
+    """gain scales the Linear weights (std = gain / sqrt(fan_in)); T5 has no 1/sqrt(d) in its scores, so gains >~ 1 give
+    near-one-hot attention and a stack whose bf16 run is chaotic (bf16 vs fp32 of the SAME model differ by 25 %)."""
+    gdev = "cpu" if str(device) == "cpu" else device  # full-size models (4.7 B parameters) are drawn on the device
+    g = torch.Generator(device=gdev).manual_seed(seed)
+    sd = {}
+    for k, shp in t5_encoder_shapes(cfg).items():
+        if "layer_norm" in k:
+            v = 1.0 + 0.2 * torch.randn(shp, generator=g, device=gdev)
+        elif "relative_attention_bias" in k:
+            v = 0.5 * torch.randn(shp, generator=g, device=gdev)
+        elif k == "shared.weight":
+            v = torch.randn(shp, generator=g, device=gdev)
+        else:
+            v = torch.randn(shp, generator=g, device=gdev) * (gain / shp[1] ** 0.5)
+        sd[k] = v.to(dtype).to(device)
+    return sd

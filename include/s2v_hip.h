@@ -198,6 +198,38 @@ int s2v_vae_encode(s2v_vae* enc, const void* image, int32_t H, int32_t W, int32_
 int s2v_vae_gaussian_sample(const void* moments, const void* noise, int32_t latent_channels, int64_t n_spatial, void* out,
                             int32_t dtype, s2v_stream stream);
 
+/* ---- prompt embeddings: T5 v1.1 encoder (the other caller-side step in front of the denoise loop) ----------------
+ * Replaces `self.text_encoder(text_input_ids.to(device))[0]` of pipelines/cogvideo/pipeline_cogvideox.py:227 for the
+ * T5EncoderModel src/inference.py:183-187 loads.  The arithmetic is transformers' models/t5/modeling_t5.py (third party,
+ * not in the reference tree; pinned by tests/golden/t5_tiny.npz): T5LayerNorm, T5Attention (no scaling, relative-position
+ * bias of block 0 added to every block's scores, softmax in fp32), T5DenseGatedActDense (gelu_new), no attention mask.
+ * Weight names are the HF state-dict keys ("shared.weight", "encoder.block.3.layer.0.SelfAttention.q.weight",
+ * "encoder.block.3.layer.1.DenseReluDense.wi_0.weight", "encoder.final_layer_norm.weight", ...). */
+typedef struct s2v_t5 s2v_t5;
+typedef struct s2v_t5_config {
+    int32_t vocab_size;                        /* 32128 (+ added special tokens, src/inference.py:180-189) */
+    int32_t d_model, d_kv, num_heads, d_ff;    /* 4096, 64, 64, 10240 */
+    int32_t num_layers;                        /* 24 */
+    int32_t relative_attention_num_buckets;    /* 32 */
+    int32_t relative_attention_max_distance;   /* 128 */
+    int32_t dtype;                             /* S2V_DTYPE_* */
+    int32_t force_simple;                      /* 1 = generic kernels only (cross-check) */
+    float layer_norm_epsilon;                  /* 1e-6 */
+    int32_t reserved[5];
+} s2v_t5_config;
+int s2v_t5_create(const s2v_t5_config* cfg, s2v_t5** out);
+void s2v_t5_destroy(s2v_t5* t5);
+int s2v_t5_load_weight(s2v_t5* t5, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
+                       int32_t src_dtype, s2v_stream stream);
+int s2v_t5_finalize(s2v_t5* t5);
+/* device address of the loaded block-0 relative_attention_bias table [num_buckets, num_heads] (model dtype) */
+int s2v_t5_rel_table(s2v_t5* t5, void** dev_ptr);
+/* position_bias [num_heads, T, T] (model dtype) = T5Attention.compute_bias(T, T) of block 0, gathered by the host from
+ * s2v_t5_rel_table with the implementation's own bucket function; sizes the workspace for (B, T) */
+int s2v_t5_set_position_bias(s2v_t5* t5, const void* bias_dev, int32_t B, int32_t T, s2v_stream stream);
+/* input_ids int64 [B, T] -> last_hidden_state [B, T, d_model] (model dtype) */
+int s2v_t5_encode(s2v_t5* t5, const int64_t* input_ids_dev, int32_t B, int32_t T, void* out, s2v_stream stream);
+
 /* ---- operator-level entry points (used by the parity tests and micro-benchmarks) ------------------------- */
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic */
 int s2v_op_linear(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,

@@ -278,6 +278,40 @@ def gen_vae_enc():
     return sorted(sd)
 
 
+T5_TINY = dict(vocab_size=100, d_model=128, d_kv=64, num_heads=2, d_ff=256, num_layers=2, feed_forward_proj="gated-gelu",
+               relative_attention_num_buckets=32, relative_attention_max_distance=128)
+
+
+def gen_t5():
+    """Prompt embeddings (pipeline_cogvideox.py:227): transformers.T5EncoderModel(input_ids)[0], no attention mask, on a
+    tiny seeded T5 v1.1 encoder; 40 tokens so that every relative-position bucket class (exact, log, clipped) occurs."""
+    import transformers
+    from transformers import T5Config, T5EncoderModel
+
+    m = T5EncoderModel(T5Config(**T5_TINY)).float().eval()
+    gen = torch.Generator().manual_seed(21)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "layer_norm" in n:
+                p.copy_(1.0 + 0.2 * torch.randn(p.shape, generator=gen))
+            elif "relative_attention_bias" in n:
+                p.copy_(torch.randn(p.shape, generator=gen))
+            elif n.endswith("shared.weight") or "embed_tokens" in n:
+                p.copy_(torch.randn(p.shape, generator=gen))
+            else:
+                p.copy_(torch.randn(p.shape, generator=gen) * (1.5 / p.shape[1] ** 0.5))
+    sd = {k: v for k, v in m.state_dict().items() if k != "encoder.embed_tokens.weight"}  # tied to shared.weight
+    ids = torch.randint(0, 100, (2, 40), generator=gen)
+    ids[1, 25:] = 0  # a padded prompt: pad id 0 repeated (attended like any token: no mask is passed)
+    out = npsd(sd)
+    out["input_ids"] = ids.numpy()
+    with torch.no_grad():
+        out["last_hidden_state"] = m(ids)[0].numpy()
+        out["last_hidden_state_T9"] = m(ids[:, :9])[0].numpy()
+    out["transformers_version"] = np.array(transformers.__version__)
+    np.savez_compressed(os.path.join(OUT, "t5_tiny.npz"), **out)
+
+
 def gen_pipeline():
     """Full CustomCogVideoXPipeline.__call__ (src/custom_cogvideox_pipe.py:125-326) with tiny modules, 480x720
     (the only geometry the shipped harness supports: 1350 tokens per frame), 3 steps, DDIM and DPM."""
@@ -322,7 +356,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     import_reference()
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["tables", "sched", "transformer", "vae", "vae_enc", "pipeline"]
+    which = sys.argv[1:] or ["tables", "sched", "transformer", "vae", "vae_enc", "t5", "pipeline"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

@@ -250,3 +250,30 @@ def test_vae_encode_oracle_small_window():
 def test_vae_encode_tile_geometry_of_the_real_config():
     tg = vae_ref.encode_tile_geometry(dict(block_out_channels=(128, 256, 256, 512), sample_height=480, sample_width=720))
     assert tg == dict(ts_h=240, ts_w=360, ov_h=200, ov_w=288, bl_h=5, bl_w=9, lim_h=25, lim_w=36)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# prompt embeddings: T5 v1.1 encoder, pinned against transformers.T5EncoderModel
+T5_CFG = dict(d_model=128, d_kv=64, num_heads=2, d_ff=256, num_layers=2, relative_attention_num_buckets=32,
+              relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
+
+
+@pytest.mark.parametrize("key,T", [("last_hidden_state", 40), ("last_hidden_state_T9", 9)])
+def test_t5_oracle_vs_transformers(key, T):
+    from oracle import t5_ref
+    g = load_golden("t5_tiny.npz")
+    ids = torch.from_numpy(g["input_ids"])[:, :T]
+    with torch.no_grad():
+        y = t5_ref.encoder_forward(weights_of(g), T5_CFG, ids)
+    assert torch.allclose(y, torch.from_numpy(g[key]), atol=1e-4, rtol=1e-5)
+
+
+def test_t5_bucket_table_host_equals_oracle():
+    import importlib
+    from oracle import t5_ref
+    t5 = importlib.import_module("disentangled-subject-to-vid_amd.t5")
+    for T in (9, 40, 226):
+        ctx, mem = torch.arange(T)[:, None], torch.arange(T)[None, :]
+        assert torch.equal(t5.position_buckets(T), t5_ref.relative_position_bucket(mem - ctx))
+    b = t5.position_buckets(226)
+    assert int(b.min()) == 0 and int(b.max()) == 31 and int(b[0, 225]) == 31 and int(b[225, 0]) == 15
