@@ -1781,7 +1781,7 @@ extern "C" int s2v_set_gemm_impl(int impl) { g_gemm_impl = impl & 0xff; g_gemm_a
 // the last tile is at least half full (N = 1920 / 5760 of the 2B model); narrower outputs go to the 128-column kernels
 static bool w_tile_ok(const GemmArgs& a) {
     if (a.N % WBN == 0) return true;
-    return a.w_rows_padded >= ((a.N + WBN - 1) / WBN) * WBN && (a.N % WBN) >= WBN / 2;
+    return a.N > WBN && a.w_rows_padded >= ((a.N + WBN - 1) / WBN) * WBN && (a.N % WBN) >= WBN / 2;
 }
 
 int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
