@@ -7,6 +7,9 @@
 //                    16-B slots; double buffered; XCD-aware + grouped tile order for L2 reuse.
 //                    MFMA is issued "swapped" (first operand = weight rows) so each lane owns 4 consecutive
 //                    output columns of one token row -> 8-byte stores and lane-local bias/gate epilogue.
+//  gemm_bf16_stag  : 256x128x64 tile, three-stage LDS-DMA ring, two wave groups half a k-step apart (N not fitting 256-column tiles)
+//  gemm_bf16_w8    : 256x256 tile, K32 half-steps, four-stage ring, lock-step (reference schedule of the race-screen test)
+//  gemm_bf16_pp64  : 256x256x64 tile, ping-pong of the two waves of a SIMD, saddr-form LDS-DMA -- the default
 //  gemm_simple<T>  : LDS-tiled VALU kernel for fp32 (the CPU-reference-parity mode) and odd shapes.
 #define S2V_HOST
 #include "common.h"
@@ -312,126 +315,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int ti
 }
 
 // ---------------------------------------------------------------------------------------------------
-// gemm_bf16_ring: 256(M) x 128(N) x 64 block tile, 8 waves (4 x 2, 64x64 each), THREE LDS stages (3 x 48 KiB) filled by
-// global_load_lds two k-steps ahead.  One raw s_barrier per k-step; the loads of tile t+2 stay in flight across it:
-// each wave waits only for its own tile-(t+1) loads with a counted s_waitcnt vmcnt(6) (6 LDS-DMA per thread per tile)
-// before the barrier that publishes them (cdna_hip_programming.md section 5 "Pipelining across barriers").
-//   RAW: tile t+1 is read after { every wave's vmcnt(6) ; barrier(t+1) }.
-//   WAR: tile t+2 overwrites stage (t-1)%3, whose last ds_reads completed before each wave arrived at barrier(t).
+// 256(M) x 128(N) x 64 block tile, 8 waves (4 x 2, 64x64 each), THREE LDS stages (3 x 48 KiB) filled by global_load_lds two
+// k-steps ahead, counted s_waitcnt vmcnt(6): the tile of gemm_bf16_stag below (its lock-step predecessor was removed).
 #define RBM 256
 #define RBN 128
 #define RA_BYTES (RBM * BK * 2)   // 32 KiB
 #define RW_BYTES (RBN * BK * 2)   // 16 KiB
 #define RSTAGE (RA_BYTES + RW_BYTES)
-
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_ring(const GemmArgs a, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int GM = 4;  // 4 x 256 rows per group: same 1024-row x all-columns sweep as the 128-tile kernel
-    const int per_group = GM * tiles_n;
-    const int group = wg / per_group;
-    const int first_m = group * GM;
-    const int gsz = min(tiles_m - first_m, GM);
-    const int in_g = wg - group * per_group;
-    const int m0 = (first_m + in_g % gsz) * RBM, n0 = (in_g / gsz) * RBN;
-
-    const bf16_t* A = (const bf16_t*)a.A;
-    const bf16_t* W = (const bf16_t*)a.W;
-
-    // per-thread staging assignments: A tile 2048 chunks (4 per thread), W tile 1024 chunks (2 per thread)
-    int64_t rbA[4], rbW[2];
-    int cA[4], cW[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int gi = i * 512 + tid, row = gi >> 3;
-        rbA[i] = a_row_base(a, m0 + row);
-        cA[i] = ((gi & 7) ^ ((row >> 1) & 7)) * 8;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int gi = i * 512 + tid, row = gi >> 3;
-        rbW[i] = (int64_t)(n0 + row) * a.ldw;
-        cW[i] = ((gi & 7) ^ ((row >> 1) & 7)) * 8;
-    }
-    auto stage = [&](int t, int s) {
-        char* base = smem + s * RSTAGE;
-        const int64_t ka = a_k_off(a, t * BK);
-        const int kw = t * BK;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            char* dst = base + (i * 512 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + rbA[i] + ka + cA[i]),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            char* dst = base + RA_BYTES + (i * 512 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + rbW[i] + kw + cW[i]),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nt = a.K / BK;
-    stage(0, 0);
-    if (nt > 1) stage(1, 1);
-    const int fr = lane & 31, hi = lane >> 5;
-    for (int t = 0; t < nt; ++t) {
-        // tile t must have landed: everything except the most recent tile's 6 loads
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt && !(a.ablate & 1)) stage(t + 2, (t + 2) % 3);
-        if (a.ablate & 2) continue;
-        const char* tA = smem + (t % 3) * RSTAGE;
-        const char* tW = tA + RA_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            bf16x8 wf[2], af[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) wf[i] = lds_frag(tW, wn * 64 + i * 32 + fr, kk * 2 + hi);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) af[j] = lds_frag(tA, wm * 64 + j * 32 + fr, kk * 2 + hi);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    if (epi_vec_ok(a, EPI)) {
-        __builtin_amdgcn_s_barrier();  // every wave has consumed the last operand stage
-        epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = m0 + wm * 64 + j * 32 + fr;
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
-                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
-                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
-            }
-        }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // gemm_bf16_stag: same 256x128x64 tile / 3-stage LDS-DMA ring, but the two wave groups (waves 0-3 / 4-7, one wave of
@@ -586,401 +476,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_stag(const GemmArgs a, int t
 }
 
 // ---------------------------------------------------------------------------------------------------
-// gemm_bf16_r32: 256 x 128 tile, BK = 32, three 24-KiB LDS stages (72 KiB) so that TWO workgroups (16 waves) share a
-// CU: one block's prologue / epilogue / barrier stalls are covered by the other block's k-loop.  LDS rows are 64 B;
-// 16-B chunk index is XOR-ed with (row>>2)&3, which makes every ds_read_b128 lane-group of the 32x32x16 fragment
-// read hit 16 distinct slots.  3 LDS-DMA per thread per k-step, counted vmcnt(3), one raw barrier per k-step.
+// 256 x 256 block tiles (gemm_bf16_w8, gemm_bf16_pp64).  A four-wave 128 x 128-wave-tile form, a ping-pong on K32 stages and a
+// sixteen-wave ping-pong were measured and removed.
+#define WBM 256
+#define WBN 256
 #define K32 32
-#define R32_A (RBM * K32 * 2)  // 16 KiB
-#define R32_W (RBN * K32 * 2)  // 8 KiB
-#define R32_STAGE (R32_A + R32_W)
-
+#define WH_A (WBM * K32 * 2)   // 16 KiB
+#define WH_STAGE (2 * WH_A)    // 32 KiB
+#define WH_NST 4
+// fragment read of a K32 stage (rows of 64 B: 4 chunks of 16 B, chunk ^= (row >> 2) & 3 on the DMA source and here)
 __device__ __forceinline__ bf16x8 lds_frag32(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + row * 64 + ((cl ^ ((row >> 2) & 3)) << 4));
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 4) void gemm_bf16_r32(const GemmArgs a, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int GM = 4;
-    const int per_group = GM * tiles_n;
-    const int group = wg / per_group;
-    const int first_m = group * GM;
-    const int gsz = min(tiles_m - first_m, GM);
-    const int in_g = wg - group * per_group;
-    const int m0 = (first_m + in_g % gsz) * RBM, n0 = (in_g / gsz) * RBN;
-
-    const bf16_t* A = (const bf16_t*)a.A;
-    const bf16_t* W = (const bf16_t*)a.W;
-    int64_t rbA[2], rbW;
-    int cA[2], cW;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int gi = i * 512 + tid, row = gi >> 2;
-        rbA[i] = a_row_base(a, m0 + row);
-        cA[i] = ((gi & 3) ^ ((row >> 2) & 3)) * 8;
-    }
-    {
-        const int row = tid >> 2;
-        rbW = (int64_t)(n0 + row) * a.ldw;
-        cW = ((tid & 3) ^ ((row >> 2) & 3)) * 8;
-    }
-    auto stage = [&](int t, int s) {
-        char* base = smem + s * R32_STAGE;
-        const int64_t ka = a_k_off(a, t * K32);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            char* dst = base + (i * 512 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + rbA[i] + ka + cA[i]),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-        char* dst = base + R32_A + (wave * 64) * 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + rbW + t * K32 + cW),
-                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nt = a.K / K32;
-    stage(0, 0);
-    if (nt > 1) stage(1, 1);
-    const int fr = lane & 31, hi = lane >> 5;
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (t + 2 < nt) stage(t + 2, (t + 2) % 3);
-        const char* tA = smem + (t % 3) * R32_STAGE;
-        const char* tW = tA + R32_A;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 wf[2], af[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) wf[i] = lds_frag32(tW, wn * 64 + i * 32 + fr, kk * 2 + hi);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) af[j] = lds_frag32(tA, wm * 64 + j * 32 + fr, kk * 2 + hi);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
-        }
-    }
-
-    if (epi_vec_ok(a, EPI)) {
-        __builtin_amdgcn_s_barrier();
-        epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = m0 + wm * 64 + j * 32 + fr;
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
-                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
-                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
-            }
-        }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// gemm_bf16_w128: 256 x 256 x 64 block tile, FOUR waves (2 x 2), one wave per SIMD, each wave owns a 128 x 128 output
-// tile = 4 x 4 MFMA 32x32 blocks = 256 accumulator registers of the unified 512-register file.  Per 32-cycle MFMA the
-// wave reads half an operand fragment from LDS (vs one with 64 x 64 wave tiles) and the block stages 2/3 of the bytes
-// per flop, which is what the LDS-DMA / ds_read contention of the smaller tiles was costing.  Two 64-KiB LDS stages:
-//   barrier -> DMA(t+1) -> 64 MFMA on stage t (fragment reads of k-slice kk+1 issued ahead of the MFMAs of kk)
-//           -> s_waitcnt vmcnt(0) -> barrier.
-#define WBM 256
-#define WBN 256
-#define W_A_BYTES (WBM * BK * 2)  // 32 KiB
-#define W_STAGE (2 * W_A_BYTES)   // 64 KiB
-
-template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm_bf16_w128_v1(const GemmArgs a, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int GM = 4;
-    const int per_group = GM * tiles_n;
-    const int group = wg / per_group;
-    const int first_m = group * GM;
-    const int gsz = min(tiles_m - first_m, GM);
-    const int in_g = wg - group * per_group;
-    const int m0 = (first_m + in_g % gsz) * WBM, n0 = (in_g / gsz) * WBN;
-
-    const bf16_t* A = (const bf16_t*)a.A;
-    const bf16_t* W = (const bf16_t*)a.W;
-    // staging: 2048 16-B chunks per operand per k-step, 8 per thread
-    int64_t rbA[8], rbW[8];
-    int cc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int gi = i * 256 + tid, row = gi >> 3;
-        rbA[i] = a_row_base(a, m0 + row);
-        rbW[i] = (int64_t)(n0 + row) * a.ldw;
-        cc[i] = ((gi & 7) ^ ((row >> 1) & 7)) * 8;
-    }
-    auto stage = [&](int t, int s) {
-        char* base = smem + s * W_STAGE;
-        const int64_t ka = a_k_off(a, t * BK);
-        const int kw = t * BK;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            char* dst = base + (i * 256 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + rbA[i] + ka + cc[i]),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            char* dst = base + W_A_BYTES + (i * 256 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + rbW[i] + kw + cc[i]),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nt = a.K / BK;
-    const int fr = lane & 31, hi = lane >> 5;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int t = 0; t < nt; ++t) {
-        if (t + 1 < nt) stage(t + 1, (t + 1) & 1);
-        const char* tA = smem + (t & 1) * W_STAGE;
-        const char* tW = tA + W_A_BYTES;
-        bf16x8 wf[2][4], af[2][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            wf[0][i] = lds_frag(tW, wn * 128 + i * 32 + fr, hi);
-            af[0][i] = lds_frag(tA, wm * 128 + i * 32 + fr, hi);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk + 1 < 4) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    wf[nxt][i] = lds_frag(tW, wn * 128 + i * 32 + fr, (kk + 1) * 2 + hi);
-                    af[nxt][i] = lds_frag(tA, wm * 128 + i * 32 + fr, (kk + 1) * 2 + hi);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], af[cur][j], acc[i][j], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-
-    // epilogue: four 64 x 64 quadrants through the wave's 8 KiB LDS patch (the k-loop ended with a barrier)
-    char* patch = smem + wave * 8192;
-    if (epi_vec_ok(a, EPI)) {
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-            for (int qj = 0; qj < 2; ++qj) {
-                f32x16 sub[2][2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) sub[i][j] = acc[qi * 2 + i][qj * 2 + j];
-                epilogue_wave64<EPI>(a, sub, m0 + wm * 128 + qj * 64, n0 + wn * 128 + qi * 64, patch, lane);
-            }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 128 + j * 32 + fr;
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int n = n0 + wn * 128 + i * 32 + 8 * rq + 4 * hi;
-                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
-                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
-            }
-        }
-}
-
-// gemm_bf16_w128 (v2): same 256 x 256 block / four waves / 128 x 128 wave tiles, but the k-loop advances in HALF steps of
-// 32 with FOUR 32-KiB LDS stages (rows of 64 B, lds_frag32 swizzle): the LDS-DMA of half-tile h+3 is issued while
-// half-tile h is computed (3 half-steps = 3 x 32 MFMA of lead instead of 1 k-step), its 8 instructions are spread
-// between the MFMA groups instead of a burst in front of them, and the wait at the top of a half-step is the counted
-// vmcnt that leaves the two newest half-tiles in flight across the barrier.
-#define WH_A (WBM * K32 * 2)   // 16 KiB
-#define WH_STAGE (2 * WH_A)    // 32 KiB
-#define WH_NST 4
-
-// ABL (diagnostics, compile-time so the shipped ABL = 0 code is untouched): 1 = no DMA wait, 2 = no LDS-DMA,
-// 3 = no fragment reads, 4 = no MFMA, 5 = no barrier in the k-loop
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(256, 1) void gemm_bf16_w128(const GemmArgs a, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int GM = 4;
-    const int per_group = GM * tiles_n;
-    const int group = wg / per_group;
-    const int first_m = group * GM;
-    const int gsz = min(tiles_m - first_m, GM);
-    const int in_g = wg - group * per_group;
-    const int m0 = (first_m + in_g % gsz) * WBM, n0 = (in_g / gsz) * WBN;
-
-    // staging: per half-step 1024 16-B chunks per operand (256 rows x 4 chunks), 4 per thread:
-    // chunk gi = i*256 + tid -> row = gi>>2 = i*64 + (tid>>2), physical chunk = tid&3, source chunk = phys ^ ((row>>2)&3)
-    const int srow = tid >> 2;
-    const int scol = ((tid & 3) ^ ((srow >> 2) & 3)) * 8;  // (row>>2)&3 does not depend on i (i*64 >> 2 = 16 i)
-    // saddr-form LDS-DMA: wave-uniform half-tile base + loop-invariant 32-bit lane offsets
-    const int64_t rbase0 = a_row_base(a, m0);
-    const char* Abase = (const char*)a.A + 2 * rbase0;
-    const char* Wbase = (const char*)a.W + 2 * (int64_t)n0 * a.ldw;
-    unsigned offA[4], offW[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        offA[i] = (unsigned)(2 * (a_row_base(a, m0 + srow + i * 64) - rbase0 + scol));
-        offW[i] = (unsigned)(2 * ((int64_t)(srow + i * 64) * a.ldw + scol));
-    }
-    int64_t ka_cur = 0;  // A-operand displacement of the half-tile being staged (one evaluation per half-step)
-    auto glds_one = [&](int h, int s, int idx8) {  // idx8 0..3 -> A piece, 4..7 -> W piece
-        char* base = smem + s * WH_STAGE;
-        const int i = idx8 & 3;
-        if (idx8 < 4) glds16_saddr(Abase + 2 * ka_cur, offA[i], base + (i * 256 + wave * 64) * 16);
-        else glds16_saddr(Wbase + 2 * (int64_t)h * K32, offW[i], base + WH_A + (i * 256 + wave * 64) * 16);
-    };
-
-    f32x16 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int nh = a.K / K32;
-    const int fr = lane & 31, hi = lane >> 5;
-    // Pipeline (half-tile t lives in LDS stage t & 3):
-    //   during half-step h the wave issues, between its 32 MFMA on the fragments of half-tile h (already in VGPRs):
-    //     - the 16 ds_read_b128 of half-tile h+1 (published by the barrier at the top of h) into the other fragment set,
-    //     - the 8 LDS-DMA of half-tile h+4 into stage h & 3 (free: every wave finished reading it before that barrier).
-    //   top of half-step h: s_waitcnt vmcnt(16) => half-tiles <= h+1 landed (h+2, h+3 stay in flight), lgkmcnt(0) =>
-    //   this wave's reads of stage h & 3 are done, then ONE barrier.
-    // The loop body is branch-free (a conditional LDS-DMA or read splits the basic block and the register allocator
-    // then spills the fragment sets): past the end of K the DMA re-loads the last half-tile into a free stage and the
-    // reads fetch fragments that are never used, so every half-step issues exactly 8 LDS-DMA and vmcnt(16) is constant.
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const int tp = min(p, nh - 1);
-        ka_cur = a.conv ? a_k_off(a, tp * K32) : (int64_t)tp * K32;
-#pragma unroll
-        for (int g8 = 0; g8 < 8; ++g8) glds_one(tp, p, g8);
-    }
-    asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    bf16x8 wfA[2][4], afA[2][4], wfB[2][4], afB[2][4];
-    auto read_frags = [&](int t, bf16x8 (&wf)[2][4], bf16x8 (&af)[2][4], int kk, int i) {
-        const char* tA = smem + (t & 3) * WH_STAGE;
-        const char* tW = tA + WH_A;
-        wf[kk][i] = lds_frag32(tW, wn * 128 + i * 32 + fr, kk * 2 + hi);
-        af[kk][i] = lds_frag32(tA, wm * 128 + i * 32 + fr, kk * 2 + hi);
-    };
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) read_frags(0, wfA, afA, kk, i);
-
-    auto half_step = [&](int h, bf16x8 (&wf)[2][4], bf16x8 (&af)[2][4], bf16x8 (&wfn)[2][4], bf16x8 (&afn)[2][4]) {
-        if (ABL == 1 || ABL == 2) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)" ::: "memory");
-        if (ABL != 5) __builtin_amdgcn_s_barrier();
-        const int tl = min(h + 4, nh - 1);
-        ka_cur = a.conv ? a_k_off(a, tl * K32) : (int64_t)tl * K32;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (ABL != 3) read_frags(h + 1, wfn, afn, kk, i);
-                if (ABL != 2) glds_one(tl, h & 3, kk * 4 + i);
-                if (ABL != 4) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
-                }
-            }
-    };
-    for (int h = 0; h < nh; h += 2) {  // nh = K/32 is even (K % 64 == 0)
-        half_step(h, wfA, afA, wfB, afB);
-        half_step(h + 1, wfB, afB, wfA, afA);
-    }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // all waves are done with the operand stages before the epilogue patches reuse them
-
-    char* patch = smem + wave * 8192;
-    if (epi_vec_ok(a, EPI)) {
-#pragma unroll
-        for (int qi = 0; qi < 2; ++qi)
-#pragma unroll
-            for (int qj = 0; qj < 2; ++qj) {
-                f32x16 sub[2][2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) sub[i][j] = acc[qi * 2 + i][qj * 2 + j];
-                epilogue_wave64<EPI>(a, sub, m0 + wm * 128 + qj * 64, n0 + wn * 128 + qi * 64, patch, lane);
-            }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 128 + j * 32 + fr;
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int n = n0 + wn * 128 + i * 32 + 8 * rq + 4 * hi;
-                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
-                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
-            }
-        }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // gemm_bf16_w8: the same 256 x 256 block tile, BK32 half-steps, four-stage LDS-DMA ring and fragment register
-// prefetch as gemm_bf16_w128, but EIGHT waves (2 x 4) of 128(m) x 64(n) wave tiles = two waves per SIMD.  A wave that is
+// prefetch of the removed four-wave form, with EIGHT waves (2 x 4) of 128(m) x 64(n) wave tiles = two waves per SIMD.  A wave that is
 // stuck issuing an LDS-DMA piece (60-180 cycles each, per MI355X_MICROARCH.md) no longer idles the matrix pipe: its
 // SIMD partner issues MFMAs meanwhile.  Per half-step and wave: 16 MFMA 32x32x16, 12 ds_read_b128 (next half-tile),
 // 4 LDS-DMA pieces (half-tile h+4); counted vmcnt(8) keeps two half-tiles in flight across the single barrier.
@@ -1109,171 +620,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_w8(const GemmArgs a, int til
                 if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
             }
         }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// gemm_bf16_pp: gemm_bf16_w8's tile / wave layout / LDS ring, re-timed as a PING-PONG of the two waves that share a SIMD.
-// Waves 0-3 (group 0, wm = 0) and 4-7 (group 1, wm = 1) run one barrier interval apart; a half-step (K = 32) of a wave is
-//     LOAD segment   : 12 ds_read_b128 (its fragments of half-tile k) + 4 LDS-DMA pieces of a later half-tile
-//     s_barrier
-//     COMPUTE segment: s_setprio 1, 16 MFMA 32x32x16, s_setprio 0
-//     s_barrier
-// so in every barrier interval one wave of each SIMD streams MFMAs while its partner does the LDS / DMA work for its own
-// next cluster: a wave stalled on an ds_read or LDS-DMA issue never holds the matrix pipe's instruction stream.
-// Interval numbering (I_n = n-th barrier interval): group 0 loads half-tile k in I_2k and computes in I_2k+1; group 1 loads
-// in I_2k+1 and computes in I_2k+2.  Ring of four 32-KiB stages, half-tile j in stage j & 3:
-//   RAW  half-tile j must be in LDS when I_2j starts: group 0 waits vmcnt(4) at the end of compute(j-1) (it has issued up
-//        to DMA(j+1)); group 1 waits vmcnt(8) at the end of load(j-1) (issued up to DMA(j+2)); both inside I_2j-1.
-//   WAR  stage j & 3 is last read by group 1 in I_2j+1, whose lgkmcnt(0) sits after the barrier that opens I_2j+2; the DMA
-//        of half-tile j+4 is issued in I_2j+3 (group 1, load(j+1): DMA(k+3)) and I_2j+4 (group 0, load(j+2): DMA(k+2)).
-// Past the end of K the DMA re-loads the last half-tile into the stage it would have used (never read again), so the
-// counts stay constant.  Group 1 executes one extra barrier before its loop, group 0 one after.
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_pp(const GemmArgs a, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int g = wm;  // ping-pong group
-
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int GM = 4;
-    const int per_group = GM * tiles_n;
-    const int group = wg / per_group;
-    const int first_m = group * GM;
-    const int gsz = min(tiles_m - first_m, GM);
-    const int in_g = wg - group * per_group;
-    const int m0 = (first_m + in_g % gsz) * WBM, n0 = (in_g / gsz) * WBN;
-
-    const int srow = tid >> 2;
-    const int scol = ((tid & 3) ^ ((srow >> 2) & 3)) * 8;
-    const bf16_t* pA = (const bf16_t*)a.A + a_row_base(a, m0 + srow) + scol;
-    const bf16_t* pW = (const bf16_t*)a.W + (int64_t)(n0 + srow) * a.ldw + scol;
-    const int dA1 = (int)(a_row_base(a, m0 + srow + 128) - a_row_base(a, m0 + srow));
-    const int64_t dW1 = (int64_t)128 * a.ldw;
-    const int nh = a.K / K32;
-    auto dma = [&](int t) {  // the thread's 4 pieces of half-tile min(t, nh-1) into stage t & 3
-        const int tc = min(t, nh - 1);
-        const int64_t ka = a.conv ? a_k_off(a, tc * K32) : (int64_t)tc * K32;
-        char* base = smem + (t & 3) * WH_STAGE + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pA + i * dA1 + ka),
-                                             (__attribute__((address_space(3))) void*)(base + i * 8192), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pW + i * dW1 + tc * K32),
-                                             (__attribute__((address_space(3))) void*)(base + WH_A + i * 8192), 16, 0, 0);
-        }
-    };
-
-    f32x16 acc[2][4];  // [n block][m block]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int fr = lane & 31, hi = lane >> 5;
-    dma(0);
-    dma(1);
-    if (g) {
-        dma(2);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    }
-    __builtin_amdgcn_s_barrier();  // opens I_0
-    if (g) __builtin_amdgcn_s_barrier();  // group 1 idles through I_0
-
-    bf16x8 wf[2][2], af[2][4];
-    for (int k = 0; k < nh; ++k) {
-        // ---- LOAD segment
-        const char* tA = smem + (k & 3) * WH_STAGE;
-        const char* tW = tA + WH_A;
-        if (ABL != 2 || k == 0) {
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) wf[kk][i] = lds_frag32(tW, wn * 64 + i * 32 + fr, kk * 2 + hi);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) af[kk][j] = lds_frag32(tA, wm * 128 + j * 32 + fr, kk * 2 + hi);
-            }
-        }
-        if (ABL != 1) {
-            dma(k + 2 + g);
-            if (g) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        // ---- COMPUTE segment
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (ABL != 3) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
-                    else asm volatile("" ::"v"(wf[kk][i]), "v"(af[kk][j]));
-                }
-        __builtin_amdgcn_s_setprio(0);
-        if (!g && ABL != 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-    }
-    if (!g) __builtin_amdgcn_s_barrier();  // pairs with group 1's last compute segment
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    char* patch = smem + wave * 8192;
-    if (epi_vec_ok(a, EPI)) {
-#pragma unroll
-        for (int qj = 0; qj < 2; ++qj) {
-            f32x16 sub[2][2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) sub[i][j] = acc[i][qj * 2 + j];
-            epilogue_wave64<EPI>(a, sub, m0 + wm * 128 + qj * 64, n0 + wn * 64, patch, lane);
-        }
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + wm * 128 + j * 32 + fr;
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
-                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
-                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
-            }
-        }
-}
-
-template <int EPI>
-static int launch_pp_t(const GemmArgs& a, hipStream_t st) {
-    const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WH_NST * WH_STAGE));
-        attr_set = true;
-    }
-    if (EPI == EPI_BIAS && a.ablate) {  // diagnostics only (tools/ablate_gemm.py)
-        const void* fn = a.ablate == 1 ? (const void*)gemm_bf16_pp<EPI_BIAS, 1> : a.ablate == 2 ? (const void*)gemm_bf16_pp<EPI_BIAS, 2> : (const void*)gemm_bf16_pp<EPI_BIAS, 3>;
-        S2V_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WH_NST * WH_STAGE));
-        void* args[] = {(void*)&a, (void*)&tiles_m, (void*)&tiles_n};
-        S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(tiles_m * tiles_n), dim3(512), args, WH_NST * WH_STAGE, st));
-        return 0;
-    }
-    hipLaunchKernelGGL(gemm_bf16_pp<EPI>, dim3(tiles_m * tiles_n), dim3(512), WH_NST * WH_STAGE, st, a, tiles_m, tiles_n);
-    S2V_CHECK_HIP(hipGetLastError());
-    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1497,202 +843,6 @@ static int launch_pp64_t(const GemmArgs& a, hipStream_t st) {
     return 0;
 }
 
-// ---------------------------------------------------------------------------------------------------
-// gemm_bf16_pp16: gemm_bf16_pp64's tile, LDS image and barrier-interval schedule with SIXTEEN waves (4 x 4 wave tiles of
-// 64 x 64, 4 waves per SIMD, <= 128 VGPRs).  Measured on pp64 (s_memtime): one LDS-DMA piece costs the issuing wave ~120
-// cycles and one ds_read_b128 ~15, so an 8-wave half-step needs 180 + 480 cycles of load segment per wave against the
-// 512 MFMA cycles of its SIMD partner, and the computing wave waits ~200 cycles per half-step at the barrier.  Per-wave DMA
-// issue is serial, CU throughput comes from the number of waves issuing.  With 16 waves a load segment is 8 reads + 2
-// pieces (~360 cycles) while the SIMD's other two waves issue 2 x 8 MFMA = 512 cycles.
-// Groups: waves 0-7 (A rows 0-127; stage A-lo, W-lo) and waves 8-15 (A rows 128-255; stage A-hi, W-hi); waves w, w+4, w+8,
-// w+12 share a SIMD, i.e. two of each group.  Interval numbering, RAW / WAR argument: see gemm_bf16_pp64.
-template <int EPI, int ABL = 0>
-__global__ __launch_bounds__(1024) void gemm_bf16_pp16(const GemmArgs a, int tiles_m, int tiles_n) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = wave >> 3, r8 = wave & 7;
-    const int wm = g * 2 + (r8 >> 2), wn = r8 & 3;
-
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int GM = 4;
-    const int per_group = GM * tiles_n;
-    const int group = wg / per_group;
-    const int first_m = group * GM;
-    const int gsz = min(tiles_m - first_m, GM);
-    const int in_g = wg - group * per_group;
-    const int m0 = (first_m + in_g % gsz) * WBM, n0 = (in_g / gsz) * WBN;
-
-    // staging: piece i (0..1) of this wave covers rows g*128 + i*64 + r8*8 + (lane>>3), 8 chunks of 16 B each
-    const int srow = g * 128 + r8 * 8 + (lane >> 3);
-    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) * 8;
-    const int64_t rbase0 = a_row_base(a, m0);
-    const char* Abase = (const char*)a.A + 2 * rbase0;
-    const char* Wbase = (const char*)a.W + 2 * (int64_t)n0 * a.ldw;
-    unsigned offA[2], offW[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        offA[i] = (unsigned)(2 * (a_row_base(a, m0 + srow + i * 64) - rbase0 + scol));
-        offW[i] = (unsigned)(2 * ((int64_t)(srow + i * 64) * a.ldw + scol));
-    }
-    const int nT = a.K / BK;
-    const int ldst = (g * 128 + r8 * 8) * 128;
-    auto dma_a = [&](int t) {
-        const int tc = min(t, nT - 1);
-        const int64_t ka = a.conv ? a_k_off(a, tc * BK) : (int64_t)tc * BK;
-        const char* tb = Abase + 2 * ka;
-        char* base = smem + (t & 1) * 65536 + ldst;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16_saddr(tb, offA[i], base + i * 8192);
-    };
-    auto dma_w = [&](int t) {
-        const int tc = min(t, nT - 1);
-        const char* tb = Wbase + 2 * (int64_t)tc * BK;
-        char* base = smem + (t & 1) * 65536 + 32768 + ldst;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) glds16_saddr(tb, offW[i], base + i * 8192);
-    };
-
-    f32x16 acc[2][2];  // [n block][m block]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    const int fr = lane & 31, hi = lane >> 5;
-    dma_a(0);
-    dma_w(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // opens I_0
-    if (g) __builtin_amdgcn_s_barrier();  // group 1 idles through I_0
-
-    bf16x8 wf[2][2], af[2][2];
-    auto reads = [&](int t, int s) {
-        const char* tA = smem + (t & 1) * 65536;
-        const char* tW = tA + 32768;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) wf[kk][i] = lds_frag(tW, wn * 64 + i * 32 + fr, s * 4 + kk * 2 + hi);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) af[kk][j] = lds_frag(tA, wm * 64 + j * 32 + fr, s * 4 + kk * 2 + hi);
-        }
-    };
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto now = [&]() -> long long { return ABL == 4 ? (long long)__builtin_amdgcn_s_memtime() : 0; };
-    auto cluster = [&](bool tile_end) {
-        __builtin_amdgcn_sched_barrier(0);
-        const long long t0 = now();
-        __builtin_amdgcn_s_barrier();
-        const long long t1 = now();
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const long long t2 = now();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        __builtin_amdgcn_sched_barrier(0);
-        const long long t3 = now();
-        if (tile_end) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const long long t4 = now();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_barrier();
-        const long long t5 = now();
-        if (ABL == 4) {
-            tacc[0] += t1 - t0;
-            tacc[1] += t2 - t1;
-            tacc[2] += t3 - t2;
-            tacc[3] += t4 - t3;
-            tacc[4] += t5 - t4;
-        }
-    };
-    const long long tl0 = now();
-    for (int t = 0; t < nT; ++t) {
-        const long long u0 = now();
-        reads(t, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        const long long u1 = now();
-        if (g) dma_w(t + 1);
-        else dma_a(t + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const long long u2 = now();
-        cluster(false);
-        const long long u3 = now();
-        reads(t, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        const long long u4 = now();
-        if (g) {
-            dma_a(t + 1);
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            dma_w(t + 1);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const long long u5 = now();
-        cluster(true);
-        if (ABL == 4) {
-            tacc[6] += (u1 - u0) + (u4 - u3);
-            tacc[7] += (u2 - u1) + (u5 - u4);
-        }
-    }
-    if (ABL == 4) {
-        tacc[5] = now() - tl0;
-        if (blockIdx.x == 100 && lane == 0 && (wave & 1) == 0)
-            for (int e = 0; e < 8; ++e) g_pp_dbg[(wave >> 1) * 8 + e] = tacc[e];
-    }
-    if (!g) __builtin_amdgcn_s_barrier();  // pairs with group 1's last compute segment
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    char* patch = smem + wave * 8192;
-    if (epi_vec_ok(a, EPI)) {
-        epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, patch, lane);
-        return;
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int m = m0 + wm * 64 + j * 32 + fr;
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
-                float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
-                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
-            }
-        }
-}
-
-template <int EPI>
-static int launch_pp16_t(const GemmArgs& a, hipStream_t st) {
-    const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp16<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        attr_set = true;
-    }
-    if (EPI == EPI_BIAS && a.ablate) {  // diagnostics only
-        const void* fn = (const void*)gemm_bf16_pp16<EPI_BIAS, 4>;
-        S2V_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        void* args[] = {(void*)&a, (void*)&tiles_m, (void*)&tiles_n};
-        S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(tiles_m * tiles_n), dim3(1024), args, 131072, st));
-        return 0;
-    }
-    hipLaunchKernelGGL(gemm_bf16_pp16<EPI>, dim3(tiles_m * tiles_n), dim3(1024), 131072, st, a, tiles_m, tiles_n);
-    S2V_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 template <int EPI>
 static int launch_w8_t(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
@@ -1702,46 +852,6 @@ static int launch_w8_t(const GemmArgs& a, hipStream_t st) {
         attr_set = true;
     }
     hipLaunchKernelGGL(gemm_bf16_w8<EPI>, dim3(tiles_m * tiles_n), dim3(512), WH_NST * WH_STAGE, st, a, tiles_m, tiles_n);
-    S2V_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-template <int EPI>
-static int launch_w128_t(const GemmArgs& a, hipStream_t st) {
-    const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w128<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WH_NST * WH_STAGE));
-        attr_set = true;
-    }
-    if (EPI == EPI_BIAS && a.ablate) {  // diagnostics only
-        const void* fn = nullptr;
-        switch (a.ablate) {
-            case 1: fn = (const void*)gemm_bf16_w128<EPI_BIAS, 1>; break;
-            case 2: fn = (const void*)gemm_bf16_w128<EPI_BIAS, 2>; break;
-            case 3: fn = (const void*)gemm_bf16_w128<EPI_BIAS, 3>; break;
-            case 4: fn = (const void*)gemm_bf16_w128<EPI_BIAS, 4>; break;
-            default: fn = (const void*)gemm_bf16_w128<EPI_BIAS, 5>; break;
-        }
-        S2V_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, WH_NST * WH_STAGE));
-        void* args[] = {(void*)&a, (void*)&tiles_m, (void*)&tiles_n};
-        S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(tiles_m * tiles_n), dim3(256), args, WH_NST * WH_STAGE, st));
-        return 0;
-    }
-    hipLaunchKernelGGL(gemm_bf16_w128<EPI>, dim3(tiles_m * tiles_n), dim3(256), WH_NST * WH_STAGE, st, a, tiles_m, tiles_n);
-    S2V_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-template <int EPI>
-static int launch_r32_t(const GemmArgs& a, hipStream_t st) {
-    const int tiles_m = (a.M + RBM - 1) / RBM, tiles_n = (a.N + RBN - 1) / RBN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_r32<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * R32_STAGE));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_bf16_r32<EPI>, dim3(tiles_m * tiles_n), dim3(512), 3 * R32_STAGE, st, a, tiles_m, tiles_n);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1759,22 +869,9 @@ static int launch_stag_t(const GemmArgs& a, hipStream_t st) {
     return 0;
 }
 
-template <int EPI>
-static int launch_ring_t(const GemmArgs& a, hipStream_t st) {
-    const int tiles_m = (a.M + RBM - 1) / RBM, tiles_n = (a.N + RBN - 1) / RBN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_ring<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * RSTAGE));
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_bf16_ring<EPI>, dim3(tiles_m * tiles_n), dim3(512), 3 * RSTAGE, st, a, tiles_m, tiles_n);
-    S2V_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
-int g_gemm_ablate = 0;  // diagnostics only (ring kernel): bit0 = no LDS-DMA in the k-loop, bit1 = no ds_read/MFMA
-int g_gemm_impl = 7;  // 7 = 256x256x64 eight-wave ping-pong (default), 8 = its 16-wave form, 6 = ping-pong on K32 stages, 5 = 256x256 eight-wave lock-step, 4 = 256x256 four-wave (both fall back to 2 when N % 256 != 0), 3 = BK32 two-block, 2 = staggered
-                      // 256x128 ring, 1 = lock-step 256x128 ring, 0 = 128x128 double-buffer kernel
+int g_gemm_ablate = 0;  // diagnostics only (tools/ablate_gemm.py, tools/stall_pp64.py): compile-time ablations of gemm_bf16_pp64
+int g_gemm_impl = 7;  // 7 = 256x256x64 eight-wave ping-pong (default), 5 = 256x256 eight-wave lock-step ring, 2 = staggered 256x128 ring,
+                      // 0 = 128x128 double buffer; 5 and 7 fall back to 2 (then 0) when the shape does not fit their tiles
 extern "C" int s2v_set_gemm_impl(int impl) { g_gemm_impl = impl & 0xff; g_gemm_ablate = impl >> 8; return 0; }
 
 // the 256-column kernels take N that is not a multiple of 256 when the weight buffer physically holds the padded rows and
@@ -1803,16 +900,6 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
         return 0;
     }
     S2V_REQUIRE(a.K % BK == 0, "gemm_bf16: K must be a multiple of 64");
-    if (g_gemm_impl == 8 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
-        S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
-        switch (epi) {
-            case EPI_BIAS: return launch_pp16_t<EPI_BIAS>(a, st);
-            case EPI_BIAS_GELU: return launch_pp16_t<EPI_BIAS_GELU>(a, st);
-            case EPI_BIAS_GATE_RES: return launch_pp16_t<EPI_BIAS_GATE_RES>(a, st);
-            case EPI_BIAS_ADD: return launch_pp16_t<EPI_BIAS_ADD>(a, st);
-            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
-        }
-    }
     if (g_gemm_impl == 7 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
@@ -1820,16 +907,6 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             case EPI_BIAS_GELU: return launch_pp64_t<EPI_BIAS_GELU>(a, st);
             case EPI_BIAS_GATE_RES: return launch_pp64_t<EPI_BIAS_GATE_RES>(a, st);
             case EPI_BIAS_ADD: return launch_pp64_t<EPI_BIAS_ADD>(a, st);
-            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
-        }
-    }
-    if (g_gemm_impl == 6 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
-        S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
-        switch (epi) {
-            case EPI_BIAS: return launch_pp_t<EPI_BIAS>(a, st);
-            case EPI_BIAS_GELU: return launch_pp_t<EPI_BIAS_GELU>(a, st);
-            case EPI_BIAS_GATE_RES: return launch_pp_t<EPI_BIAS_GATE_RES>(a, st);
-            case EPI_BIAS_ADD: return launch_pp_t<EPI_BIAS_ADD>(a, st);
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }
@@ -1843,26 +920,6 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }
-    if (g_gemm_impl == 4 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
-        S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
-        switch (epi) {
-            case EPI_BIAS: return launch_w128_t<EPI_BIAS>(a, st);
-            case EPI_BIAS_GELU: return launch_w128_t<EPI_BIAS_GELU>(a, st);
-            case EPI_BIAS_GATE_RES: return launch_w128_t<EPI_BIAS_GATE_RES>(a, st);
-            case EPI_BIAS_ADD: return launch_w128_t<EPI_BIAS_ADD>(a, st);
-            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
-        }
-    }
-    if (g_gemm_impl == 3 && a.K % K32 == 0 && (a.conv || a.a_rows_padded >= ((a.M + RBM - 1) / RBM) * RBM)) {
-        S2V_REQUIRE((a.conv ? a.cin % 32 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
-        switch (epi) {
-            case EPI_BIAS: return launch_r32_t<EPI_BIAS>(a, st);
-            case EPI_BIAS_GELU: return launch_r32_t<EPI_BIAS_GELU>(a, st);
-            case EPI_BIAS_GATE_RES: return launch_r32_t<EPI_BIAS_GATE_RES>(a, st);
-            case EPI_BIAS_ADD: return launch_r32_t<EPI_BIAS_ADD>(a, st);
-            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
-        }
-    }
     if ((g_gemm_impl == 2 || g_gemm_impl >= 4) && (a.conv || a.a_rows_padded >= ((a.M + RBM - 1) / RBM) * RBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
@@ -1870,16 +927,6 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             case EPI_BIAS_GELU: return launch_stag_t<EPI_BIAS_GELU>(a, st);
             case EPI_BIAS_GATE_RES: return launch_stag_t<EPI_BIAS_GATE_RES>(a, st);
             case EPI_BIAS_ADD: return launch_stag_t<EPI_BIAS_ADD>(a, st);
-            default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
-        }
-    }
-    if (g_gemm_impl == 1 && (a.conv || a.a_rows_padded >= ((a.M + RBM - 1) / RBM) * RBM)) {
-        S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
-        switch (epi) {
-            case EPI_BIAS: return launch_ring_t<EPI_BIAS>(a, st);
-            case EPI_BIAS_GELU: return launch_ring_t<EPI_BIAS_GELU>(a, st);
-            case EPI_BIAS_GATE_RES: return launch_ring_t<EPI_BIAS_GATE_RES>(a, st);
-            case EPI_BIAS_ADD: return launch_ring_t<EPI_BIAS_ADD>(a, st);
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }

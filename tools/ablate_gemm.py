@@ -12,9 +12,7 @@ W = (torch.randn(N, K, device=DEV) * 0.02).bfloat16()
 b = torch.zeros(N, device=DEV, dtype=torch.bfloat16)
 C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
 f = lambda: L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, 0, 1, 0, L.stream_ptr()))
-cases = [("pp64 full", 7), ("pp64 no-DMA", 7 | (1 << 8)), ("pp64 no-MFMA", 7 | (3 << 8)), ("pp full", 6), ("pp no-DMA", 6 | (1 << 8)), ("pp no-ds_read", 6 | (2 << 8)), ("pp no-MFMA", 6 | (3 << 8))]
-cases_w128 = [("w128 full", 4), ("w128 no-DMA-wait", 4 | (1 << 8)), ("w128 no-DMA", 4 | (2 << 8)), ("w128 no-ds_read", 4 | (3 << 8)),
-         ("w128 no-MFMA", 4 | (4 << 8)), ("w128 no-barrier", 4 | (5 << 8))]
+cases = [("pp64 full", 7), ("pp64 no-DMA", 7 | (1 << 8)), ("pp64 no-MFMA", 7 | (3 << 8)), ("pp64 no-setprio", 7 | (7 << 8))]
 for rep in range(2):
     for name, code in cases:
         L.lib().s2v_set_gemm_impl(code)

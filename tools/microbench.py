@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT)
 s2v = importlib.import_module("disentangled-subject-to-vid_amd")
 L = s2v._lib
 DEV = "cuda:0"
-IMPLS = [int(x) for x in os.environ.get("S2V_IMPLS", "7").split(",")]
+LABELS = {0: "tile128x128", 2: "stag256x128", 5: "w8-lockstep", 7: "pp64-pingpong"}
+IMPLS = [int(x) for x in os.environ.get("S2V_IMPLS", "7,5").split(",")]
 
 
 def timeit(fn, iters=10, warm=3):
@@ -47,10 +48,10 @@ def bench_gemm():
             elif not torch.equal(ref, C):
                 print(f"   !! impl {impl} differs from impl {IMPLS[0]}: max abs {(ref.float() - C.float()).abs().max().item():.4g}", flush=True)
             ms = timeit(f)
-            print(f"gemm[{('tile128x128','ring256x128','stag256x128','r32-2blk','w128-4wave','w8-8wave','pp-8wave','pp64-8wave','pp16-16wave')[impl]}] {name:9s} M={M} N={N} K={K}: {ms:8.3f} ms  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
+            print(f"gemm[{LABELS[impl]}] {name:9s} M={M} N={N} K={K}: {ms:8.3f} ms  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
         t = timeit(lambda: torch.matmul(A, W.T), iters=5)
         print(f"   (hipBLASLt via torch.matmul: {t:8.3f} ms  {2*M*N*K/t/1e9:8.1f} TFLOP/s)", flush=True)
-        L.lib().s2v_set_gemm_impl(5)
+        L.lib().s2v_set_gemm_impl(7)
         del A, W, C
 
 

@@ -19,4 +19,4 @@ for (M, N, K) in ((4096, 4096, 1024), (4096, 4096, 3072), (4096, 4096, 12288), (
         ms = timeit(f, iters=20)
         by = tiles * 2 * 256 * K * 2
         print(f"tiles={tiles:5d} K={K:5d} {name:8s}: {ms:7.3f} ms  DMA {by/ms/1e9:7.2f} TB/s = {by/ms/1e6/min(tiles,256)/2.1:6.1f} B/clk/CU@2.1GHz  ({2*M*N*K/ms/1e9:7.1f} TF)", flush=True)
-L.lib().s2v_set_gemm_impl(5)
+L.lib().s2v_set_gemm_impl(7)

@@ -22,4 +22,4 @@ nh = K // 32
 print("cycles per half-step (s_memtime ticks / %d half-steps); %s" % (nh, ", ".join(names)))
 for w in range(8):
     print(f"wave {w}: " + "  ".join(f"{buf[w*8+e]/nh:8.1f}" for e in range(8)))
-L.lib().s2v_set_gemm_impl(5)
+L.lib().s2v_set_gemm_impl(7)
