@@ -11,3 +11,4 @@ from .vae import HipAutoencoderKLCogVideoX  # noqa: F401
 from . import dist  # noqa: F401
 from . import checkpoint  # noqa: F401
 from .t5 import HipT5EncoderModel, T5Config  # noqa: F401
+from . import video_generate  # noqa: F401
