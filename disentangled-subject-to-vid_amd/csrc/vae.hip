@@ -458,6 +458,29 @@ __global__ void postprocess_k(const T* v, int C, int F, int H, int W, float* out
         out[i] = fminf(fmaxf(x, 0.f), 1.f);
     }
 }
+// the same, followed by export_to_video's `(frame * 255).astype(np.uint8)` (utils/export_utils.py:175): uint8 [F][H][W][C]
+template <typename T>
+__global__ void postprocess_u8_k(const T* v, int C, int F, int H, int W, unsigned char* out) {
+    const int64_t total = (int64_t)C * F * H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t p = i / C;
+        const int64_t fhw = (int64_t)F * H * W;
+        float x = ET<T>::ld(v + (int64_t)c * fhw + p);
+        x = ET<T>::rnd(ET<T>::rnd(x / 2.0f) + 0.5f);
+        x = fminf(fmaxf(x, 0.f), 1.f) * 255.0f;   // float32 product, then truncation toward zero
+        out[i] = (unsigned char)(int)x;
+    }
+}
+int launch_postprocess_u8(const void* v, int C, int F, int H, int W, unsigned char* out, int dtype, hipStream_t st) {
+    const int64_t total = (int64_t)C * F * H * W;
+    if (dtype == S2V_BF16)
+        hipLaunchKernelGGL(postprocess_u8_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)v, C, F, H, W, out);
+    else
+        hipLaunchKernelGGL(postprocess_u8_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)v, C, F, H, W, out);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 int launch_postprocess(const void* v, int C, int F, int H, int W, float* out, int dtype, hipStream_t st) {
     const int64_t total = (int64_t)C * F * H * W;
     if (dtype == S2V_BF16)

@@ -515,6 +515,12 @@ extern "C" int s2v_vae_decode(s2v_vae* v, const void* latents, int32_t F, int32_
     return 0;
 }
 
+extern "C" int s2v_vae_postprocess_u8(const void* video, int32_t C, int32_t F, int32_t H, int32_t W, uint8_t* out, int32_t dtype,
+                                      s2v_stream stream) {
+    S2V_REQUIRE(video && out, "s2v_vae_postprocess_u8: null argument");
+    return launch_postprocess_u8(video, C, F, H, W, out, dtype, (hipStream_t)stream);
+}
+
 extern "C" int s2v_vae_postprocess(const void* video, int32_t C, int32_t F, int32_t H, int32_t W, float* out, int32_t dtype,
                                    s2v_stream stream) {
     S2V_REQUIRE(video && out, "s2v_vae_postprocess: null argument");

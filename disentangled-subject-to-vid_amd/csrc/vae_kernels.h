@@ -30,4 +30,5 @@ int launch_blend(const void* a, int Ha, int Wa, void* b, int Hb, int Wb, int CF,
 int launch_paste(const void* tile, int Ht, int Wt, int ch, int cw, void* out, int H, int W, int y0, int x0, int CF,
                  int dtype, hipStream_t st);
 int launch_postprocess(const void* v, int C, int F, int H, int W, float* out, int dtype, hipStream_t st);
+int launch_postprocess_u8(const void* v, int C, int F, int H, int W, unsigned char* out, int dtype, hipStream_t st);
 int launch_conv_w_repack(const void* src, int sdt, int cout, int cin, int taps, void* dst, int ddt, hipStream_t st);

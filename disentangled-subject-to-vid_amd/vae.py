@@ -30,6 +30,7 @@ _lib.register_sigs({
     "s2v_vae_out_shape": [_P, _I32, _I32, _I32, _I32, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)],
     "s2v_vae_decode": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "s2v_vae_postprocess": [_P, _I32, _I32, _I32, _I32, _P, _I32, _P],
+    "s2v_vae_postprocess_u8": [_P, _I32, _I32, _I32, _I32, _P, _I32, _P],
     "s2v_vae_enc_create": [ctypes.POINTER(VaeConfigC), ctypes.POINTER(_P)],
     "s2v_vae_encode_shape": [_P, _I32, _I32, _I32, ctypes.POINTER(_I32), ctypes.POINTER(_I32)],
     "s2v_vae_encode": [_P, _P, _I32, _I32, _I32, _P, _P],
@@ -198,6 +199,17 @@ class HipAutoencoderKLCogVideoX:
         if not return_dict:
             return (dec,)
         return SimpleNamespace(sample=dec)
+
+    def frames_uint8(self, video):
+        """decoded video [1,3,F,H,W] -> uint8 [F,H,W,3]: postprocess_video(..., "np")[0] followed by export_to_video's
+        `(frame * 255).astype(np.uint8)` (utils/export_utils.py:175), converted on the device"""
+        if video.shape[0] != 1:
+            raise NotImplementedError("one video per call")
+        _, C, F, H, W = video.shape
+        v = video[0].contiguous()
+        o = torch.empty((F, H, W, C), dtype=torch.uint8, device=v.device)
+        _lib.check(_lib.lib().s2v_vae_postprocess_u8(_lib.ptr(v), C, F, H, W, _lib.ptr(o), _lib.DTYPE_OF[v.dtype], _lib.stream_ptr()))
+        return o
 
     def postprocess_video(self, video, output_type="np"):
         """VideoProcessor.postprocess_video: [B,3,F,H,W] -> np float32 [B,F,H,W,3] (or 'pt' [B,F,3,H,W])"""

@@ -43,3 +43,19 @@ def inference(pipe, text_encoder, ref_image_uint8, prompt_ids, negative_prompt_i
                return_dict=True, **pipe_kwargs)
     video = out["frames"]
     return video[0] if output_type == "np" else video
+
+
+def export_to_video(frames_uint8, output_video_path, fps=8):
+    """utils/export_utils.py:143-186 with the frames already uint8 [F,H,W,3] (HipAutoencoderKLCogVideoX.frames_uint8): the mp4
+    container / codec work is imageio-ffmpeg's (host side, third party); this function only hands the frames over and fails
+    loudly when that backend is absent -- there is no other encoder on the path."""
+    try:
+        import imageio
+        imageio.plugins.ffmpeg.get_exe()
+    except Exception as e:  # ImportError / AttributeError / missing binary
+        raise RuntimeError("export_to_video needs imageio + imageio-ffmpeg (src/video_generate.py:65-66); not present here") from e
+    frames = frames_uint8.cpu().numpy() if hasattr(frames_uint8, "cpu") else np.asarray(frames_uint8)
+    with imageio.get_writer(output_video_path, fps=fps) as writer:
+        for frame in frames:
+            writer.append_data(frame)
+    return output_video_path

@@ -177,6 +177,10 @@ int s2v_vae_decode(s2v_vae* vae, const void* latents, int32_t F, int32_t h, int3
  * video [C,F,H,W] -> float32 [F,H,W,C], clamp(x/2 + 0.5, 0, 1) */
 int s2v_vae_postprocess(const void* video, int32_t C, int32_t F, int32_t H, int32_t W, float* out, int32_t dtype,
                         s2v_stream stream);
+/* the same followed by export_to_video's frame conversion `(frame * 255).astype(np.uint8)` (utils/export_utils.py:175;
+ * src/video_generate.py:65-66): video [C,F,H,W] -> uint8 [F,H,W,C], what the mp4 writer consumes (4x less D2H traffic) */
+int s2v_vae_postprocess_u8(const void* video, int32_t C, int32_t F, int32_t H, int32_t W, uint8_t* out, int32_t dtype,
+                           s2v_stream stream);
 
 /* ---- reference-image encode (the step in front of the denoise loop) ------------------------------------------
  * Replaces pipe.vae.encode(ref_image).latent_dist.sample() of src/video_generate.py:35-37

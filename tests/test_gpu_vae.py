@@ -92,3 +92,18 @@ def test_vae_mfma_channels_vs_oracle(s2v, dt_name, simple, tiling):
     else:
         rel = ((y - exp).double().norm() / exp.double().norm()).item()
         assert rel <= 3e-2 and err <= 0.15 * exp.abs().max().item(), (rel, err)
+
+
+def test_frames_uint8_matches_export_to_video_conversion(s2v):
+    """(postprocess_video(..., "np")[0] * 255).astype(np.uint8) of utils/export_utils.py:175, bit-exact, both dtypes"""
+    g = load_golden("vae_tiny.npz")
+    vae = make_vae(s2v, TINY, torch.float32, weights_of(g))
+    for dt in (torch.float32, torch.bfloat16):
+        video = t(g["dec_2f"]).to(dt).to(DEV)
+        video[0, 0, 0, 0, :4] = torch.tensor([5.0, -5.0, 1.0, -1.0], dtype=dt)  # clamp edges: 255, 0, 255, 0
+        u8 = vae.frames_uint8(video).cpu().numpy()
+        ref = (vae.postprocess_video(video, "np")[0] * 255).astype(np.uint8)
+        assert u8.dtype == np.uint8 and u8.shape == ref.shape
+        assert np.array_equal(u8, ref)
+    with pytest.raises(RuntimeError, match="imageio"):
+        s2v.video_generate.export_to_video(u8, "/tmp/never_written.mp4")
