@@ -29,6 +29,8 @@ WORKLOADS = {
     "cogvideox-5b-49x480x720": ("cogvideox-5b", 13, 60, 90, 226),
     "cogvideox-2b-49x480x720": ("cogvideox-2b", 13, 60, 90, 226),
     "cogvideox-2b-9x256x256": ("cogvideox-2b", 3, 32, 32, 226),
+    # the geometry of BASELINE configs[4] (49 frames 720x1280, N = 50626 tokens) on the bf16 path; its fp8-weight form is not built
+    "cogvideox-5b-49x720x1280": ("cogvideox-5b", 13, 90, 160, 226),
 }
 
 
