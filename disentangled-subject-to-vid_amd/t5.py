@@ -126,12 +126,10 @@ class HipT5EncoderModel:
         _lib.check(_lib.lib().s2v_t5_rel_table(self._h, ctypes.byref(p)))
         nb, H = self.cfg.relative_attention_num_buckets, self.cfg.num_heads
         table = torch.empty((nb, H), dtype=self.dtype, device=self.device)
-        esz = table.element_size()
-        ctypes_copy = torch.cuda.current_stream(self.device)
-        # device -> device view of the loaded table (owned by the handle)
-        src = _ArenaView(p.value, nb * H * esz)
+        # device -> device copy out of the handle-owned table
+        src = _ArenaView(p.value, nb * H * table.element_size())
         table.view(torch.uint8).view(-1).copy_(torch.as_tensor(src, device=self.device))
-        ctypes_copy.synchronize()
+        torch.cuda.current_stream(self.device).synchronize()
         buckets = position_buckets(T, nb, self.cfg.relative_attention_max_distance).to(self.device)
         bias = table[buckets].permute(2, 0, 1).contiguous()  # compute_bias: [H, T, T]
         _lib.check(_lib.lib().s2v_t5_set_position_bias(self._h, _lib.ptr(bias), B, T, _lib.stream_ptr()))

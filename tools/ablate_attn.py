@@ -21,7 +21,7 @@ out = torch.empty(B * N, D, device=DEV, dtype=torch.bfloat16)
 vt = torch.zeros(B * H * 64 * ((N + 63) // 64 * 64), dtype=torch.bfloat16, device=DEV)
 f = lambda: L.check(L.lib().s2v_op_attention(L.ptr(qkv), L.ptr(vt), L.ptr(out), B, H, N, 1, 0, L.stream_ptr()))
 fl = 4 * B * H * N * N * 64
-names = {9: "online-max kernel only", 0: "bounded q64 kernel (default)", 1: "no exp", 2: "no row-sum adds", 3: "no max", 4: "variant 4", 5: "variant 5", 6: "variant 6", 7: "variant 7"}
+names = {0: "default (8 waves)", 1: "no exp2", 2: "no row-sum adds", 3: "no row max", 4: "4-wave blocks"}
 ref = None
 for v in [int(x) for x in sys.argv[1:]] or [0, 1, 2, 3]:
     L.lib().s2v_set_attn_variant(v)
