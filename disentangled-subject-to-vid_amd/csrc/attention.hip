@@ -136,7 +136,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
         // exactly when no row of the wave grew (alpha == 1 for every lane).
         if (t == 0 || __any(mx > 0.f)) {
             const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
-            const float alpha = __builtin_amdgcn_exp2f(-d);
+            // t == 0: O and l are still zero, and exp2(-d) would overflow to inf (0 * inf = NaN) for scores below -128
+            const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d);
             m_run += d;
             l_run *= alpha;
 #pragma unroll

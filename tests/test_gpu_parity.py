@@ -295,3 +295,29 @@ def test_cogvideox_2b_width_c1_geometry_vs_oracle(s2v, dt_name):
     npred_hip = eng.last_noise_pred()
     assert_close(npred_hip, npred, dt_name, "2B noise_pred")
     assert_close(x, exp, dt_name, "2B latents after one step")
+
+
+def test_op_attention_strongly_negative_and_positive_scores(s2v):
+    """scores far outside [-128, 128] in the exp2 domain: the first-tile maximum must be adopted without forming exp2(+-big)
+    (0 * inf = NaN otherwise); softmax is shift invariant, so the result is the plain softmax-weighted mean of V."""
+    L = s2v._lib
+    B, H, N = 1, 2, 200
+    D = H * 64
+    g = torch.Generator().manual_seed(5)
+    for sign in (-1.0, 1.0):
+        q = torch.full((B * N, D), 4.0) + 0.05 * torch.randn(B * N, D, generator=g)
+        k = sign * (torch.full((B * N, D), 4.0) + 0.05 * torch.randn(B * N, D, generator=g))
+        v = torch.randn(B * N, D, generator=g)
+        qkv = torch.cat([q, k, v], dim=1).bfloat16()
+        pad = torch.zeros(64, 3 * D, dtype=torch.bfloat16)
+        qkv_d = torch.cat([qkv, pad]).to(DEV)
+        out = torch.full((B * N, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        vt = torch.zeros(B * H * 64 * 256, dtype=torch.bfloat16, device=DEV)
+        L.check(L.lib().s2v_op_attention(L.ptr(qkv_d), L.ptr(vt), L.ptr(out), B, H, N, 1, 0, L.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(out.float()).all()
+        qf, kf, vf = (x.float().reshape(B, N, H, 64).transpose(1, 2) for x in (qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]))
+        exp = torch.softmax(qf @ kf.transpose(-1, -2) * 0.125, dim=-1) @ vf
+        exp = exp.transpose(1, 2).reshape(B * N, D)
+        rel = ((out.float().cpu() - exp).norm() / exp.norm()).item()
+        assert rel <= 3e-2, (sign, rel)
