@@ -142,7 +142,7 @@ int launch_gaussian_sample(const void* mom, const void* noise, int64_t n, void* 
 // GroupNorm statistics: sums[g] = {sum x, sum x^2} in fp64 over P pixels x (C/G) channels
 #define GN_PIX_PER_BLOCK 512
 // Deterministic (no atomics): per-thread partials -> LDS [pixel lane][channel] -> per-channel sums in lane order ->
-// per-group fp64 block partials part[block][g][2]; gn_finalize_k adds the block partials in block order.
+// per-group fp64 block partials part[block][g][2]; gn_finalize_k adds them with a fixed 256-way split + tree (no atomics).
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_k(const T* x, int64_t P, int C, int G, double* part) {
     constexpr int VN = V16<T>::N;
@@ -180,13 +180,20 @@ __global__ __launch_bounds__(256) void gn_stats_k(const T* x, int64_t P, int C, 
         part[((int64_t)blockIdx.x * G + g) * 2 + 1] = s2;
     }
 }
-__global__ void gn_finalize_k(const double* part, int nblocks, int G, double* sums) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G) return;
-    double s = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblocks; ++b) { s += part[((int64_t)b * G + g) * 2]; s2 += part[((int64_t)b * G + g) * 2 + 1]; }
-    sums[2 * g] = s;
-    sums[2 * g + 1] = s2;
+__global__ __launch_bounds__(256) void gn_finalize_k(const double* part, int nblocks, int G, double* sums) {
+    // one block per (group, sum | sum of squares): 256 threads add strided subsets of the block partials in index order,
+    // then a fixed-shape tree in LDS -- deterministic (no atomics) and 256-wide instead of one thread walking every partial
+    __shared__ double red[256];
+    const int i = blockIdx.x, t = threadIdx.x;
+    double s = 0.0;
+    for (int b = t; b < nblocks; b += 256) s += part[(size_t)b * 2 * G + i];
+    red[t] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) red[t] += red[t + w];
+        __syncthreads();
+    }
+    if (t == 0) sums[i] = red[0];
 }
 int64_t gn_stats_scratch_bytes(int64_t P, int G) {
     return ((P + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK) * G * 2 * (int64_t)sizeof(double);
@@ -200,7 +207,7 @@ int launch_gn_stats(const void* x, int64_t P, int C, int G, double* sums, double
         hipLaunchKernelGGL(gn_stats_k<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, P, C, G, part);
     else
         hipLaunchKernelGGL(gn_stats_k<float>, dim3(grid), dim3(256), 0, st, (const float*)x, P, C, G, part);
-    hipLaunchKernelGGL(gn_finalize_k, dim3((G + 63) / 64), dim3(64), 0, st, part, (int)grid, G, sums);
+    hipLaunchKernelGGL(gn_finalize_k, dim3(2 * G), dim3(256), 0, st, part, (int)grid, G, sums);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
