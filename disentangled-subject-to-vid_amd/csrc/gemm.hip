@@ -352,38 +352,29 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_stag(const GemmArgs a, int t
     const int in_g = wg - group * per_group;
     const int m0 = (first_m + in_g % gsz) * RBM, n0 = (in_g / gsz) * RBN;
 
-    const bf16_t* A = (const bf16_t*)a.A;
-    const bf16_t* W = (const bf16_t*)a.W;
-    int64_t rbA[4], rbW[2];
-    int cA[4], cW[2];
+    // saddr-form LDS-DMA (see glds16_saddr): wave-uniform tile base + loop-invariant 32-bit lane offsets
+    const int64_t rbase0 = a_row_base(a, m0);
+    const char* Abase = (const char*)a.A + 2 * rbase0;
+    const char* Wbase = (const char*)a.W + 2 * (int64_t)n0 * a.ldw;
+    unsigned offA[4], offW[2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int gi = i * 512 + tid, row = gi >> 3;
-        rbA[i] = a_row_base(a, m0 + row);
-        cA[i] = ((gi & 7) ^ ((row >> 1) & 7)) * 8;
+        offA[i] = (unsigned)(2 * (a_row_base(a, m0 + row) - rbase0 + ((gi & 7) ^ ((row >> 1) & 7)) * 8));
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int gi = i * 512 + tid, row = gi >> 3;
-        rbW[i] = (int64_t)(n0 + row) * a.ldw;
-        cW[i] = ((gi & 7) ^ ((row >> 1) & 7)) * 8;
+        offW[i] = (unsigned)(2 * ((int64_t)row * a.ldw + ((gi & 7) ^ ((row >> 1) & 7)) * 8));
     }
     auto stage = [&](int t, int s) {
         char* base = smem + s * RSTAGE;
-        const int64_t ka = a_k_off(a, t * BK);
-        const int kw = t * BK;
+        const char* ta = Abase + 2 * a_k_off(a, t * BK);
+        const char* tw = Wbase + 2 * (int64_t)t * BK;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            char* dst = base + (i * 512 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(A + rbA[i] + ka + cA[i]),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i) glds16_saddr(ta, offA[i], base + (i * 512 + wave * 64) * 16);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            char* dst = base + RA_BYTES + (i * 512 + wave * 64) * 16;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + rbW[i] + kw + cW[i]),
-                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-        }
+        for (int i = 0; i < 2; ++i) glds16_saddr(tw, offW[i], base + RA_BYTES + (i * 512 + wave * 64) * 16);
     };
 
     f32x16 acc[2][2];
