@@ -20,9 +20,17 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_library(force=False, verbose=True):
+DIAG_LIB = os.path.join(HERE, "libs2v_hip_diag.so")
+
+
+def build_library(force=False, verbose=True, diag=False):
+    """diag=False: the product library (exports exactly what include/s2v_hip.h declares).
+    diag=True: libs2v_hip_diag.so = the same sources with -DS2V_DIAG (A/B reference kernels, stall accounting, ablations and
+    their knobs); only tools/ and the race-screen test load it."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build_diag" if diag else "build")
+    LIB = DIAG_LIB if diag else globals()["LIB"]
+    FLAGS = globals()["FLAGS"] + (["-DS2V_DIAG"] if diag else [])
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
     headers.append(os.path.join(HERE, "..", "include", "s2v_hip.h"))
@@ -51,5 +59,4 @@ def build_library(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build_library(force="--force" in sys.argv)
-    print(LIB)
+    print(build_library(force="--force" in sys.argv, diag="--diag" in sys.argv))

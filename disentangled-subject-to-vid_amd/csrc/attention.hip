@@ -1,16 +1,17 @@
 // Joint [text | ref-image | video] self-attention, head_dim 64, no mask
 // (replaces F.scaled_dot_product_attention at attention_processor.py:2083-2087).
 //
-//  attn_bf16_k : flash-attention forward on v_mfma_f32_32x32x16_bf16.
-//     block = NW (8; 4 as diagnostic) waves x 32 query rows; KV tile = 64 keys; K tile [64 kv][64 d] and V^T tile [64 d][64 kv] are
-//     staged with global_load_lds into double-buffered, XOR-swizzled LDS (same image as gemm.hip).
+//  attn_pp_k : flash-attention forward on v_mfma_f32_32x32x16_bf16, eight waves in a two-group ping-pong (below).
+//     block = 8 waves x 32 query rows; KV tile = 64 keys; K tile [64 kv][64 d] and V^T tile [64 d][64 kv] are staged with
+//     LDS-DMA (global_load_lds) into a ring of XOR-swizzled LDS slots (same image as gemm.hip).
 //     QK^T is issued swapped (S^T = K . Q^T) so every lane owns ONE query row: row max / row sum / rescale are
 //     lane-local (one cross-half exchange per tile).  P^T feeds the PV MFMA straight from the S^T accumulator
 //     registers: the MFMA k-slot <-> key assignment is free, so V^T is stored in HBM with the keys of every
 //     16-group permuted [0-3, 8-11, 4-7, 12-15] (done by qk_norm_rope) and no lane exchange is needed.
 //     O^T = V^T . P^T accumulates with the query again on the lane axis.
 //     Softmax in the exp2 domain: Q is pre-multiplied by scale * log2(e) and the S^T accumulators start at -m_run (a
-//     loop-carried register block), so p = exp2(MFMA result) with no per-score fma (measured +3.5 % at C3).
+//     loop-carried register block), so p = exp2(MFMA result) with no per-score fma.
+//  attn_bf16_k (S2V_DIAG builds only): the round-1 lock-step kernel with a per-tile row maximum, kept as the A/B reference.
 //  attn_simple_k<T> : one wave per query row, fp32 math, any dtype (CPU-reference-parity mode / cross-check).
 #define S2V_HOST
 #include "common.h"
@@ -44,11 +45,18 @@ __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ kg, size_t l
     stage64<NW * 64>(kg, ldk, lds, tid);
     stage64<NW * 64>(vg, ldv, lds + ATT_TILE_BYTES, tid);
 }
+// v_max3_f32 written out so that the max tree keeps the order it is given (the scores are never NaN: no canonicalisation)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ bf16x8 frag64(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + row * 128 + ((cl ^ ((row >> 1) & 7)) << 4));
 }
 
-// ABL (diagnostics, tools/ablate_attn.py; results are wrong on purpose): 1 = no exp2, 2 = no row-sum adds, 3 = no row max
+#ifdef S2V_DIAG
+// round-1 lock-step kernel (A/B reference of tools/attn_harness); ABL is unused
 template <int ABL, int NW = 8>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K tile | VT tile]
@@ -194,28 +202,292 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
             }
     }
 }
+#endif  // S2V_DIAG
 
-int g_attn_variant = 0;  // diagnostics (tools/microbench.py): timing-only ablations of the softmax VALU work
+// ---------------------------------------------------------------------------------------------------
+// attn_pp_k: 8-wave PING-PONG flash attention.  Waves w and w + 4 share a SIMD; group A = waves 0-3, group B = waves 4-7, one
+// barrier interval apart.  Every interval one group is in its MATRIX segment M(t+1) (QK^T of tile t+1, P.V of tile t) while
+// its SIMD partner is in its SOFTMAX segment S(t).
+//
+// What shapes the split (tools/probes/valu_rate.hip, MI355X): a wave issues plain VALU every 4.9 cycles and v_exp_f32 every 8.9
+// on its own, but beside a partner that streams v_mfma_f32_32x32x16_bf16 back to back the SIMD grants the partner one VALU
+// per 16 cycles (exp2 or not, any priority, either wave older); (exp2, exp2, add, add) per MFMA is the densest partner stream
+// that still fits (33 cycles per MFMA), and the MFMA wave can place two plain VALU of its own behind each MFMA.  Head
+// dimension 64 needs 32 exp2 per 16 MFMA, so the softmax is cut down to what those slots hold:
+//   * NO per-tile row maximum.  The running maximum is adopted from the first tile; afterwards a tile only checks its row
+//     SUMS (psum > 2^13, wave-wide vote) and takes the slow path -- true row max, rescale of O and l, exp2 again -- when some
+//     p exceeded ~2^8 (deferred maximum: p stays far inside the fp32 / bf16 range, the result is the same up to rounding);
+//   * S(t): 32 exp2 + 32 row-sum adds as 16 (exp2, exp2, add, add) groups, the vote, the wait for this wave's LDS-DMA;
+//   * M(t+1): per MFMA one fragment read; the 16 v_cvt_pk (bf16 packing of P) behind the 8 QK^T MFMAs, the K fragments of
+//     tile t+2 behind the 8 P.V MFMAs, and the wave's two LDS-DMA pieces AFTER its last MFMA (an LDS-DMA instruction keeps its
+//     wave from issuing for 60-100 cycles: between MFMAs that is a bubble of the matrix pipe, after them it is barrier slack).
+// Phases (one per barrier): A runs M(t) in phase 2t and S(t) in phase 2t+1, B one phase later.
+// LDS ring of 4 slots x [K tile 8 KiB | V^T tile 8 KiB]; in M(t+1) every wave issues ONE K piece (8 rows) of tile t+4 and ONE
+// V^T piece of tile t+2 and waits for them (vmcnt(0)) at the end of S(t+1):
+//   RAW  K(t+4): A's pieces land by the end of phase 2t+3, B's by 2t+4; first read (fragment prefetch in M(t+3)) in phase 2t+6.
+//        V(t+2): first read in M(t+3) = phase 2t+6.
+//   WAR  K(t+4) replaces K(t), last read in phase 2t-1 (B's M(t-1) prefetch; K(0) and K(1): M(0), phases 0-1); first write in
+//        phase 2t+2.  V(t+2) replaces V(t-2), last read by B's M(t-1) in phase 2t-1.
+// Measured at C3 (B 2, H 48, N 19126; tools/attn_harness): 8.1 ms against 9.2-9.4 for the lock-step kernel; variants that
+// lost the A/B (kept out of the tree): row sums with v_pk_add_f32 (+5 %), no s_setprio in M (+6 %), LDS-DMA between the P.V
+// MFMAs (+3 %) or in S (+4 %), dedicated loader waves (three waves per SIMD force 168 registers and drop the fragment
+// prefetch: +2 %), bounded scores with no maximum at all and the row sums on the matrix pipe (20 MFMA per tile: -1.5 %, not
+// worth its precondition).
+#ifdef S2V_DIAG
+__device__ long long g_attn_dbg[64];  // ACCT: per-wave s_memtime totals of block 100
+extern "C" int s2v_attn_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
+#endif
+template <bool ACCT>
+__global__ __launch_bounds__(512, 2) void attn_pp_k(const AttnArgs a, int nqb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 slots][K tile | VT tile]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;
+    const int fr = lane & 31, hi = lane >> 5;
+
+    // XCD-aware order: all q-blocks of one (b,h) run on one XCD so its K/V stay in that XCD's L2
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
+    const int bh = wg / nqb, qb = wg - bh * nqb;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int D = a.H * 64;
+
+    const bf16_t* qkv = (const bf16_t*)a.qkv + (size_t)b * a.Ntok * a.ld_qkv;
+    const char* Kg = (const char*)(qkv + D + h * 64);
+    const char* VTg = (const char*)((const bf16_t*)a.vt + (size_t)(b * a.H + h) * 64 * a.ntok_pad);
+    const int nt = (a.Ntok + KV_TILE - 1) / KV_TILE;
+
+    // staging: this wave's piece = rows wave*8 .. +7 of a tile, lane = (row, 16-B chunk), chunk XOR on the SOURCE address;
+    // global address = wave-uniform tile base (SGPR pair) + per-lane 32-bit offset
+    const int srow = wave * 8 + (lane >> 3);
+    const int sc = (lane & 7) ^ ((srow >> 1) & 7);
+    const unsigned offK = (unsigned)(2 * (srow * a.ld_qkv + sc * 8));
+    const unsigned offV = (unsigned)(2 * (srow * a.ntok_pad + sc * 8));
+    const size_t k_tile_stride = (size_t)KV_TILE * a.ld_qkv * 2;
+    auto dma_k = [&](int t) {  // tiles past the end are clamped (re-staged into a dead slot) so that every wave issues the same count
+        const int tc = min(t, nt - 1);
+        glds16_saddr(Kg + (size_t)tc * k_tile_stride, offK, smem + (t & 3) * 16384 + wave * 1024);
+    };
+    auto dma_v = [&](int t) {
+        const int tc = min(t, nt - 1);
+        glds16_saddr(VTg + (size_t)tc * (KV_TILE * 2), offV, smem + (t & 3) * 16384 + 8192 + wave * 1024);
+    };
+    dma_k(0); dma_v(0); dma_k(1); dma_v(1); dma_k(2); dma_k(3);
+
+    // Q fragments (B operand of S^T = K.Q^T): lane (q = fr, hi) holds Q[q][16kk + 8hi .. +8], pre-multiplied by
+    // scale * log2(e) and rounded to bf16 once (the reference's math path rounds its scaled q and k to bf16 as well), so the
+    // MFMA result is already the exp2 argument
+    const int q_row = qb * 256 + wave * 32 + fr;
+    const int q_ld = min(q_row, a.Ntok - 1);
+    const float c0 = a.scale * 1.4426950408889634f;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        qf[kk] = *(const bf16x8*)(qkv + (size_t)q_ld * a.ld_qkv + h * 64 + kk * 16 + hi * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[kk][e] = (__bf16)((float)qf[kk][e] * c0);
+    }
+
+    // the S^T accumulators START at -m_run: this 16-register block is loop-carried and only rewritten on the slow path
+    f32x16 ot[2], st[2], negm16;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { ot[0][e] = 0.f; ot[1][e] = 0.f; negm16[e] = 0.f; }
+    float l_run = 0.f;
+    bf16x8 pk[4], kf[8], vf[8];
+    f32x16 pp[2];  // exp2 results of the tile in flight between S(t) and M(t+1)
+
+    // fragment byte offsets inside a tile: K (kk, kb) and V^T (s, db) use the same (row, chunk) pattern
+    int foff[4][2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            const int row = kb * 32 + fr, cl = kk * 2 + hi;
+            foff[kk][kb] = row * 128 + ((cl ^ ((row >> 1) & 7)) << 4);
+        }
+    auto k_frag = [&](int t, int i) -> bf16x8 { return *(const bf16x8*)(smem + (t & 3) * 16384 + foff[i >> 1][i & 1]); };
+    auto v_frag = [&](int t, int i) -> bf16x8 { return *(const bf16x8*)(smem + (t & 3) * 16384 + 8192 + foff[i >> 1][i & 1]); };
+    auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (grp) __builtin_amdgcn_s_barrier();  // group B runs one phase behind
+    fence();
+    // M(0): QK^T of tile 0 and the K fragments of tile 1
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kf[i] = k_frag(0, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[i >> 1], i < 2 ? negm16 : st[i & 1], 0, 0, 0);
+    fence();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) kf[i] = k_frag(min(1, nt - 1), i);
+    fence();
+    __builtin_amdgcn_s_barrier();
+    fence();
+
+    long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    auto now = [&]() -> long long { return ACCT ? (long long)__builtin_amdgcn_s_memtime() : 0; };
+    const long long tl0 = now();
+    for (int t = 0; t < nt; ++t) {
+        // ---- softmax segment S(t)
+        const long long u0 = now();
+        const int kv0 = t * KV_TILE;
+        if (kv0 + KV_TILE > a.Ntok) {  // tail tile: mask keys >= Ntok
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int kv = kv0 + kb * 32 + (e & 3) + 8 * (e >> 2) + 4 * hi;
+                    if (kv >= a.Ntok) st[kb][e] = -INFINITY;
+                }
+        }
+        float ps0 = 0.f, ps1 = 0.f;
+        // 16 groups of (exp2, exp2, add, add): the adds of a group consume the exp2 results of the group before.  Written as
+        // asm so that neither the SLP vectoriser (it packs the adds) nor the scheduler reorders the stream.
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int kb = g >> 3, e = (g & 7) * 2;
+            asm volatile("v_exp_f32 %0, %1" : "=v"(pp[kb][e]) : "v"(st[kb][e]));
+            asm volatile("v_exp_f32 %0, %1" : "=v"(pp[kb][e + 1]) : "v"(st[kb][e + 1]));
+            if (g > 0) {
+                const int gp = g - 1, kbp = gp >> 3, ep = (gp & 7) * 2;
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(ps0) : "v"(pp[kbp][ep]));
+                asm volatile("v_add_f32 %0, %0, %1" : "+v"(ps1) : "v"(pp[kbp][ep + 1]));
+            }
+        }
+        ps0 += pp[1][14];
+        ps1 += pp[1][15];
+        float psum = ps0 + ps1;
+        // Deferred maximum: the slow path runs for the first tile (adopts its maximum; its first exp2 pass may overflow, the
+        // vote is NaN-safe) and whenever some p of the wave grew past ~2^8: m_run rises to the true maximum, everything at
+        // the old scale is rescaled once, and the tile's exp2 is redone at the new scale.
+        if (t == 0 || __any(!(psum <= 8192.f))) {
+            float m0 = max3f(st[0][0], st[0][1], st[0][2]), m1 = max3f(st[1][0], st[1][1], st[1][2]);
+#pragma unroll
+            for (int e = 3; e < 15; e += 2) { m0 = max3f(m0, st[0][e], st[0][e + 1]); m1 = max3f(m1, st[1][e], st[1][e + 1]); }
+            const float mxp = max3f(m0, m1, fmaxf(st[0][15], st[1][15]));
+            // cross-half exchange without LDS: sw[0] = lower half's value in both halves, sw[1] = upper half's
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mxp), __float_as_uint(mxp), false, false);
+            const float mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            const float d = (t == 0) ? mx : fmaxf(mx, 0.f);
+            // t == 0: O and l are still zero, and exp2(-d) would overflow to inf (0 * inf = NaN) for scores below -128
+            const float alpha = (t == 0) ? 1.0f : __builtin_amdgcn_exp2f(-d);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) ot[i][e] *= alpha;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) negm16[e] -= d;  // -(m + d) == (-m) - d exactly
+            psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    pp[kb][e] = __builtin_amdgcn_exp2f(st[kb][e] - d);
+                    psum += pp[kb][e];
+                }
+        }
+        l_run += psum;
+        asm volatile("" : "+v"(l_run));
+        fence();
+        const long long u1 = now();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const long long u2 = now();
+        __builtin_amdgcn_s_barrier();
+        const long long u3 = now();
+        fence();
+
+        // ---- matrix segment M(t+1), in issue order, one fenced step per MFMA.
+        // QK^T of tile t+1 (clamped: the last one is computed twice and dropped): K fragments were prefetched; behind each MFMA
+        // the V^T fragment of tile t for the matching P.V step and two v_cvt_pk of P.
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            st[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[i], qf[i >> 1], i < 2 ? negm16 : st[i & 1], 0, 0, 0);
+            vf[i] = v_frag(t, i);
+            // P values 4i .. 4i+3: pk[s] element e = pp[s >> 1][(s & 1) * 8 + e]
+            const int s = i >> 1, kb = s >> 1, r0 = (s & 1) * 8 + (i & 1) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[s][(i & 1) * 4 + e] = (__bf16)pp[kb][r0 + e];
+            fence();
+        }
+        // P.V of tile t; behind the MFMAs the K fragments of tile t+2
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            ot[i & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[i], pk[i >> 1], ot[i & 1], 0, 0, 0);
+            kf[i] = k_frag(min(t + 2, nt - 1), i);
+            fence();
+        }
+        dma_k(t + 4);
+        dma_v(t + 2);
+        __builtin_amdgcn_s_setprio(0);
+        fence();
+        const long long u4 = now();
+        __builtin_amdgcn_s_barrier();
+        const long long u5 = now();
+        fence();
+        if (ACCT) {
+            tacc[0] += u1 - u0;  // softmax segment
+            tacc[1] += u2 - u1;  // vmcnt(0)
+            tacc[2] += u3 - u2;  // barrier after S
+            tacc[3] += u4 - u3;  // matrix segment
+            tacc[4] += u5 - u4;  // barrier after M
+        }
+    }
+#ifdef S2V_DIAG
+    if (ACCT) {
+        tacc[5] = now() - tl0;
+        if (blockIdx.x == 100 && lane == 0)
+            for (int e = 0; e < 6; ++e) g_attn_dbg[wave * 8 + e] = tacc[e];
+    }
+#endif
+    if (!grp) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    // A lane holds dims 8g + 4hi .. + 3 of its row for the eight groups g: one half-wave exchange per pair of groups (g, g + 1)
+    // gives the lower half 16 contiguous bytes of group g and the upper half those of group g + 1 -> 4 x 16-B stores per lane
+    // instead of 8 x 8-B (the store tail of a block is issue-bound)
+    u32x2 og[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int db = g >> 2, rq = g & 3;
+        og[g].x = pack2bf(ot[db][rq * 4 + 0] * inv, ot[db][rq * 4 + 1] * inv);
+        og[g].y = pack2bf(ot[db][rq * 4 + 2] * inv, ot[db][rq * 4 + 3] * inv);
+    }
+    bf16_t* o = (bf16_t*)a.out + (size_t)(b * a.Ntok + min(q_row, a.Ntok - 1)) * a.ld_out + h * 64 + hi * 8;
+#pragma unroll
+    for (int g = 0; g < 8; g += 2) {
+        const auto rx = __builtin_amdgcn_permlane32_swap(og[g].x, og[g + 1].x, false, false);
+        const auto ry = __builtin_amdgcn_permlane32_swap(og[g].y, og[g + 1].y, false, false);
+        u32x4 v = {rx[0], ry[0], rx[1], ry[1]};
+        if (q_row < a.Ntok) *(u32x4*)(o + 8 * g) = v;
+    }
+}
+
+#ifdef S2V_DIAG
+int g_attn_variant = 0;  // 0 = product kernel, 1 = product kernel with stall accounting, 2 = round-1 lock-step kernel (A/B reference)
 extern "C" int s2v_set_attn_variant(int v) { g_attn_variant = v; return 0; }
+#endif
 
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
     S2V_REQUIRE(a.vt != nullptr, "attn_bf16: V^T buffer missing");
     S2V_REQUIRE(a.ld_qkv % 8 == 0 && a.ntok_pad % 64 == 0, "attn_bf16: bad leading dims");
     S2V_REQUIRE(a.ntok_pad >= ((a.Ntok + 63) / 64) * 64, "attn_bf16: ntok_pad too small");
-    const int nqb = (a.Ntok + Q_BLOCK - 1) / Q_BLOCK;
-    const int grid = nqb * a.B * a.H;
-    // default: eight waves (256 query rows) per block -- each thread moves one K and one V^T piece per KV tile, half the
-    // LDS-DMA issue work per wave of the four-wave form (measured +2 % at C3); variants are diagnostics (tools/ablate_attn.py)
-    const int nqb8 = (a.Ntok + 255) / 256;
+    const int nqb8 = (a.Ntok + 255) / 256;  // eight waves x 32 query rows per block
     const dim3 g8(nqb8 * a.B * a.H), b8(512);
-    switch (g_attn_variant) {
-        case 1: hipLaunchKernelGGL((attn_bf16_k<1, 8>), g8, b8, 4 * ATT_TILE_BYTES, st, a, nqb8); break;
-        case 2: hipLaunchKernelGGL((attn_bf16_k<2, 8>), g8, b8, 4 * ATT_TILE_BYTES, st, a, nqb8); break;
-        case 3: hipLaunchKernelGGL((attn_bf16_k<3, 8>), g8, b8, 4 * ATT_TILE_BYTES, st, a, nqb8); break;
-        case 4: hipLaunchKernelGGL((attn_bf16_k<0, 4>), dim3(grid), dim3(256), 4 * ATT_TILE_BYTES, st, a, nqb); break;
-        default: hipLaunchKernelGGL((attn_bf16_k<0, 8>), g8, b8, 4 * ATT_TILE_BYTES, st, a, nqb8); break;
-    }
-    S2V_CHECK_HIP(hipGetLastError());
+    const void* fn = (const void*)attn_pp_k<false>;
+    size_t lds = 65536;
+#ifdef S2V_DIAG
+    if (g_attn_variant == 1) fn = (const void*)attn_pp_k<true>;
+    if (g_attn_variant == 2) { fn = (const void*)attn_bf16_k<0, 8>; lds = 4 * ATT_TILE_BYTES; }
+#endif
+    S2V_TRY(ensure_lds_attr(fn, 65536));
+    void* args[] = {(void*)&a, (void*)&nqb8};
+    S2V_CHECK_HIP(hipLaunchKernel(fn, g8, b8, args, lds, st));
     return 0;
 }
 

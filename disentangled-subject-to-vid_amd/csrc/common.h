@@ -85,6 +85,22 @@ int s2v_fail(const char* file, int line, const char* msg, int code);
     do {                                                                             \
         if (!(cond)) return s2v_fail(__FILE__, __LINE__, msg, -1);                   \
     } while (0)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): the attribute is per device, and a process may
+// drive several GPUs (transformer on one, VAE / T5 on another)
+#include <mutex>
+#include <set>
+#include <utility>
+static inline int ensure_lds_attr(const void* fn, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    S2V_CHECK_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({fn, dev})) return 0;
+    S2V_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.insert({fn, dev});
+    return 0;
+}
 #define S2V_TRY(expr)                                                                \
     do {                                                                             \
         int _r = (expr);                                                             \

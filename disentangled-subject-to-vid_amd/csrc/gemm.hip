@@ -817,11 +817,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
 template <int EPI>
 static int launch_pp64_t(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_pp64<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
-        attr_set = true;
-    }
+    S2V_TRY(ensure_lds_attr((const void*)gemm_bf16_pp64<EPI>, 131072));
     if (EPI == EPI_BIAS && a.ablate) {  // diagnostics only (tools/ablate_gemm.py)
         const void* fn = a.ablate == 1 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 1> : a.ablate == 4 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 4> : a.ablate == 5 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 5> : a.ablate == 6 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 6> : a.ablate == 7 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 7> : (const void*)gemm_bf16_pp64<EPI_BIAS, 3>;
         S2V_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -837,11 +833,7 @@ static int launch_pp64_t(const GemmArgs& a, hipStream_t st) {
 template <int EPI>
 static int launch_w8_t(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_w8<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, WH_NST * WH_STAGE));
-        attr_set = true;
-    }
+    S2V_TRY(ensure_lds_attr((const void*)gemm_bf16_w8<EPI>, WH_NST * WH_STAGE));
     hipLaunchKernelGGL(gemm_bf16_w8<EPI>, dim3(tiles_m * tiles_n), dim3(512), WH_NST * WH_STAGE, st, a, tiles_m, tiles_n);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
@@ -850,11 +842,7 @@ static int launch_w8_t(const GemmArgs& a, hipStream_t st) {
 template <int EPI>
 static int launch_stag_t(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + RBM - 1) / RBM, tiles_n = (a.N + RBN - 1) / RBN;
-    static bool attr_set = false;
-    if (!attr_set) {
-        S2V_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_bf16_stag<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * RSTAGE));
-        attr_set = true;
-    }
+    S2V_TRY(ensure_lds_attr((const void*)gemm_bf16_stag<EPI>, 3 * RSTAGE));
     hipLaunchKernelGGL(gemm_bf16_stag<EPI>, dim3(tiles_m * tiles_n), dim3(512), 3 * RSTAGE, st, a, tiles_m, tiles_n);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;

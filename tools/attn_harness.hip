@@ -1,0 +1,167 @@
+// Stand-alone A/B harness for the attention kernels of libs2v_hip_diag.so (no torch: starts in a second on a fresh GPU box).
+//   variants: 0 = product kernel (attn_pp_k), 1 = the same with stall accounting, 2 = round-1 lock-step kernel
+//   checks: every variant against attn_simple_k (fp32 math on the same bf16 inputs) on small / ragged shapes, with rare
+//           outliers and with a block of keys whose scores jump by ~+40 at a late tile (forces the deferred-maximum slow
+//           path after O and l have accumulated), and against the first variant at full size;
+//   times:  interleaved rounds at the C3 shape (B = 2, H = 48, N = 19126).
+// Build:  python disentangled-subject-to-vid_amd/build.py --diag && hipcc --offload-arch=gfx950 -O3 -o tools/attn_harness tools/attn_harness.hip \
+//             -Ldisentangled-subject-to-vid_amd -ls2v_hip_diag -Wl,-rpath,'$ORIGIN/../disentangled-subject-to-vid_amd'
+// Run:    tools/attn_harness [variants, e.g. 0,2] [rounds]
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+extern "C" {
+int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype, int32_t impl, void* stream);
+int s2v_set_attn_variant(int v);
+int s2v_attn_debug_read(long long* out);
+const char* s2v_last_error(void);
+}
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+#define S2(x) do { if ((x) != 0) { printf("s2v error: %s (line %d)\n", s2v_last_error(), __LINE__); exit(1); } } while (0)
+
+__global__ void fill_k(unsigned short* p, size_t n, unsigned seed, float scale, float spike) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned x = (unsigned)(i * 2654435761u) ^ seed;
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        unsigned y = x * 747796405u + 2891336453u; y ^= y >> 13;
+        // sum of 4 uniforms ~ normal-ish, full sign range
+        float u = ((x & 0xffff) + (x >> 16) + (y & 0xffff) + (y >> 16)) * (1.0f / 65536.0f) - 2.0f;
+        float v = u * 1.7320508f * scale;
+        if (spike != 0.f && (x % 9973u) == 0) v *= spike;  // rare outliers exercise the rescale branch
+        p[i] = __builtin_bit_cast(unsigned short, (__bf16)v);
+    }
+}
+// keys [k0, k0 + nk) of every (b, h) := g * (query row r0 of the same head): their scores against the rows that resemble r0 jump
+__global__ void jump_k(unsigned short* qkv, int B, int H, int N, int k0, int nk, int r0, float g) {
+    const int D = H * 64;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H * nk * 64) return;
+    const int d = i & 63, k = (i >> 6) % nk, bh = (i >> 6) / nk, h = bh % H, b = bh / H;
+    const size_t rowq = (size_t)(b * N + r0) * 3 * D, rowk = (size_t)(b * N + k0 + k) * 3 * D;
+    const unsigned u = (unsigned)qkv[rowq + h * 64 + d] << 16;
+    const float q = __builtin_bit_cast(float, u);
+    qkv[rowk + D + h * 64 + d] = __builtin_bit_cast(unsigned short, (__bf16)(q * g));
+}
+static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+struct Bufs { unsigned short *qkv, *vt, *out; int B, H, N; size_t n_out; };
+static Bufs make(int B, int H, int N, float scale, float spike) {
+    Bufs b{}; b.B = B; b.H = H; b.N = N;
+    const int D = H * 64;
+    const size_t nq = ((size_t)B * N + 256) * 3 * D;
+    CK(hipMalloc(&b.qkv, nq * 2));
+    CK(hipMalloc(&b.vt, (size_t)B * H * 64 * ((N + 63) / 64 * 64) * 2));
+    b.n_out = (size_t)B * N * D;
+    CK(hipMalloc(&b.out, b.n_out * 2));
+    fill_k<<<4096, 256>>>(b.qkv, nq, 12345u + N, scale, spike);
+    CK(hipDeviceSynchronize());
+    return b;
+}
+static void release(Bufs& b) { CK(hipFree(b.qkv)); CK(hipFree(b.vt)); CK(hipFree(b.out)); }
+static void run(const Bufs& b, int variant, int impl = 0) {
+    s2v_set_attn_variant(variant);
+    S2(s2v_op_attention(b.qkv, b.vt, b.out, b.B, b.H, b.N, 1, impl, nullptr));
+}
+static std::vector<unsigned short> fetch(const Bufs& b) {
+    std::vector<unsigned short> h(b.n_out);
+    CK(hipMemcpy(h.data(), b.out, b.n_out * 2, hipMemcpyDeviceToHost));
+    return h;
+}
+
+int main(int argc, char** argv) {
+    std::vector<int> vars;
+    {
+        const char* s = argc > 1 ? argv[1] : "0,2";
+        char* dup = strdup(s);
+        for (char* tok = strtok(dup, ","); tok; tok = strtok(nullptr, ",")) vars.push_back(atoi(tok));
+    }
+    const int rounds = argc > 2 ? atoi(argv[2]) : 5;
+    int bad = 0;
+    // ---- correctness on small / ragged shapes against the fp32-math kernel
+    const int shapes[][3] = {{1, 2, 1250}, {2, 3, 64}, {1, 1, 65}, {1, 2, 700}, {2, 2, 19126 / 8}, {1, 1, 257}};
+    for (auto& sh : shapes) {
+        for (float spike : {0.f, 6.f, -1.f}) {
+            if (spike < 0.f && sh[2] < 600) continue;
+            Bufs b = make(sh[0], sh[1], sh[2], 1.0f, spike < 0.f ? 0.f : spike);
+            if (spike < 0.f) {  // late jump: 40 keys from key 5/8 N on score ~ +5 |q_r0|^2 / 8 against row r0 (and its like)
+                const int k0 = sh[2] * 5 / 8, nk = 40, r0 = 17;
+                jump_k<<<(sh[0] * sh[1] * nk * 64 + 255) / 256, 256>>>(b.qkv, sh[0], sh[1], sh[2], k0, nk, r0, 5.0f);
+                CK(hipDeviceSynchronize());
+            }
+            CK(hipMemset(b.out, 0, b.n_out * 2));
+            run(b, 0, 1);  // impl 1: attn_simple_k
+            CK(hipDeviceSynchronize());
+            auto ref = fetch(b);
+            for (int v : vars) {
+                CK(hipMemset(b.out, 0xff, b.n_out * 2));
+                run(b, v);
+                CK(hipDeviceSynchronize());
+                auto got = fetch(b);
+                double maxd = 0, maxr = 0;
+                for (size_t i = 0; i < ref.size(); ++i) {
+                    const float r = bf2f(ref[i]), g = bf2f(got[i]);
+                    if (!(std::isfinite(g))) { maxd = 1e30; break; }
+                    maxd = std::max(maxd, (double)fabsf(r - g));
+                    maxr = std::max(maxr, (double)fabsf(r));
+                }
+                const bool ok = maxd <= 2e-2 * std::max(1.0, maxr);
+                if (!ok) ++bad;
+                printf("check B=%d H=%d N=%5d spike=%g variant %2d: max|diff| %.3e (max|ref| %.2f) %s\n", sh[0], sh[1], sh[2], spike, v, maxd, maxr, ok ? "ok" : "FAIL");
+            }
+            release(b);
+        }
+    }
+    // ---- full size: bitwise against the first variant, then interleaved timing
+    {
+        const int B = 2, H = 48, N = 19126;
+        Bufs b = make(B, H, N, 1.0f, 0.f);
+        std::vector<unsigned short> ref;
+        for (size_t vi = 0; vi < vars.size(); ++vi) {
+            CK(hipMemset(b.out, 0xff, b.n_out * 2));
+            run(b, vars[vi]);
+            CK(hipDeviceSynchronize());
+            auto got = fetch(b);
+            if (vi == 0) ref = got;
+            else {
+                size_t nd = 0; double maxd = 0;
+                for (size_t i = 0; i < ref.size(); ++i) if (ref[i] != got[i]) { ++nd; maxd = std::max(maxd, (double)fabsf(bf2f(ref[i]) - bf2f(got[i]))); }
+                printf("full size variant %2d vs variant %2d: %zu / %zu words differ (max |diff| %.3e) %s\n", vars[vi], vars[0], nd, ref.size(), maxd, nd == 0 ? "bit-identical" : "");
+                if (maxd > 2e-2) ++bad;
+            }
+        }
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        std::vector<std::vector<float>> ms(vars.size());
+        const double fl = 4.0 * B * H * (double)N * N * 64;
+        for (int r = 0; r < rounds; ++r)
+            for (size_t vi = 0; vi < vars.size(); ++vi) {
+                s2v_set_attn_variant(vars[vi]);
+                run(b, vars[vi]);  // warm
+                CK(hipEventRecord(e0));
+                for (int k = 0; k < 3; ++k) run(b, vars[vi]);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float t; CK(hipEventElapsedTime(&t, e0, e1));
+                ms[vi].push_back(t / 3);
+            }
+        for (size_t vi = 0; vi < vars.size(); ++vi) {
+            if (vars[vi] == 1) {  // stall accounting
+                run(b, vars[vi]); CK(hipDeviceSynchronize());
+                long long d[64]; s2v_attn_debug_read(d);
+                const double nt = (N + 63) / 64;
+                printf("variant %d: cycles per KV tile per wave [softmax seg | vmcnt | barrier after S | matrix seg | barrier after M | loop total]\n", vars[vi]);
+                for (int w = 0; w < 8; ++w) printf("   wave %d: %7.1f %7.1f %7.1f %7.1f %7.1f | %7.1f\n", w, d[w * 8] / nt, d[w * 8 + 1] / nt, d[w * 8 + 2] / nt, d[w * 8 + 3] / nt, d[w * 8 + 4] / nt, d[w * 8 + 5] / nt);
+            }
+            std::sort(ms[vi].begin(), ms[vi].end());
+            const float med = ms[vi][ms[vi].size() / 2], mn = ms[vi][0];
+            printf("time variant %2d (incl. V^T transpose ~0.1 ms): median %.3f ms  min %.3f ms  -> %.0f TFLOP/s (median)\n", vars[vi], med, mn, fl / med / 1e9);
+        }
+        release(b);
+    }
+    printf(bad ? "HARNESS: %d FAILURES\n" : "HARNESS: all checks ok\n", bad);
+    return bad ? 1 : 0;
+}
