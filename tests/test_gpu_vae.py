@@ -91,7 +91,34 @@ def test_vae_mfma_channels_vs_oracle(s2v, dt_name, simple, tiling):
         assert err <= 1e-3, err
     else:
         rel = ((y - exp).double().norm() / exp.double().norm()).item()
-        assert rel <= 3e-2 and err <= 0.15 * exp.abs().max().item(), (rel, err)
+        assert rel <= 3e-2 and err <= 6e-2 * exp.abs().max().item(), (rel, err)
+
+
+REAL = dict(block_out_channels=(128, 256, 256, 512), layers_per_block=3, norm_num_groups=32, latent_channels=16,
+            sample_height=480, sample_width=720, scaling_factor=0.7, temporal_compression_ratio=4)
+
+
+@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+def test_vae_real_width_decoder_vs_oracle(s2v, dt_name):
+    """the decoder the checkpoints ship -- (128, 256, 256, 512) channels, 3 resnets per block, 32 groups
+    (autoencoder_kl_cogvideox.py:921-981) -- on a small latent (3 x 8 x 12 -> 9 frames 64 x 96), against the fp32 oracle"""
+    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    cfg = s2v.VAEConfig(**REAL)
+    sd = {k: v.to(dt).float() for k, v in s2v.weights.synthetic_vae_state_dict(cfg, seed=61).items()}
+    lat = torch.randn(1, 3, 16, 8, 12, generator=torch.Generator().manual_seed(62)).to(dt).float()
+    with torch.no_grad():
+        exp = vae_ref.decode_latents(sd, REAL, lat, False)
+    vae = make_vae(s2v, REAL, dt, sd)
+    y = vae.decode_latents(lat.to(DEV, dt)).float().cpu()
+    torch.cuda.synchronize()
+    assert y.shape == exp.shape == (1, 3, 9, 64, 96)
+    assert torch.isfinite(y).all()
+    err = (y - exp).abs().max().item()
+    if dt_name == "f32":
+        assert err <= 1e-3, err
+    else:
+        rel = ((y - exp).double().norm() / exp.double().norm()).item()
+        assert rel <= 2e-2 and err <= 6e-2 * exp.abs().max().item(), (rel, err)
 
 
 def test_frames_uint8_matches_export_to_video_conversion(s2v):

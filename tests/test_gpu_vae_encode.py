@@ -109,6 +109,30 @@ def test_encode_mfma_width_bf16_vs_oracle(s2v, tiling):
         assert rel <= 3e-2, (simple, rel)
 
 
+@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+def test_encode_real_width_vs_oracle(s2v, dt_name):
+    """the encoder the checkpoints ship -- (128, 256, 256, 512) channels, 3 resnets per block, 32 groups
+    (autoencoder_kl_cogvideox.py:755-814) -- on a 64 x 96 image, against the fp32 oracle"""
+    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    cfgd = dict(block_out_channels=(128, 256, 256, 512), layers_per_block=3, norm_num_groups=32, latent_channels=16,
+                sample_height=480, sample_width=720, scaling_factor=0.7, temporal_compression_ratio=4)
+    cfg = s2v.VAEConfig(**cfgd)
+    sd = {k: v.to(dt).float() for k, v in s2v.weights.synthetic_vae_encoder_state_dict(cfg, seed=71).items()}
+    img = (torch.rand(1, 3, 1, 64, 96, generator=torch.Generator().manual_seed(72)) * 2 - 1).to(dt).float()
+    with torch.no_grad():
+        exp = vae_ref.encode_moments(sd, cfgd, img, False)
+    vae = make_vae(s2v, cfgd, dt, sd)
+    y = vae.encode(img.to(DEV, dt)).latent_dist.parameters.float().cpu()
+    torch.cuda.synchronize()
+    assert y.shape == exp.shape == (1, 32, 1, 8, 12)
+    err = (y - exp).abs().max().item()
+    if dt_name == "f32":
+        assert err <= 1e-3, err
+    else:
+        rel = ((y - exp).norm() / exp.norm()).item()
+        assert rel <= 2e-2 and err <= 6e-2 * exp.abs().max().item(), (rel, err)
+
+
 def test_encode_full_size_determinism(s2v):
     """480 x 720 reference image through the full-width encoder, tiled (9 tiles of <= 240 x 360): finite, the right shape,
     and bit-identical across two runs (deterministic GroupNorm reductions)."""
