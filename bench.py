@@ -6,7 +6,8 @@
 
 One "step" = one iteration of the denoise loop of src/custom_cogvideox_pipe.py:241-296 on one video: the B=2 (CFG pair)
 transformer forward + fp32 CFG + DDIM scheduler step + round to bf16, all inside libs2v_hip.so, inputs resident in
-HBM.  Workload (BASELINE.json metric): CogVideoX-5B, 49 frames 480x720 -> latents 13x60x90, N = 226+1350+17550 tokens,
+HBM; the timed region replays it from ONE captured hipGraph (--graph 1, default) and carries no profiling; the eager time and
+the per-kernel HIP-event durations come from separate passes after it.  Workload (BASELINE.json metric): CogVideoX-5B, 49 frames 480x720 -> latents 13x60x90, N = 226+1350+17550 tokens,
 bf16, synthetic seeded weights (no checkpoints offline).  N > 1: independent replicas, one prompt per GPU, weights
 broadcast once rank0 -> all over RCCL before the timed region; value = total steps/s.
 """
@@ -52,43 +53,55 @@ def load_synthetic(s2v, eng, cfg, seed):
     torch.cuda.synchronize()
 
 
-def cpu_baseline(cfg, F, H, W, T, budget_s=60.0):
+def cpu_baseline(s2v, cfg, F, H, W, T, dev):
     """the oracle (CPU restatement, torch fp32, all host cores) timed on a bounded sample: ONE transformer block for
-    ONE of the two CFG samples at the full token count, extrapolated x2 x num_layers."""
+    ONE of the two CFG samples at the full token count, extrapolated x2 x num_layers.  The block's output is then compared with
+    the HIP path (bf16, s2v_block_forward) on the same bf16-rounded weights and inputs: the oracle is the checker here."""
+    import copy
+
     from oracle import transformer_ref as tr
 
     cores = os.cpu_count() or 1
     torch.set_num_threads(cores)
-    D, heads = cfg.inner_dim, cfg.num_attention_heads
+    c1 = copy.copy(cfg)
+    c1.num_layers = 1
+    D, heads = c1.inner_dim, c1.num_attention_heads
     R = (H // 2) * (W // 2)
     V = F * R
-    g = torch.Generator().manual_seed(0)
-    sd = {}
-    p = "transformer_blocks.0."
-    for k, shp in importlib.import_module("disentangled-subject-to-vid_amd").weights.state_dict_shapes(cfg).items():
-        if k.startswith(p):
-            sd[k] = torch.randn(shp, generator=g) * 0.02 if len(shp) >= 2 else torch.zeros(shp)
-    for n in ("norm1", "norm2"):
-        sd[p + n + ".norm.weight"] = torch.ones(D)
-    sd[p + "attn1.norm_q.weight"] = torch.ones(64)
-    sd[p + "attn1.norm_k.weight"] = torch.ones(64)
-    h, e0, e1 = torch.randn(1, V, D, generator=g), torch.randn(1, T, D, generator=g), torch.randn(1, R, D, generator=g)
-    temb = torch.randn(1, cfg.time_embed_dim, generator=g)
+    dt = torch.bfloat16
+    sd = {k: v.to(dt).float() for k, v in s2v.weights.synthetic_state_dict(c1, seed=21, parity=True).items()}
+    g = torch.Generator().manual_seed(22)
+    h, e0, e1 = (torch.randn(1, n, D, generator=g).to(dt).float() for n in (V, T, R))
+    temb = torch.randn(1, c1.time_embed_dim, generator=g).to(dt).float()
     rope = ref_rope = None
-    if cfg.use_rotary_positional_embeddings:
+    if c1.use_rotary_positional_embeddings:
         ref_rope, rope = tr.pipeline_rope(H * 8, W * 8, F)
     with torch.no_grad():
         t0 = time.time()
-        tr.block_forward(sd, p, heads, h, e0, e1, temb, rope, ref_rope)
-        dt = time.time() - t0
-    step_s = dt * 2 * cfg.num_layers
+        exp = tr.block_forward(sd, "transformer_blocks.0.", heads, h, e0, e1, temb, rope, ref_rope)
+        dts = time.time() - t0
+    m = s2v.HipCogVideoXTransformer3DModel(c1, dt, dev)
+    m.load_state_dict(sd)
+    kw = {}
+    if rope is not None:
+        kw = dict(image_rotary_emb=tuple(x.to(dev) for x in rope), ref_image_rotary_emb=tuple(x.to(dev) for x in ref_rope))
+    got = m.transformer_blocks[0](hidden_states=h.to(dev, dt), encoder_hidden_states=e0.to(dev, dt), temb=temb.to(dev, dt),
+                                  enc_hidden_states1=e1.to(dev, dt), embed_ref_img=True, ref_img_seq_start=T,
+                                  ref_img_seq_end=T + R, position_delta=0, timestep=None, layer=0, **kw)
+    torch.cuda.synchronize()
+    y, e = torch.cat([x.float().cpu().flatten() for x in got]), torch.cat([x.flatten() for x in exp])
+    step_s = dts * 2 * cfg.num_layers
     return {"value": 1.0 / step_s, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"1 of {cfg.num_layers} transformer blocks x 1 of 2 CFG samples at the full token count, torch "
-                      f"fp32 on {cores} threads: {dt:.1f} s, extrapolated x{2 * cfg.num_layers}"}
+                      f"fp32 on {cores} threads: {dts:.1f} s, extrapolated x{2 * cfg.num_layers}",
+            "max_abs_vs_hip": round((y - e).abs().max().item(), 5), "rel_l2_vs_hip": round(((y - e).norm() / e.norm()).item(), 6),
+            "max_abs_ref": round(e.abs().max().item(), 3),
+            "vs_hip_note": "the same block through s2v_block_forward in bf16 on the same bf16-rounded weights / inputs"}
 
 
-KERNEL_OF_CLASS = {"attention": "attn_bf16_k", "gemm_qkv": "gemm_bf16_w8<0>", "gemm_ff1_gelu": "gemm_bf16_w8<1>",
-                   "gemm_out": "gemm_bf16_w8<2>", "gemm_ff2": "gemm_bf16_w8<2>"}
+# kernel names as rocprofv3 prints them (template arguments included)
+KERNEL_OF_CLASS = {"attention": "attn_pp_k<false>", "gemm_qkv": "gemm_bf16_pp64<0>", "gemm_ff1_gelu": "gemm_bf16_pp64<1>",
+                   "gemm_out": "gemm_bf16_pp64<2>", "gemm_ff2": "gemm_bf16_pp64<2>"}
 
 
 def pmc_traffic_bytes(kernel_class):
@@ -105,10 +118,13 @@ def pmc_traffic_bytes(kernel_class):
         return None
 
     def mean_kb(path):
+        tot = cnt = 0.0
         for row in csv.reader(open(path)):
-            if row and row[0].split("<")[0] == name:  # template arguments are part of the profiled name
-                return float(row[2])
-        return None
+            got = row[0].replace("void ", "").replace(", 0>", ">").replace(" ", "") if row else ""
+            if got == name.replace(" ", ""):  # default template arguments and the return type are printed too
+                tot += float(row[2]) * float(row[1])
+                cnt += float(row[1])
+        return tot / cnt if cnt else None
 
     f, w = mean_kb(fetch[-1]), mean_kb(write[-1])
     if f is None or w is None:
@@ -122,7 +138,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cogvideox-5b-49x480x720", choices=sorted(WORKLOADS))
-    ap.add_argument("--graph", type=int, default=0, help="replay the step from a captured hipGraph")
+    ap.add_argument("--graph", type=int, default=1, help="timed region replays the step from a captured hipGraph (north_star); 0 = eager launches")
+    ap.add_argument("--single-mode", action="store_true", help="skip the pass in the other launch mode (rocprofv3 runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the one-off VAE decode timing")
@@ -168,34 +185,51 @@ def main():
     sch.set_timesteps(50)
     coefs = [sch.coef(t, dt, 6.0) for t in sch.timesteps]
 
-    def step(i):
-        eng.denoise_step(latents, float(sch.timesteps[i % 50]), coefs[i % 50], use_graph=bool(args.graph))
+    def step(i, graph):
+        eng.denoise_step(latents, float(sch.timesteps[i % 50]), coefs[i % 50], use_graph=graph)
 
-    for i in range(args.warmup):
-        step(i)
-    profile = (not args.no_roofline) and not args.graph
-    if profile:
-        s2v._lib.check(s2v.lib().s2v_profile_enable(eng._h, 1))
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = tt.item()
+    def timed(graph, nsteps, nwarm):
+        """W untimed + K timed steps between barrier + synchronize on both sides; max over ranks"""
+        for i in range(nwarm):
+            step(i, graph)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for i in range(nsteps):
+            step(nwarm + i, graph)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = tt.item()
+        return el
+
+    # ---- the timed region of the contract: no event recording, no profiling inside it
+    elapsed = timed(bool(args.graph), args.steps, args.warmup)
     finite = bool(torch.isfinite(latents.float()).all().item())
+    # ---- the other launch mode, timed the same way (beside the metric, not in it)
+    other_steps = min(args.steps, 5)
+    other = None if args.single_mode else timed(not bool(args.graph), other_steps, 1)
+    this_ms, other_ms = elapsed / args.steps * 1e3, None if other is None else other / other_steps * 1e3
+    graph_ms, eager_ms = (this_ms, other_ms) if args.graph else (other_ms, this_ms)
 
+    # ---- per-kernel durations: a SEPARATE eager pass with HIP events around every launch on the launch stream
     roofline = None
-    if profile:
+    if not args.no_roofline:
         import ctypes
 
+        prof_steps = min(args.steps, 3)
+        s2v._lib.check(s2v.lib().s2v_profile_enable(eng._h, 1))
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for i in range(prof_steps):
+            step(i, False)
+        torch.cuda.synchronize()
+        prof_elapsed = time.perf_counter() - tp
         ms = (ctypes.c_float * 8)()
         cnt = (ctypes.c_int32 * 8)()
         s2v._lib.check(s2v.lib().s2v_profile_read(eng._h, ms, cnt, 8))
@@ -209,7 +243,7 @@ def main():
             if cnt[k] == 0:
                 continue
             avg = ms[k] / cnt[k]
-            e = {"avg_ms": round(avg, 4), "launches": int(cnt[k]), "share_of_step": round(ms[k] / (elapsed * 1e3), 4)}
+            e = {"avg_ms": round(avg, 4), "launches": int(cnt[k]), "share_of_step": round(ms[k] / (prof_elapsed * 1e3), 4)}
             if name in flops:
                 e["tflops"] = round(flops[name] / avg / 1e9, 1)
             per_kernel[name] = e
@@ -219,6 +253,7 @@ def main():
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic_bytes(dom),
                     "traffic_unit": "bytes/launch (profiles/rNN_pmc_{fetch,write}.csv, FETCH_SIZE x2 per MI355X_MICROARCH)",
                     "algorithmic_flops_per_launch": flops[dom], "avg_launch_ms": per_kernel[dom]["avg_ms"],
+                    "measured": f"HIP events on the launch stream in a separate eager pass of {prof_steps} steps after the timed region",
                     "per_kernel": per_kernel}
 
     video = None
@@ -285,14 +320,16 @@ def main():
             "dtype": "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
             "config": {"workload": args.workload, "latent_frames": F, "latent_hw": [H, W], "tokens": T + (F + 1) * (H // 2) * (W // 2),
                        "cfg_pair": 2, "scheduler": "ddim-trailing-50", "parallelism": f"replicas x{args.gpus}",
-                       "hipgraph": bool(args.graph), "per_gpu_steps_per_s": round(args.steps / elapsed, 4),
+                       "hipgraph": bool(args.graph), "graph_ms_per_step": None if graph_ms is None else round(graph_ms, 2),
+                       "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 2),
+                       "per_gpu_steps_per_s": round(args.steps / elapsed, 4),
                        "weight_load_s": round(t_load, 2), "weight_broadcast_s": None if bcast_s is None else round(bcast_s, 3),
                        "outputs_finite": finite},
             "roofline": roofline,
             "wall_clock_per_video": video,
         }
         if not args.no_cpu_baseline and args.gpus == 1:
-            out["cpu_baseline"] = cpu_baseline(cfg, F, H, W, T)
+            out["cpu_baseline"] = cpu_baseline(s2v, cfg, F, H, W, T, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

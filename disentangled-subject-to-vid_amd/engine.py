@@ -37,6 +37,9 @@ class S2VEngine:
         _lib.check(_lib.lib().s2v_create(ctypes.byref(c), ctypes.byref(self._h)))
         self.geometry = None
         self._keep = []
+        # bumped by every write of the engine-side RoPE / positional table ("rope") and conditioning ("cond"): the seam
+        # adapters' caches (transformer._Cache) are valid only for the epoch they were stored at
+        self.epoch = {"rope": 0, "cond": 0}
 
     def close(self):
         if self._h:
@@ -87,9 +90,18 @@ class S2VEngine:
         _lib.check(_lib.lib().s2v_mark_weights_loaded(self._h))
 
     # ---- geometry / tables / conditioning ----------------------------------------------------------------------
+    def _bump(self, *kinds):
+        for k in kinds:
+            self.epoch[k] += 1
+
     def set_geometry(self, B, T, F, H, W):
         _lib.check(_lib.lib().s2v_set_geometry(self._h, B, T, F, H, W))
         self.geometry = (B, T, F, H, W)
+        self._bump("rope", "cond")
+
+    def clear_rope(self):
+        _lib.check(_lib.lib().s2v_set_rope(self._h, None, None, _lib.stream_ptr()))
+        self._bump("rope")
 
     def set_rope(self, cos, sin):
         cos = cos.to(self.device, torch.float32).contiguous()
@@ -100,11 +112,13 @@ class S2VEngine:
             raise _lib.S2VError(f"RoPE tables must be [{n}, 64] ([ref | video] rows)")
         _lib.check(_lib.lib().s2v_set_rope(self._h, _lib.ptr(cos), _lib.ptr(sin), _lib.stream_ptr()))
         torch.cuda.current_stream().synchronize()
+        self._bump("rope")
 
     def set_pos_embed(self, table):
         t = table.to(self.device, self.dtype).contiguous()
         _lib.check(_lib.lib().s2v_set_pos_embed(self._h, _lib.ptr(t), _lib.stream_ptr()))
         torch.cuda.current_stream().synchronize()
+        self._bump("rope")
 
     def prepare_tables(self, height, width):
         """build + upload the step-invariant positional tables for a video of height x width pixels"""
@@ -127,6 +141,7 @@ class S2VEngine:
             raise _lib.S2VError("ref_img_states must be [1,1,C,H,W] with the geometry's H, W")
         _lib.check(_lib.lib().s2v_set_conditioning(self._h, _lib.ptr(text), _lib.ptr(ref), _lib.stream_ptr()))
         torch.cuda.current_stream().synchronize()
+        self._bump("cond")
 
     # ---- compute -------------------------------------------------------------------------------------------
     def forward(self, latents, timesteps, shared_latent=False):

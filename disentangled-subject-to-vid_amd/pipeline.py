@@ -60,6 +60,12 @@ class S2VPipeline:
         if num_frames > 49:
             raise ValueError("The number of frames must be less than or equal to 49 due to static positional embeddings.")
         self.check_inputs(height, width, prompt_embeds, negative_prompt_embeds)
+        if negative_prompt_embeds is None:
+            raise ValueError("Provide `negative_prompt_embeds`: the reference builds them from the empty prompt with its text "
+                             "encoder (pipeline_cogvideox.py:239-318), which is a caller-side step here "
+                             "(video_generate.inference does it)")
+        if ref_img_states is None:
+            raise ValueError("Provide `ref_img_states` (the VAE latent of the reference image, [1, 1, C, H/8, W/8])")
         if prompt_embeds.shape[0] != 1:
             raise RuntimeError("one prompt per call: the transformer duplicates the reference tokens exactly x2 "
                                "(cogvideox_transformer_3d.py:503-504)")

@@ -29,17 +29,28 @@ def _rope_pair(image_rotary_emb, ref_image_rotary_emb, R):
 
 
 class _Cache:
-    """re-upload a table / recompute conditioning only when the caller's tensor changed"""
+    """re-upload a table / recompute conditioning only when the caller's tensor changed.
 
-    def __init__(self):
+    The key holds STRONG references to the tensors (so their storage cannot be freed and handed to a different tensor at the
+    same address) and compares object identity + in-place version; it also records the engine's epoch for its kind of state
+    ("rope" / "cond"), which every S2VEngine.set_rope / set_pos_embed / set_conditioning / set_geometry bumps -- a write that
+    did not go through this cache (the fused pipeline, another seam object sharing the engine) invalidates it."""
+
+    def __init__(self, kind):
+        self.kind = kind
         self.key = None
 
-    def changed(self, *tensors):
-        key = tuple((t.data_ptr(), t._version, tuple(t.shape), t.dtype) if t is not None else None for t in tensors)
-        if key == self.key:
-            return False
-        self.key = key
-        return True
+    def changed(self, engine, *tensors):
+        epoch = engine.epoch[self.kind]
+        k = self.key
+        same = (k is not None and k[0] == epoch and len(k[1]) == len(tensors)
+                and all((a is None and t is None) or (a is not None and t is not None and a[0] is t and a[1] == t._version)
+                        for a, t in zip(k[1], tensors)))
+        return not same
+
+    def store(self, engine, *tensors):
+        """call AFTER the engine was updated: records the post-update epoch"""
+        self.key = (engine.epoch[self.kind], tuple(None if t is None else (t, t._version) for t in tensors))
 
 
 class HipCogVideoXTransformer3DModel:
@@ -53,7 +64,7 @@ class HipCogVideoXTransformer3DModel:
         self.dtype = dtype
         self.device = self.engine.device
         self.qk_replace = False  # set by CustomCogVideoXPipeline.__init__ (custom_cogvideox_pipe.py:41); never read
-        self._rope_cache, self._cond_cache = _Cache(), _Cache()
+        self._rope_cache, self._cond_cache = _Cache("rope"), _Cache("cond")
         self.transformer_blocks = [HipCogVideoXBlock(self.engine, i) for i in range(cfg.num_layers)]
 
     def eval(self):
@@ -88,15 +99,17 @@ class HipCogVideoXTransformer3DModel:
         T = encoder_hidden_states.shape[1]
         if eng.geometry != (B, T, F, H, W):
             eng.set_geometry(B, T, F, H, W)
-            self._rope_cache.key = self._cond_cache.key = None
             if not use_rope:
                 eng.prepare_tables(H * 8, W * 8)  # the reference rebuilds this table on every forward (:433-446)
         if image_rotary_emb is not None:
             ref = ref_image_rotary_emb
-            if self._rope_cache.changed(image_rotary_emb[0], image_rotary_emb[1], None if ref is None else ref[0]):
+            key = (image_rotary_emb[0], image_rotary_emb[1], None if ref is None else ref[0], None if ref is None else ref[1])
+            if self._rope_cache.changed(eng, *key):
                 eng.set_rope(*_rope_pair(image_rotary_emb, ref, (H // 2) * (W // 2)))
-        if self._cond_cache.changed(encoder_hidden_states, ref_img_states):
+                self._rope_cache.store(eng, *key)
+        if self._cond_cache.changed(eng, encoder_hidden_states, ref_img_states):
             eng.set_conditioning(encoder_hidden_states, ref_img_states)
+            self._cond_cache.store(eng, encoder_hidden_states, ref_img_states)
         t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep] * B)
         out = eng.forward(hidden_states, t.reshape(-1).float())
         if not return_dict:
@@ -111,7 +124,7 @@ class HipCogVideoXBlock:
 
     def __init__(self, engine: S2VEngine, layer: int):
         self.engine, self.layer = engine, layer
-        self._rope_cache = _Cache()
+        self._rope_cache = _Cache("rope")
 
     def __call__(self, hidden_states, encoder_hidden_states, temb, enc_hidden_states1=None, image_rotary_emb=None,
                  embed_ref_img=False, ref_img_seq_start=None, ref_img_seq_end=None, position_delta=None,
@@ -128,14 +141,14 @@ class HipCogVideoXBlock:
         geo = (B, T, V // R, 2, 2 * R)
         if eng.geometry != geo:
             eng.set_geometry(*geo)
-            self._rope_cache.key = None
         if image_rotary_emb is not None:
             ref = ref_image_rotary_emb if embed_ref_img else None
-            if self._rope_cache.changed(image_rotary_emb[0], image_rotary_emb[1], None if ref is None else ref[0]):
+            key = (image_rotary_emb[0], image_rotary_emb[1], None if ref is None else ref[0], None if ref is None else ref[1])
+            if self._rope_cache.changed(eng, *key):
                 eng.set_rope(*_rope_pair(image_rotary_emb, ref, R))
+                self._rope_cache.store(eng, *key)
         else:
-            _lib.check(_lib.lib().s2v_set_rope(eng._h, None, None, _lib.stream_ptr()))
-            self._rope_cache.key = None
+            eng.clear_rope()
         return eng.block_forward(self.layer, hidden_states, encoder_hidden_states, enc_hidden_states1, temb)
 
     forward = __call__
@@ -164,7 +177,7 @@ class HipCogVideoXAttnProcessor2_0:
                 eng.load_weight(p + name + ".bias", mod.bias.detach())
             torch.cuda.synchronize()
             eng.mark_weights_loaded()  # only attn1 is used through s2v_attn_forward
-            self._engines[key] = (eng, _Cache())
+            self._engines[key] = (eng, _Cache("rope"), attn)  # the module is kept alive: id(attn) stays unique
         return self._engines[key]
 
     def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask=None, image_rotary_emb=None,
@@ -182,18 +195,18 @@ class HipCogVideoXAttnProcessor2_0:
             raise NotImplementedError("the fork always calls with embed_ref_img=True and the reference-image tokens at "
                                       "the tail of encoder_hidden_states (cogvideox_transformer_3d.py:510-512)")
         T, R = ref_img_seq_start, ref_img_seq_end - ref_img_seq_start
-        eng, cache = self._engine_for(attn, hidden_states.dtype, hidden_states.device)
+        eng, cache, _ = self._engine_for(attn, hidden_states.dtype, hidden_states.device)
         geo = (B, T, V // R, 2, 2 * R)
         if V % R != 0:
             raise RuntimeError("video tokens must be a whole number of frames of the reference image's token count")
         if eng.geometry != geo:
             eng.set_geometry(*geo)
-            cache.key = None
         if image_rotary_emb is not None:
-            if cache.changed(image_rotary_emb[0], image_rotary_emb[1],
-                             None if ref_image_rotary_emb is None else ref_image_rotary_emb[0]):
-                eng.set_rope(*_rope_pair(image_rotary_emb, ref_image_rotary_emb, R))
+            ref = ref_image_rotary_emb
+            key = (image_rotary_emb[0], image_rotary_emb[1], None if ref is None else ref[0], None if ref is None else ref[1])
+            if cache.changed(eng, *key):
+                eng.set_rope(*_rope_pair(image_rotary_emb, ref, R))
+                cache.store(eng, *key)
         else:
-            _lib.check(_lib.lib().s2v_set_rope(eng._h, None, None, _lib.stream_ptr()))
-            cache.key = None
+            eng.clear_rope()
         return eng.attn_forward(0, hidden_states, encoder_hidden_states)

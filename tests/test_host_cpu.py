@@ -143,3 +143,35 @@ def test_weight_key_inventory(s2v):
     g = load_golden("transformer_tiny_rope.npz")
     gk = {k[2:] for k in g if k.startswith("w:")}
     assert gk == set(s2v.weights.state_dict_shapes(s2v.tiny()))
+
+
+def test_seam_cache_keys_on_identity_version_and_engine_epoch():
+    """transformer._Cache: a new tensor (even at a recycled address), an in-place edit, or a write to the engine from outside
+    the cache (epoch bump) all invalidate; the cached tensors are kept alive so that their addresses cannot be recycled"""
+    import importlib
+    import weakref
+
+    tm = importlib.import_module("disentangled-subject-to-vid_amd.transformer")
+
+    class FakeEngine:
+        def __init__(self):
+            self.epoch = {"rope": 0, "cond": 0}
+
+    e, c = FakeEngine(), tm._Cache("cond")
+    a, b = torch.zeros(3), torch.zeros(3)
+    assert c.changed(e, a, b)
+    c.store(e, a, b)
+    assert not c.changed(e, a, b)
+    a.add_(1)
+    assert c.changed(e, a, b)           # in-place edit
+    c.store(e, a, b)
+    assert c.changed(e, torch.zeros(3), b)  # another tensor object with equal shape / dtype
+    e.epoch["cond"] += 1
+    assert c.changed(e, a, b)           # engine state was rewritten behind the cache
+    c.store(e, a, None)
+    assert not c.changed(e, a, None) and c.changed(e, a, b)
+    t = torch.zeros(4)
+    w = weakref.ref(t)
+    c.store(e, t)
+    del t
+    assert w() is not None              # strong reference held by the key

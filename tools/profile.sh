@@ -6,11 +6,11 @@ TAG=${1:-r01}; shift || true
 OUT=gpurun_out/prof_$TAG
 mkdir -p "$OUT/summary"
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-vae $*"
+BENCH="python bench.py --steps 2 --warmup 1 --graph 0 --single-mode --no-cpu-baseline --no-vae $*"
 
-rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
-rocprofv3 --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o fetch -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
-rocprofv3 --pmc WRITE_SIZE -d "$OUT/pmc_write" -o write -- $BENCH > "$OUT/pmc_write.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -o fetch -- $BENCH > "$OUT/pmc_fetch.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -o write -- $BENCH > "$OUT/pmc_write.log" 2>&1
 
 python - "$OUT" "$TAG" <<'EOF'
 import csv, glob, json, os, sys, collections
