@@ -34,7 +34,7 @@ for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     with open(f"{out}/summary/{tag}_{name}.csv", "w") as f:
         f.write(f"kernel,launches,mean_{ctr}_KB_raw,total_{ctr}_KB_raw\n")
         for k, (s, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
-            f.write(f"{k},{n},{s/n:.1f},{s:.1f}\n")
+            f.write(f'"{k}",{n},{s/n:.1f},{s:.1f}\n')
     res[name] = f"{out}/summary/{tag}_{name}.csv"
 print(json.dumps(res))
 EOF
