@@ -147,11 +147,20 @@ struct s2v_t5 {
     int64_t Mpad = 0;
     char *X = nullptr, *Xn = nullptr, *QKV = nullptr, *AO = nullptr, *FF = nullptr, *G = nullptr, *bias = nullptr;
     std::vector<void*> ws_allocs;
+    // every weight lives in ONE arena (s2v_t5_weight_arena: the replica broadcast); sized by a first pass of the plan
+    char* arena = nullptr;
+    int64_t arena_bytes = 0, arena_off = 0;
+    bool sizing = false;
 };
 
 static int64_t rup_(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 static int t5_alloc(s2v_t5* t, char** p, int64_t bytes, bool ws = false) {
+    if (!ws) {  // weight carve-out, 256-byte aligned; the arena is zero-initialised
+        *p = t->sizing ? nullptr : t->arena + t->arena_off;
+        t->arena_off += rup_(bytes > 0 ? bytes : 16, 256);
+        return 0;
+    }
     void* q = nullptr;
     S2V_CHECK_HIP(hipMalloc(&q, (size_t)(bytes > 0 ? bytes : 16)));
     S2V_CHECK_HIP(hipMemset(q, 0, (size_t)(bytes > 0 ? bytes : 16)));
@@ -165,6 +174,7 @@ extern "C" void s2v_t5_destroy(s2v_t5* t) {
     (void)hipDeviceSynchronize();
     for (void* p : t->allocs) (void)hipFree(p);
     for (void* p : t->ws_allocs) (void)hipFree(p);
+    if (t->arena) (void)hipFree(t->arena);
     delete t;
 }
 
@@ -181,46 +191,76 @@ extern "C" int s2v_t5_create(const s2v_t5_config* cfg, s2v_t5** out) {
     t->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
     t->inner = cfg->num_heads * cfg->d_kv;
     t->mfma = cfg->dtype == S2V_DTYPE_BF16 && !cfg->force_simple && cfg->d_model % 64 == 0 && cfg->d_ff % 64 == 0;
-    const int64_t d = cfg->d_model, in = t->inner, F = cfg->d_ff, E = t->esz;
-    int r = t5_alloc(t, &t->shared, (int64_t)cfg->vocab_size * d * E);
-    if (!r) r = t5_alloc(t, &t->final_ln, d * E);
-    if (!r) r = t5_alloc(t, &t->rel_table, (int64_t)cfg->relative_attention_num_buckets * cfg->num_heads * E);
-    t->slots["shared.weight"] = T5Slot{t->shared, cfg->vocab_size, d, false};
-    t->slots["encoder.final_layer_norm.weight"] = T5Slot{t->final_ln, d, 1, false};
-    t->slots["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] =
-        T5Slot{t->rel_table, cfg->relative_attention_num_buckets, cfg->num_heads, false};
-    t->layers.resize(cfg->num_layers);
-    char nm[160];
-    for (int i = 0; i < cfg->num_layers && !r; ++i) {
-        T5Layer& L = t->layers[i];
-        // weight rows padded to the 256-column GEMM tile (zero rows)
-        if (!r) r = t5_alloc(t, &L.ln0, d * E);
-        if (!r) r = t5_alloc(t, &L.wqkv, rup_(3 * in, 256) * d * E);
-        if (!r) r = t5_alloc(t, &L.wo, rup_(d, 256) * in * E);
-        if (!r) r = t5_alloc(t, &L.ln1, d * E);
-        if (!r) r = t5_alloc(t, &L.wi, rup_(2 * F, 256) * d * E);
-        if (!r) r = t5_alloc(t, &L.wff, rup_(d, 256) * F * E);
-        if (r) break;
-        const char* qkvn[3] = {"q", "k", "v"};
-        for (int j = 0; j < 3; ++j) {
-            snprintf(nm, sizeof(nm), "encoder.block.%d.layer.0.SelfAttention.%s.weight", i, qkvn[j]);
-            t->slots[nm] = T5Slot{L.wqkv + (int64_t)j * in * d * E, in, d, false};
+    auto build = [&]() -> int {
+        const int64_t d = cfg->d_model, in = t->inner, F = cfg->d_ff, E = t->esz;
+        int r = t5_alloc(t, &t->shared, (int64_t)cfg->vocab_size * d * E);
+        if (!r) r = t5_alloc(t, &t->final_ln, d * E);
+        if (!r) r = t5_alloc(t, &t->rel_table, (int64_t)cfg->relative_attention_num_buckets * cfg->num_heads * E);
+        t->slots["shared.weight"] = T5Slot{t->shared, cfg->vocab_size, d, false};
+        t->slots["encoder.final_layer_norm.weight"] = T5Slot{t->final_ln, d, 1, false};
+        t->slots["encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"] =
+            T5Slot{t->rel_table, cfg->relative_attention_num_buckets, cfg->num_heads, false};
+        t->layers.resize(cfg->num_layers);
+        char nm[160];
+        for (int i = 0; i < cfg->num_layers && !r; ++i) {
+            T5Layer& L = t->layers[i];
+            // weight rows padded to the 256-column GEMM tile (zero rows)
+            if (!r) r = t5_alloc(t, &L.ln0, d * E);
+            if (!r) r = t5_alloc(t, &L.wqkv, rup_(3 * in, 256) * d * E);
+            if (!r) r = t5_alloc(t, &L.wo, rup_(d, 256) * in * E);
+            if (!r) r = t5_alloc(t, &L.ln1, d * E);
+            if (!r) r = t5_alloc(t, &L.wi, rup_(2 * F, 256) * d * E);
+            if (!r) r = t5_alloc(t, &L.wff, rup_(d, 256) * F * E);
+            if (r) break;
+            const char* qkvn[3] = {"q", "k", "v"};
+            for (int j = 0; j < 3; ++j) {
+                snprintf(nm, sizeof(nm), "encoder.block.%d.layer.0.SelfAttention.%s.weight", i, qkvn[j]);
+                t->slots[nm] = T5Slot{L.wqkv + (int64_t)j * in * d * E, in, d, false};
+            }
+            snprintf(nm, sizeof(nm), "encoder.block.%d.layer.0.SelfAttention.o.weight", i);
+            t->slots[nm] = T5Slot{L.wo, d, in, false};
+            snprintf(nm, sizeof(nm), "encoder.block.%d.layer.0.layer_norm.weight", i);
+            t->slots[nm] = T5Slot{L.ln0, d, 1, false};
+            snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.layer_norm.weight", i);
+            t->slots[nm] = T5Slot{L.ln1, d, 1, false};
+            snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.DenseReluDense.wi_0.weight", i);
+            t->slots[nm] = T5Slot{L.wi, F, d, false};
+            snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.DenseReluDense.wi_1.weight", i);
+            t->slots[nm] = T5Slot{L.wi + F * d * E, F, d, false};
+            snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.DenseReluDense.wo.weight", i);
+            t->slots[nm] = T5Slot{L.wff, d, F, false};
         }
-        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.0.SelfAttention.o.weight", i);
-        t->slots[nm] = T5Slot{L.wo, d, in, false};
-        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.0.layer_norm.weight", i);
-        t->slots[nm] = T5Slot{L.ln0, d, 1, false};
-        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.layer_norm.weight", i);
-        t->slots[nm] = T5Slot{L.ln1, d, 1, false};
-        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.DenseReluDense.wi_0.weight", i);
-        t->slots[nm] = T5Slot{L.wi, F, d, false};
-        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.DenseReluDense.wi_1.weight", i);
-        t->slots[nm] = T5Slot{L.wi + F * d * E, F, d, false};
-        snprintf(nm, sizeof(nm), "encoder.block.%d.layer.1.DenseReluDense.wo.weight", i);
-        t->slots[nm] = T5Slot{L.wff, d, F, false};
+        return r;
+    };
+    t->sizing = true;
+    int r = build();
+    if (!r) {
+        t->arena_bytes = t->arena_off;
+        if (hipMalloc((void**)&t->arena, (size_t)t->arena_bytes) != hipSuccess || hipMemset(t->arena, 0, (size_t)t->arena_bytes) != hipSuccess)
+            r = s2v_fail(__FILE__, __LINE__, "s2v_t5_create: weight arena allocation failed", -2);
+    }
+    if (!r) {
+        t->sizing = false;
+        t->arena_off = 0;
+        t->slots.clear();
+        r = build();
     }
     if (r) { s2v_t5_destroy(t); return r; }
     *out = t;
+    return 0;
+}
+
+/* One device range holding every weight, for the replica broadcast; the receiver calls s2v_t5_mark_weights_loaded. */
+extern "C" int s2v_t5_weight_arena(s2v_t5* t, void** dev_ptr, int64_t* bytes) {
+    S2V_REQUIRE(t && dev_ptr && bytes, "s2v_t5_weight_arena: null argument");
+    *dev_ptr = t->arena;
+    *bytes = t->arena_bytes;
+    return 0;
+}
+extern "C" int s2v_t5_mark_weights_loaded(s2v_t5* t) {
+    S2V_REQUIRE(t, "s2v_t5_mark_weights_loaded: null argument");
+    for (auto& kv : t->slots) kv.second.loaded = true;
+    t->finalized = true;
     return 0;
 }
 

@@ -52,10 +52,22 @@ struct s2v_vae {
     std::vector<void*> geo_allocs;
     std::vector<char*> tiles; std::vector<int> tile_h, tile_w;
     int tiles_F = 0;
+    // every weight lives in ONE arena (replicas receive it by one broadcast, s2v_vae_weight_arena): the plan is built twice,
+    // a sizing pass (arena == nullptr) that only adds up the carve-outs, then the real pass that bumps through the arena
+    char* arena = nullptr;
+    int64_t arena_bytes = 0, arena_off = 0;
+    bool sizing = false;
 };
 
 static int vfail(const char* m) { return s2v_fail(__FILE__, __LINE__, m, -1); }
 
+template <typename T>
+static int wmalloc(s2v_vae* v, T** p, int64_t bytes) {  // weight carve-out (256-byte aligned, zero-initialised with the arena)
+    const int64_t sz = rup64(bytes > 0 ? bytes : 16, 256);
+    *p = v->sizing ? nullptr : (T*)(v->arena + v->arena_off);
+    v->arena_off += sz;
+    return 0;
+}
 template <typename T>
 static int dmalloc(s2v_vae* v, T** p, int64_t bytes, bool geo = false) {
     void* q = nullptr;
@@ -69,8 +81,8 @@ static int dmalloc(s2v_vae* v, T** p, int64_t bytes, bool geo = false) {
 static int make_conv(s2v_vae* v, ConvL& c, const std::string& name, int cin, int cout, int kt, int level) {
     c.cin = cin; c.cout = cout; c.kt = kt; c.level = level;
     const int taps = kt == 3 ? 27 : (kt == 1 ? 9 : 1);
-    S2V_TRY(dmalloc(v, &c.w, rup64(cout, 256) * taps * cin * v->esz));
-    S2V_TRY(dmalloc(v, &c.b, (int64_t)cout * v->esz));
+    S2V_TRY(wmalloc(v, &c.w, rup64(cout, 256) * taps * cin * v->esz));
+    S2V_TRY(wmalloc(v, &c.b, (int64_t)cout * v->esz));
     v->slots[name + ".weight"] = VSlot{1, c.w, cout, cin, taps, false};
     v->slots[name + ".bias"] = VSlot{0, c.b, cout, 1, 1, false};
     return 0;
@@ -78,12 +90,12 @@ static int make_conv(s2v_vae* v, ConvL& c, const std::string& name, int cin, int
 static int make_snorm(s2v_vae* v, SNormL& n, const std::string& name, int C) {
     n.C = C;
     const int Cz = v->Cz;
-    S2V_TRY(dmalloc(v, &n.gn_w, (int64_t)C * v->esz));
-    S2V_TRY(dmalloc(v, &n.gn_b, (int64_t)C * v->esz));
-    S2V_TRY(dmalloc(v, &n.wy, (int64_t)C * Cz * 4));
-    S2V_TRY(dmalloc(v, &n.wb, (int64_t)C * Cz * 4));
-    S2V_TRY(dmalloc(v, &n.by, (int64_t)C * 4));
-    S2V_TRY(dmalloc(v, &n.bb, (int64_t)C * 4));
+    S2V_TRY(wmalloc(v, &n.gn_w, (int64_t)C * v->esz));
+    S2V_TRY(wmalloc(v, &n.gn_b, (int64_t)C * v->esz));
+    S2V_TRY(wmalloc(v, &n.wy, (int64_t)C * Cz * 4));
+    S2V_TRY(wmalloc(v, &n.wb, (int64_t)C * Cz * 4));
+    S2V_TRY(wmalloc(v, &n.by, (int64_t)C * 4));
+    S2V_TRY(wmalloc(v, &n.bb, (int64_t)C * 4));
     v->slots[name + ".norm_layer.weight"] = VSlot{0, n.gn_w, C, 1, 1, false};
     v->slots[name + ".norm_layer.bias"] = VSlot{0, n.gn_b, C, 1, 1, false};
     v->slots[name + ".conv_y.conv.weight"] = VSlot{2, n.wy, C, Cz, 1, false};
@@ -108,20 +120,27 @@ extern "C" void s2v_vae_destroy(s2v_vae* v) {
     for (void* p : v->allocs) (void)hipFree(p);
     for (void* p : v->geo_allocs) (void)hipFree(p);
     for (char* p : v->tiles) (void)hipFree(p);
+    if (v->arena) (void)hipFree(v->arena);
     delete v;
 }
 
-extern "C" int s2v_vae_create(const s2v_vae_config* cfg, s2v_vae** out) {
-    S2V_REQUIRE(cfg && out, "s2v_vae_create: null argument");
-    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_vae_create: unsupported dtype");
-    S2V_REQUIRE(cfg->num_blocks >= 1 && cfg->num_blocks <= 6, "s2v_vae_create: 1..6 blocks");
-    s2v_vae* v = new s2v_vae();
-    v->cfg = *cfg;
-    v->dtype = cfg->dtype;
-    v->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
-    v->G = cfg->norm_num_groups;
-    v->Cz = cfg->latent_channels;
-    v->mfma = cfg->dtype == S2V_DTYPE_BF16 && !cfg->force_simple;
+static int build_two_pass(s2v_vae* v, int (*build)(s2v_vae*)) {
+    v->sizing = true;
+    v->arena_off = 0;
+    S2V_TRY(build(v));
+    v->arena_bytes = v->arena_off;
+    S2V_CHECK_HIP(hipMalloc((void**)&v->arena, (size_t)v->arena_bytes));
+    S2V_CHECK_HIP(hipMemset(v->arena, 0, (size_t)v->arena_bytes));
+    v->sizing = false;
+    v->arena_off = 0;
+    v->stages.clear();
+    v->slots.clear();
+    S2V_TRY(build(v));
+    return dmalloc(v, &v->sums, sizeof(double) * 2 * v->G);
+}
+
+static int build_decoder(s2v_vae* v) {
+    const s2v_vae_config* cfg = &v->cfg;
     const int nb = cfg->num_blocks;
     // decoder channel plan = reversed block_out_channels (autoencoder_kl_cogvideox.py:871-915)
     std::vector<int> rc(nb);
@@ -156,9 +175,38 @@ extern "C" int s2v_vae_create(const s2v_vae_config* cfg, s2v_vae** out) {
     }
     if (!r) r = make_snorm(v, v->norm_out, "decoder.norm_out", rc[nb - 1]);
     if (!r) r = make_conv(v, v->conv_out, "decoder.conv_out.conv", rc[nb - 1], cfg->out_channels, 3, level);
-    if (!r) r = dmalloc(v, &v->sums, sizeof(double) * 2 * v->G);
+    return r;
+}
+
+extern "C" int s2v_vae_create(const s2v_vae_config* cfg, s2v_vae** out) {
+    S2V_REQUIRE(cfg && out, "s2v_vae_create: null argument");
+    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_vae_create: unsupported dtype");
+    S2V_REQUIRE(cfg->num_blocks >= 1 && cfg->num_blocks <= 6, "s2v_vae_create: 1..6 blocks");
+    s2v_vae* v = new s2v_vae();
+    v->cfg = *cfg;
+    v->dtype = cfg->dtype;
+    v->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
+    v->G = cfg->norm_num_groups;
+    v->Cz = cfg->latent_channels;
+    v->mfma = cfg->dtype == S2V_DTYPE_BF16 && !cfg->force_simple;
+    const int r = build_two_pass(v, build_decoder);
     if (r) { s2v_vae_destroy(v); return r; }
     *out = v;
+    return 0;
+}
+
+/* One device range holding every weight of the handle (decoder or encoder), for the replica broadcast; a replica that
+ * received it calls s2v_vae_mark_weights_loaded instead of s2v_vae_load_weight + s2v_vae_finalize. */
+extern "C" int s2v_vae_weight_arena(s2v_vae* v, void** dev_ptr, int64_t* bytes) {
+    S2V_REQUIRE(v && dev_ptr && bytes, "s2v_vae_weight_arena: null argument");
+    *dev_ptr = v->arena;
+    *bytes = v->arena_bytes;
+    return 0;
+}
+extern "C" int s2v_vae_mark_weights_loaded(s2v_vae* v) {
+    S2V_REQUIRE(v, "s2v_vae_mark_weights_loaded: null argument");
+    for (auto& kv : v->slots) kv.second.loaded = true;
+    v->finalized = true;
     return 0;
 }
 
@@ -537,8 +585,8 @@ extern "C" int s2v_vae_postprocess(const void* video, int32_t C, int32_t F, int3
 // ConvL::level l works at (tile height >> l) x (tile width >> l).
 static int make_gn(s2v_vae* v, SNormL& n, const std::string& name, int C) {
     n.C = C;
-    S2V_TRY(dmalloc(v, &n.gn_w, (int64_t)C * v->esz));
-    S2V_TRY(dmalloc(v, &n.gn_b, (int64_t)C * v->esz));
+    S2V_TRY(wmalloc(v, &n.gn_w, (int64_t)C * v->esz));
+    S2V_TRY(wmalloc(v, &n.gn_b, (int64_t)C * v->esz));
     v->slots[name + ".weight"] = VSlot{0, n.gn_w, C, 1, 1, false};
     v->slots[name + ".bias"] = VSlot{0, n.gn_b, C, 1, 1, false};
     return 0;
@@ -553,18 +601,8 @@ static int make_resnet_gn(s2v_vae* v, ResnetL& r, const std::string& name, int c
     return 0;
 }
 
-extern "C" int s2v_vae_enc_create(const s2v_vae_config* cfg, s2v_vae** out) {
-    S2V_REQUIRE(cfg && out, "s2v_vae_enc_create: null argument");
-    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_vae_enc_create: unsupported dtype");
-    S2V_REQUIRE(cfg->num_blocks >= 1 && cfg->num_blocks <= 6, "s2v_vae_enc_create: 1..6 blocks");
-    s2v_vae* v = new s2v_vae();
-    v->cfg = *cfg;
-    v->dtype = cfg->dtype;
-    v->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
-    v->G = cfg->norm_num_groups;
-    v->Cz = cfg->latent_channels;
-    v->mfma = cfg->dtype == S2V_DTYPE_BF16 && !cfg->force_simple;
-    v->encoder = true;
+static int build_encoder(s2v_vae* v) {
+    const s2v_vae_config* cfg = &v->cfg;
     const int nb = cfg->num_blocks;
     const int tlevel = (int)std::lround(std::log2((double)cfg->temporal_compression_ratio));
     int r = make_conv(v, v->conv_in, "encoder.conv_in.conv", cfg->out_channels, cfg->block_out_channels[0], 3, 0);
@@ -597,7 +635,22 @@ extern "C" int s2v_vae_enc_create(const s2v_vae_config* cfg, s2v_vae** out) {
     }
     if (!r) r = make_gn(v, v->norm_out, "encoder.norm_out", prev);
     if (!r) r = make_conv(v, v->conv_out, "encoder.conv_out.conv", prev, 2 * v->Cz, 3, level);
-    if (!r) r = dmalloc(v, &v->sums, sizeof(double) * 2 * v->G);
+    return r;
+}
+
+extern "C" int s2v_vae_enc_create(const s2v_vae_config* cfg, s2v_vae** out) {
+    S2V_REQUIRE(cfg && out, "s2v_vae_enc_create: null argument");
+    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_vae_enc_create: unsupported dtype");
+    S2V_REQUIRE(cfg->num_blocks >= 1 && cfg->num_blocks <= 6, "s2v_vae_enc_create: 1..6 blocks");
+    s2v_vae* v = new s2v_vae();
+    v->cfg = *cfg;
+    v->dtype = cfg->dtype;
+    v->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
+    v->G = cfg->norm_num_groups;
+    v->Cz = cfg->latent_channels;
+    v->mfma = cfg->dtype == S2V_DTYPE_BF16 && !cfg->force_simple;
+    v->encoder = true;
+    const int r = build_two_pass(v, build_encoder);
     if (r) { s2v_vae_destroy(v); return r; }
     *out = v;
     return 0;

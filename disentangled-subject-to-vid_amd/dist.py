@@ -43,6 +43,20 @@ def broadcast_arena(arena, src=0, chunk_bytes=256 << 20):
     return n
 
 
+def broadcast_components(components, src=0):
+    """replicate every component of the path -- transformer engine, VAE (decoder [+ encoder]), T5 encoder: anything with
+    .weight_arenas() -> [uint8 tensors] and .mark_weights_loaded() -- rank `src` -> all.  Returns the bytes moved."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    total = 0
+    for c in components:
+        for arena in c.weight_arenas():
+            total += broadcast_arena(arena, src)
+        if dist.get_rank() != src:
+            c.mark_weights_loaded()
+    return total
+
+
 def gather_results(local_results, dst=0):
     """collect {prompt_id: tensor} from every rank on `dst` (CPU tensors; result latents are a few MB)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
@@ -59,17 +73,17 @@ def gather_results(local_results, dst=0):
 
 
 def run_replicas(make_engine, load_weights_rank0, prompts, run_prompt):
-    """generic driver: rank 0 ingests the checkpoint, everybody else receives the arena; then each rank runs its
-    prompts.  make_engine() -> engine with .weight_arena() / .mark_weights_loaded();
-    load_weights_rank0(engine) loads + finalizes; run_prompt(engine, prompt_id, prompt) -> tensor."""
+    """generic driver: rank 0 ingests the checkpoints, everybody else receives the arenas; then each rank runs its
+    prompts (prompt p on rank p mod world: an uneven count leaves the last ranks one prompt short, nobody waits for anybody).
+    make_engine() -> one component or a tuple / list of components (transformer engine, VAE, T5 ...), each with
+    .weight_arenas() / .mark_weights_loaded(); load_weights_rank0(engine) loads + finalizes on rank 0;
+    run_prompt(engine, prompt_id, prompt) -> tensor."""
     rank = dist.get_rank() if dist.is_initialized() else 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     eng = make_engine()
     if rank == 0:
         load_weights_rank0(eng)
     if world > 1:
-        broadcast_arena(eng.weight_arena(), 0)
-        if rank != 0:
-            eng.mark_weights_loaded()
+        broadcast_components(eng if isinstance(eng, (tuple, list)) else [eng], 0)
     mine = {p: run_prompt(eng, p, prompts[p]) for p in shard_prompts(len(prompts), rank, world)}
     return gather_results(mine, 0)

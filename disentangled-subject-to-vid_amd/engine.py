@@ -86,6 +86,9 @@ class S2VEngine:
         _lib.check(_lib.lib().s2v_weight_arena(self._h, ctypes.byref(p), ctypes.byref(n)))
         return torch.as_tensor(_ArenaView(p.value, n.value), device=self.device)
 
+    def weight_arenas(self):
+        return [self.weight_arena()]
+
     def mark_weights_loaded(self):
         _lib.check(_lib.lib().s2v_mark_weights_loaded(self._h))
 

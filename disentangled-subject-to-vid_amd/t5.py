@@ -38,6 +38,8 @@ _lib.register_sigs({
     "s2v_t5_create": [ctypes.POINTER(T5ConfigC), ctypes.POINTER(_P)],
     "s2v_t5_load_weight": [_P, ctypes.c_char_p, _P, ctypes.POINTER(_I64), _I32, _I32, _P],
     "s2v_t5_finalize": [_P],
+    "s2v_t5_weight_arena": [_P, ctypes.POINTER(_P), ctypes.POINTER(_I64)],
+    "s2v_t5_mark_weights_loaded": [_P],
     "s2v_t5_rel_table": [_P, ctypes.POINTER(_P)],
     "s2v_t5_set_position_bias": [_P, _P, _I32, _I32, _P],
     "s2v_t5_encode": [_P, _P, _I32, _I32, _P, _P],
@@ -118,6 +120,17 @@ class HipT5EncoderModel:
         torch.cuda.synchronize(self.device)
         _lib.check(_lib.lib().s2v_t5_finalize(self._h))
         self._bias_for = None
+
+    def weight_arenas(self):
+        """[uint8 CUDA tensor aliasing the packed weights] (dist.broadcast_components)"""
+        from .engine import _ArenaView
+
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(_lib.lib().s2v_t5_weight_arena(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return [torch.as_tensor(_ArenaView(p.value, n.value), device=self.device)]
+
+    def mark_weights_loaded(self):
+        _lib.check(_lib.lib().s2v_t5_mark_weights_loaded(self._h))
 
     def _set_bias(self, B, T):
         if self._bias_for == (B, T):

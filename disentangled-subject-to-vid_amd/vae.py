@@ -27,6 +27,8 @@ _lib.register_sigs({
     "s2v_vae_create": [ctypes.POINTER(VaeConfigC), ctypes.POINTER(_P)],
     "s2v_vae_load_weight": [_P, ctypes.c_char_p, _P, ctypes.POINTER(_I64), _I32, _I32, _P],
     "s2v_vae_finalize": [_P],
+    "s2v_vae_weight_arena": [_P, ctypes.POINTER(_P), ctypes.POINTER(_I64)],
+    "s2v_vae_mark_weights_loaded": [_P],
     "s2v_vae_out_shape": [_P, _I32, _I32, _I32, _I32, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)],
     "s2v_vae_decode": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "s2v_vae_postprocess": [_P, _I32, _I32, _I32, _I32, _P, _I32, _P],
@@ -152,6 +154,24 @@ class HipAutoencoderKLCogVideoX:
         torch.cuda.synchronize(self.device)
         for pre in loaded:
             _lib.check(_lib.lib().s2v_vae_finalize(halves[pre]))
+
+    # ---- replicas: the weights of each half are one device range (dist.broadcast_components) ------------------------
+    def weight_arenas(self, with_encoder=False):
+        """list of uint8 CUDA tensors aliasing the packed weights: [decoder] or [decoder, encoder]"""
+        from .engine import _ArenaView
+
+        if with_encoder and not self._enc:
+            _lib.check(_lib.lib().s2v_vae_enc_create(ctypes.byref(self._cfg_c), ctypes.byref(self._enc)))
+        out = []
+        for h in [self._h] + ([self._enc] if with_encoder else []):
+            p, n = ctypes.c_void_p(), ctypes.c_int64()
+            _lib.check(_lib.lib().s2v_vae_weight_arena(h, ctypes.byref(p), ctypes.byref(n)))
+            out.append(torch.as_tensor(_ArenaView(p.value, n.value), device=self.device))
+        return out
+
+    def mark_weights_loaded(self, with_encoder=False):
+        for h in [self._h] + ([self._enc] if with_encoder else []):
+            _lib.check(_lib.lib().s2v_vae_mark_weights_loaded(h))
 
     def encode(self, x, return_dict=True):
         """AutoencoderKLCogVideoX.encode (:1205-1229) for the reference image: x [1,3,1,H,W] in [-1,1] ->

@@ -162,6 +162,12 @@ void s2v_vae_destroy(s2v_vae* vae);
 int s2v_vae_load_weight(s2v_vae* vae, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
                         int32_t src_dtype, s2v_stream stream);
 int s2v_vae_finalize(s2v_vae* vae);
+/* Replicas ("11.14 GB transformer + 0.25 GB VAE decoder" are broadcast rank0 -> all): every weight of
+ * a handle (decoder, or encoder for an s2v_vae_enc_create handle) lives in ONE device range; the receiving rank copies into
+ * it and calls s2v_vae_mark_weights_loaded instead of s2v_vae_load_weight + s2v_vae_finalize.  Stands where the reference
+ * would call .to(device) on every rank after from_pretrained (src/inference.py:191-215). */
+int s2v_vae_weight_arena(s2v_vae* vae, void** dev_ptr, int64_t* bytes);
+int s2v_vae_mark_weights_loaded(s2v_vae* vae);
 /* output extent of s2v_vae_decode for latents [1,F,C,h,w] */
 int s2v_vae_out_shape(s2v_vae* vae, int32_t F, int32_t h, int32_t w, int32_t tiling, int32_t* Fo, int32_t* Ho, int32_t* Wo);
 /* CogVideoXPipeline.decode_latents (pipeline_cogvideox.py:346-351) = 1/scaling_factor * latents, then
@@ -226,6 +232,9 @@ void s2v_t5_destroy(s2v_t5* t5);
 int s2v_t5_load_weight(s2v_t5* t5, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
                        int32_t src_dtype, s2v_stream stream);
 int s2v_t5_finalize(s2v_t5* t5);
+/* the same replica hand-off for the text encoder (9.4 GB in bf16) */
+int s2v_t5_weight_arena(s2v_t5* t5, void** dev_ptr, int64_t* bytes);
+int s2v_t5_mark_weights_loaded(s2v_t5* t5);
 /* device address of the loaded block-0 relative_attention_bias table [num_buckets, num_heads] (model dtype) */
 int s2v_t5_rel_table(s2v_t5* t5, void** dev_ptr);
 /* position_bias [num_heads, T, T] (model dtype) = T5Attention.compute_bias(T, T) of block 0, gathered by the host from

@@ -23,6 +23,9 @@ class FakeEngine:
     def weight_arena(self):
         return self.arena
 
+    def weight_arenas(self):
+        return [self.arena]
+
     def mark_weights_loaded(self):
         self.loaded = True
 
@@ -86,8 +89,78 @@ def test_two_rank_replicas_match_single_process():
         np.testing.assert_array_equal(got[pid], _run_prompt(eng, pid, prompt).numpy())
 
 
+class FakeVAE:
+    """two arenas (decoder, encoder), like HipAutoencoderKLCogVideoX.weight_arenas(with_encoder=True)"""
+
+    def __init__(self):
+        self.dec, self.enc = torch.zeros(70001, dtype=torch.uint8), torch.zeros(513, dtype=torch.uint8)
+        self.loaded = False
+
+    def weight_arenas(self):
+        return [self.dec, self.enc]
+
+    def mark_weights_loaded(self):
+        self.loaded = True
+
+
+def _worker_multi(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    d = importlib.import_module("disentangled-subject-to-vid_amd.dist")
+    d.init_from_env("gloo")
+
+    def load0(parts):
+        eng, vae, t5 = parts
+        _load_rank0(eng)
+        g = torch.Generator().manual_seed(2)
+        for a in vae.weight_arenas() + t5.weight_arenas():
+            a.copy_(torch.randint(0, 256, a.shape, generator=g, dtype=torch.uint8))
+        vae.loaded = t5.loaded = True
+
+    def run(parts, pid, prompt):
+        eng, vae, t5 = parts
+        assert eng.loaded and vae.loaded and t5.loaded
+        lat = _run_prompt(eng, pid, prompt)
+        # "decode" and "text encode" stand-ins read the other components' arenas: a rank that missed one broadcast differs
+        return lat * (1.0 + vae.dec[:64].float().mean() / 255.0) + vae.enc[:8].float().sum() + t5.arena[-16:].float().sum()
+
+    prompts = [7, 8, 9]  # uneven over 2 ranks: rank 0 runs prompts 0 and 2, rank 1 runs prompt 1
+    res = d.run_replicas(lambda: (FakeEngine(1 << 20), FakeVAE(), FakeEngine(300007)), load0, prompts, run)
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in res.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_multi_component_broadcast_and_uneven_prompts():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_multi, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    eng, vae, t5 = FakeEngine(1 << 20), FakeVAE(), FakeEngine(300007)
+    _load_rank0(eng)
+    g = torch.Generator().manual_seed(2)
+    for a in vae.weight_arenas() + t5.weight_arenas():
+        a.copy_(torch.randint(0, 256, a.shape, generator=g, dtype=torch.uint8))
+    assert sorted(got) == [0, 1, 2]
+    for pid, prompt in enumerate([7, 8, 9]):
+        lat = _run_prompt(eng, pid, prompt)
+        exp = lat * (1.0 + vae.dec[:64].float().mean() / 255.0) + vae.enc[:8].float().sum() + t5.arena[-16:].float().sum()
+        np.testing.assert_array_equal(got[pid], exp.numpy())
+
+
 def test_single_process_paths():
     d = importlib.import_module("disentangled-subject-to-vid_amd.dist")
     assert d.broadcast_arena(torch.zeros(10, dtype=torch.uint8)) == 0
+    assert d.broadcast_components([FakeEngine(10)]) == 0
     assert d.gather_results({0: torch.ones(2)})[0].sum() == 2
     assert d.shard_prompts(8, 3, 8) == [3]

@@ -131,3 +131,34 @@ def test_vae_full_size_tiled_decode_is_deterministic_and_finite(s2v):
     assert torch.equal(y1, y2)
     frames = vae.postprocess_video(y1, "pt")
     assert frames.shape == (1, 49, 3, 480, 720) and frames.min() >= 0 and frames.max() <= 1
+
+
+def test_vae_and_t5_weight_arenas_replicate_a_loaded_model(s2v):
+    """what a receiving rank does: copy the sender's arenas into a fresh handle, mark it loaded, get bit-identical outputs"""
+    vcfg = s2v.VAEConfig(block_out_channels=(16, 16, 32, 32), layers_per_block=1, norm_num_groups=4, latent_channels=16,
+                         sample_height=96, sample_width=160, scaling_factor=0.7, temporal_compression_ratio=4)
+    sd = dict(s2v.weights.synthetic_vae_state_dict(vcfg, seed=3))
+    sd.update(s2v.weights.synthetic_vae_encoder_state_dict(vcfg, seed=4))
+    a = s2v.HipAutoencoderKLCogVideoX(vcfg, torch.bfloat16, DEV)
+    a.load_state_dict(sd)
+    b = s2v.HipAutoencoderKLCogVideoX(vcfg, torch.bfloat16, DEV)
+    src, dst = a.weight_arenas(with_encoder=True), b.weight_arenas(with_encoder=True)
+    assert len(src) == 2 and all(x.dtype == torch.uint8 and x.numel() > 1024 for x in src)
+    for s_, d_ in zip(src, dst):
+        assert s_.numel() == d_.numel()
+        d_.copy_(s_)
+    b.mark_weights_loaded(with_encoder=True)
+    g = torch.Generator().manual_seed(5)
+    lat = torch.randn(1, 2, 16, 6, 10, generator=g).bfloat16().to(DEV)
+    img = (torch.rand(1, 3, 1, 48, 80, generator=g) * 2 - 1).bfloat16().to(DEV)
+    assert torch.equal(a.decode_latents(lat), b.decode_latents(lat))
+    assert torch.equal(a.encode(img).latent_dist.parameters, b.encode(img).latent_dist.parameters)
+
+    tcfg = s2v.T5Config(vocab_size=100, d_model=64, d_kv=64, num_heads=2, d_ff=128, num_layers=2)
+    ta = s2v.HipT5EncoderModel(tcfg, torch.bfloat16, DEV)
+    ta.load_state_dict(s2v.weights.synthetic_t5_state_dict(tcfg, seed=6, gain=0.6))
+    tb = s2v.HipT5EncoderModel(tcfg, torch.bfloat16, DEV)
+    tb.weight_arenas()[0].copy_(ta.weight_arenas()[0])
+    tb.mark_weights_loaded()
+    ids = torch.randint(1, 100, (2, 9), generator=g).to(DEV)
+    assert torch.equal(ta(ids)[0], tb(ids)[0])
