@@ -90,6 +90,27 @@ def lib():
     return _lib
 
 
+_diag = None
+DIAG_LIB_PATH = os.path.join(_HERE, "libs2v_hip_diag.so")
+
+
+def diag_lib():
+    """libs2v_hip_diag.so: the same sources built with -DS2V_DIAG (A/B reference kernels, stall accounting, ablations and their
+    knobs s2v_set_gemm_impl / s2v_set_attn_variant / s2v_debug_read / s2v_attn_debug_read).  Only tools/ and the race-screen
+    test load it (`python disentangled-subject-to-vid_amd/build.py --diag`); the product never does."""
+    global _diag
+    if _diag is None:
+        if not os.path.exists(DIAG_LIB_PATH):
+            raise S2VError(f"{DIAG_LIB_PATH} is missing: build it with `python {os.path.join(_HERE, 'build.py')} --diag`")
+        l = ctypes.CDLL(DIAG_LIB_PATH)
+        _apply_sigs(l, {k: v for k, v in _SIGS.items() if k.startswith("s2v_op_")})
+        l.s2v_last_error.restype = ctypes.c_char_p
+        for name in ("s2v_set_gemm_impl", "s2v_set_attn_variant"):
+            getattr(l, name).argtypes = [ctypes.c_int]
+        _diag = l
+    return _diag
+
+
 def check(rc):
     if rc != 0:
         raise S2VError(f"s2v call failed ({rc}): {lib().s2v_last_error().decode()}")

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
 // worth its precondition).
 #ifdef S2V_DIAG
 __device__ long long g_attn_dbg[64];  // ACCT: per-wave s_memtime totals of block 100
-extern "C" int s2v_attn_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
+extern "C" __attribute__((visibility("default"))) int s2v_attn_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
 #endif
 template <bool ACCT>
 __global__ __launch_bounds__(512, 2) void attn_pp_k(const AttnArgs a, int nqb) {
@@ -470,7 +470,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_k(const AttnArgs a, int nqb) {
 
 #ifdef S2V_DIAG
 int g_attn_variant = 0;  // 0 = product kernel, 1 = product kernel with stall accounting, 2 = round-1 lock-step kernel (A/B reference)
-extern "C" int s2v_set_attn_variant(int v) { g_attn_variant = v; return 0; }
+extern "C" __attribute__((visibility("default"))) int s2v_set_attn_variant(int v) { g_attn_variant = v; return 0; }
 #endif
 
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {

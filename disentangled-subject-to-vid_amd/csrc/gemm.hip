@@ -481,6 +481,7 @@ __device__ __forceinline__ bf16x8 lds_frag32(const char* tile, int row, int cl) 
 }
 
 // ---------------------------------------------------------------------------------------------------
+#ifdef S2V_DIAG  // the lock-step reference schedule of the race-screen test lives in libs2v_hip_diag.so only
 // gemm_bf16_w8: the same 256 x 256 block tile, BK32 half-steps, four-stage LDS-DMA ring and fragment register
 // prefetch of the removed four-wave form, with EIGHT waves (2 x 4) of 128(m) x 64(n) wave tiles = two waves per SIMD.  A wave that is
 // stuck issuing an LDS-DMA piece (60-180 cycles each, per MI355X_MICROARCH.md) no longer idles the matrix pipe: its
@@ -613,9 +614,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_w8(const GemmArgs a, int til
         }
 }
 
+#endif  // S2V_DIAG
+
 // ---------------------------------------------------------------------------------------------------
+#ifdef S2V_DIAG
 __device__ long long g_pp_dbg[64];  // diagnostics (ABL == 4)
-extern "C" int s2v_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
+extern "C" __attribute__((visibility("default"))) int s2v_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
+#endif
 
 // gemm_bf16_pp64: the ping-pong schedule of gemm_bf16_pp on K-tiles of 64 with 128-byte LDS rows, so every LDS-DMA lane
 // group fetches a FULL 128-B line (gemm_bf16_pp / _w8 fetch 64-B half lines: twice the L2 requests for the same bytes, and
@@ -795,8 +800,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
         if ((ABL >= 4)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             tacc[3] = now() - te0;  // epilogue incl. store drain (replaces the vmcnt slot)
+#ifdef S2V_DIAG
             if (blockIdx.x == 100 && lane == 0)
                 for (int e = 0; e < 8; ++e) g_pp_dbg[wave * 8 + e] = tacc[e];
+#endif
         }
         return;
     }
@@ -818,6 +825,7 @@ template <int EPI>
 static int launch_pp64_t(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
     S2V_TRY(ensure_lds_attr((const void*)gemm_bf16_pp64<EPI>, 131072));
+#ifdef S2V_DIAG
     if (EPI == EPI_BIAS && a.ablate) {  // diagnostics only (tools/ablate_gemm.py)
         const void* fn = a.ablate == 1 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 1> : a.ablate == 4 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 4> : a.ablate == 5 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 5> : a.ablate == 6 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 6> : a.ablate == 7 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 7> : (const void*)gemm_bf16_pp64<EPI_BIAS, 3>;
         S2V_CHECK_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
@@ -825,11 +833,13 @@ static int launch_pp64_t(const GemmArgs& a, hipStream_t st) {
         S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(tiles_m * tiles_n), dim3(512), args, 131072, st));
         return 0;
     }
+#endif
     hipLaunchKernelGGL(gemm_bf16_pp64<EPI>, dim3(tiles_m * tiles_n), dim3(512), 131072, st, a, tiles_m, tiles_n);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
+#ifdef S2V_DIAG
 template <int EPI>
 static int launch_w8_t(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
@@ -838,6 +848,7 @@ static int launch_w8_t(const GemmArgs& a, hipStream_t st) {
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
+#endif
 
 template <int EPI>
 static int launch_stag_t(const GemmArgs& a, hipStream_t st) {
@@ -848,10 +859,17 @@ static int launch_stag_t(const GemmArgs& a, hipStream_t st) {
     return 0;
 }
 
-int g_gemm_ablate = 0;  // diagnostics only (tools/ablate_gemm.py, tools/stall_pp64.py): compile-time ablations of gemm_bf16_pp64
-int g_gemm_impl = 7;  // 7 = 256x256x64 eight-wave ping-pong (default), 5 = 256x256 eight-wave lock-step ring, 2 = staggered 256x128 ring,
-                      // 0 = 128x128 double buffer; 5 and 7 fall back to 2 (then 0) when the shape does not fit their tiles
-extern "C" int s2v_set_gemm_impl(int impl) { g_gemm_impl = impl & 0xff; g_gemm_ablate = impl >> 8; return 0; }
+// 7 = 256x256x64 eight-wave ping-pong (the product schedule), 2 = staggered 256x128 ring, 0 = 128x128 double buffer; 7 falls back
+// to 2 (then 0) when the shape does not fit its tiles.  libs2v_hip_diag.so (S2V_DIAG) can also select 5 = the 256x256 eight-wave
+// lock-step ring and the compile-time ablations of gemm_bf16_pp64 (tools/ablate_gemm.py, tools/stall_pp64.py).
+#ifdef S2V_DIAG
+int g_gemm_ablate = 0;
+int g_gemm_impl = 7;
+extern "C" __attribute__((visibility("default"))) int s2v_set_gemm_impl(int impl) { g_gemm_impl = impl & 0xff; g_gemm_ablate = impl >> 8; return 0; }
+#else
+static constexpr int g_gemm_ablate = 0;
+static constexpr int g_gemm_impl = 7;
+#endif
 
 // the 256-column kernels take N that is not a multiple of 256 when the weight buffer physically holds the padded rows and
 // the last tile is at least half full (N = 1920 / 5760 of the 2B model); narrower outputs go to the 128-column kernels
@@ -889,6 +907,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }
+#ifdef S2V_DIAG
     if (g_gemm_impl == 5 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
@@ -899,6 +918,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }
+#endif
     if ((g_gemm_impl == 2 || g_gemm_impl >= 4) && (a.conv || a.a_rows_padded >= ((a.M + RBM - 1) / RBM) * RBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {

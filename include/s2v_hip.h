@@ -22,6 +22,13 @@
 extern "C" {
 #endif
 
+/* the shared library is built with -fvisibility=hidden: exactly the entry points declared here are exported */
+#if defined(__GNUC__)
+#define S2V_API __attribute__((visibility("default")))
+#else
+#define S2V_API
+#endif
+
 typedef struct s2v_ctx s2v_ctx;
 typedef void* s2v_stream; /* hipStream_t */
 
@@ -44,58 +51,58 @@ typedef struct s2v_model_config {
     int32_t reserved[5];
 } s2v_model_config;
 
-const char* s2v_last_error(void);
-const char* s2v_version(void);
+S2V_API const char* s2v_last_error(void);
+S2V_API const char* s2v_version(void);
 
-int s2v_create(const s2v_model_config* cfg, s2v_ctx** out);
-void s2v_destroy(s2v_ctx* ctx);
+S2V_API int s2v_create(const s2v_model_config* cfg, s2v_ctx** out);
+S2V_API void s2v_destroy(s2v_ctx* ctx);
 
 /* Load one state-dict tensor.  `name` is the reference's own key, e.g.
  * "transformer_blocks.3.attn1.to_q.weight", "patch_embed.proj.weight" [D,16,2,2], "norm_out.linear.bias"
  * (key list: SURVEY.md section 8b).  src_dtype may differ from the model dtype (converted on the fly).
  * Replaces ModelMixin.from_pretrained/.to(device,dtype) for this model (src/inference.py:191-215). */
-int s2v_load_weight(s2v_ctx* ctx, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
+S2V_API int s2v_load_weight(s2v_ctx* ctx, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
                     int32_t src_dtype, s2v_stream stream);
 /* W[name] += scale * B.A   (A:[r,in] B:[out,r], fp32 device tensors; Conv2d patch_embed.proj takes A as [r,in*k*k]).
  * The merge the reference's PEFT LoRA is equivalent to (src/inference.py:218-229, alpha/r = 0.5).
  * Must be called after s2v_load_weight(name) and before s2v_finalize_weights. */
-int s2v_merge_lora(s2v_ctx* ctx, const char* name, const float* A, const float* B, int32_t rank, float scale,
+S2V_API int s2v_merge_lora(s2v_ctx* ctx, const char* name, const float* A, const float* B, int32_t rank, float scale,
                    s2v_stream stream);
 /* Checks that every tensor was loaded; after this call the weights are immutable. */
-int s2v_finalize_weights(s2v_ctx* ctx, s2v_stream stream);
+S2V_API int s2v_finalize_weights(s2v_ctx* ctx, s2v_stream stream);
 /* Total bytes of context-owned weights (for the broadcast) and access to the packed arena so that ONE
  * collective can replicate a finalized model rank0 -> all. */
-int s2v_weight_arena(s2v_ctx* ctx, void** dev_ptr, int64_t* bytes);
+S2V_API int s2v_weight_arena(s2v_ctx* ctx, void** dev_ptr, int64_t* bytes);
 
 /* Token geometry of the next calls: batch B (2 = CFG pair), text tokens T, latent frames F and latent H x W
  * (R = (H/2)(W/2) reference-image tokens, V = F*R video tokens, sequence order [text | ref | video]).
  * Allocates the activation workspace (no allocation happens inside the compute calls). */
-int s2v_set_geometry(s2v_ctx* ctx, int32_t B, int32_t T, int32_t F, int32_t H, int32_t W);
+S2V_API int s2v_set_geometry(s2v_ctx* ctx, int32_t B, int32_t T, int32_t F, int32_t H, int32_t W);
 
 /* RoPE tables, fp32 [R + V, 64] (reference rows first): cos/sin as produced by
  * get_3d_rotary_pos_embed (embeddings.py:505-570) and sliced in custom_cogvideox_pipe.py:223-235. */
-int s2v_set_rope(s2v_ctx* ctx, const float* cos_dev, const float* sin_dev, s2v_stream stream);
+S2V_API int s2v_set_rope(s2v_ctx* ctx, const float* cos_dev, const float* sin_dev, s2v_stream stream);
 /* 2B only: additive 3-D sincos table for the video tokens, model dtype [V, D] (embeddings.py:380-401,440-446). */
-int s2v_set_pos_embed(s2v_ctx* ctx, const void* table_dev, s2v_stream stream);
+S2V_API int s2v_set_pos_embed(s2v_ctx* ctx, const void* table_dev, s2v_stream stream);
 
 /* Step-invariant conditioning: text [B,T,text_embed_dim] -> patch_embed.text_proj; ref image latent [1,1,C,H,W] ->
  * patch_embed.proj, duplicated over the batch (cogvideox_transformer_3d.py:494-504). */
-int s2v_set_conditioning(s2v_ctx* ctx, const void* text_dev, const void* ref_latent_dev, s2v_stream stream);
+S2V_API int s2v_set_conditioning(s2v_ctx* ctx, const void* text_dev, const void* ref_latent_dev, s2v_stream stream);
 
 /* CogVideoXTransformer3DModel.forward (cogvideox_transformer_3d.py:450-560) with eval=True.
  * latents [B,F,C,H,W] (lat_bstride = elements between samples, 0 = all samples share one latent), timesteps fp32
  * DEVICE [B]; out [B,F,C,H,W]. */
-int s2v_transformer_forward(s2v_ctx* ctx, const void* latents, int64_t lat_bstride, const float* timesteps_dev,
+S2V_API int s2v_transformer_forward(s2v_ctx* ctx, const void* latents, int64_t lat_bstride, const float* timesteps_dev,
                             void* out, s2v_stream stream);
 
 /* CogVideoXBlock.forward (cogvideox_transformer_3d.py:122-186) for layer `layer`: three residual streams in/out,
  * hidden [B,V,D], enc0 (text) [B,T,D], enc1 (ref) [B,R,D], temb [B,time_embed_dim]. */
-int s2v_block_forward(s2v_ctx* ctx, int32_t layer, const void* hidden, const void* enc0, const void* enc1,
+S2V_API int s2v_block_forward(s2v_ctx* ctx, int32_t layer, const void* hidden, const void* enc0, const void* enc1,
                       const void* temb, void* out_hidden, void* out_enc0, void* out_enc1, s2v_stream stream);
 
 /* CogVideoXAttnProcessor2_0.__call__ (attention_processor.py:2024-2097) with layer `layer`'s attn1 weights:
  * hidden [B,V,D] and encoder [B,T+R,D] are the already-modulated inputs; outputs have the same shapes. */
-int s2v_attn_forward(s2v_ctx* ctx, int32_t layer, const void* hidden, const void* encoder, void* out_hidden,
+S2V_API int s2v_attn_forward(s2v_ctx* ctx, int32_t layer, const void* hidden, const void* encoder, void* out_hidden,
                      void* out_encoder, s2v_stream stream);
 
 /* Per-step scheduler scalars, computed on the host exactly as scheduling_ddim_cogvideox.py:364-394 /
@@ -113,7 +120,7 @@ typedef struct s2v_sched_coef {
  *       bit2: latents_out is fp32 and un-rounded (scheduler.step's own return value) instead of `dtype`.
  * latents in/out [n] (may alias); x0_hist fp32 [n] (DPM: read as old x0, then overwritten; may be NULL for DDIM);
  * noise [n] in `dtype` (DPM only). */
-int s2v_sched_step(s2v_ctx* ctx, const s2v_sched_coef* coef_host, const void* noise_pred, int32_t flags,
+S2V_API int s2v_sched_step(s2v_ctx* ctx, const s2v_sched_coef* coef_host, const void* noise_pred, int32_t flags,
                    const void* latents_in, void* latents_out, float* x0_hist, const void* noise, int64_t n,
                    int32_t dtype, s2v_stream stream);
 
@@ -121,19 +128,19 @@ int s2v_sched_step(s2v_ctx* ctx, const s2v_sched_coef* coef_host, const void* no
  * `latents` [1,F,C,H,W], fp32 CFG, scheduler step, round to the model dtype; latents updated IN PLACE.
  * use_graph != 0 captures the launch sequence into a hipGraph on first use and replays it afterwards
  * (timestep and coefficients live in device memory, so one graph serves all steps). */
-int s2v_denoise_step(s2v_ctx* ctx, void* latents, float timestep, const s2v_sched_coef* coef_host, float* x0_hist,
+S2V_API int s2v_denoise_step(s2v_ctx* ctx, void* latents, float timestep, const s2v_sched_coef* coef_host, float* x0_hist,
                      const void* noise, int32_t use_graph, s2v_stream stream);
 /* pointer to the [B,F,C,H,W] model output of the last s2v_denoise_step (context-owned, model dtype) */
-int s2v_last_noise_pred(s2v_ctx* ctx, void** dev_ptr);
+S2V_API int s2v_last_noise_pred(s2v_ctx* ctx, void** dev_ptr);
 
 /* Live per-kernel timing for the roofline report (bench.py): HIP events are recorded on the launch stream around
  * every launch of a class; classes 0 qkv GEMM, 1 attention, 2 out-proj GEMM, 3 FF1 GEMM, 4 FF2 GEMM,
  * 5 LN-modulate, 6 qk-norm/rope/V^T.  Not recorded inside a captured graph.  s2v_profile_read synchronises the
  * device, returns total ms and launch counts per class since the previous read, and resets the counters. */
-int s2v_profile_enable(s2v_ctx* ctx, int32_t on);
-int s2v_profile_read(s2v_ctx* ctx, float* ms_by_class, int32_t* launches_by_class, int32_t nclass);
+S2V_API int s2v_profile_enable(s2v_ctx* ctx, int32_t on);
+S2V_API int s2v_profile_read(s2v_ctx* ctx, float* ms_by_class, int32_t* launches_by_class, int32_t nclass);
 /* Marks every tensor as loaded on a replica whose arena was filled by a broadcast of s2v_weight_arena. */
-int s2v_mark_weights_loaded(s2v_ctx* ctx);
+S2V_API int s2v_mark_weights_loaded(s2v_ctx* ctx);
 
 /* ---- CogVideoX 3-D causal VAE decode ------------------------------------------------------------------------- */
 typedef struct s2v_vae s2v_vae;
@@ -154,22 +161,22 @@ typedef struct s2v_vae_config {
     int32_t reserved[4];
 } s2v_vae_config;
 
-int s2v_vae_create(const s2v_vae_config* cfg, s2v_vae** out);
-void s2v_vae_destroy(s2v_vae* vae);
+S2V_API int s2v_vae_create(const s2v_vae_config* cfg, s2v_vae** out);
+S2V_API void s2v_vae_destroy(s2v_vae* vae);
 /* name = the reference's state-dict key ("decoder.conv_in.conv.weight", "decoder.up_blocks.1.resnets.0.conv_shortcut.
  * weight", "decoder.mid_block.resnets.0.norm1.conv_y.conv.bias", ...); conv weights are re-packed to
  * [cout][(dt,dy,dx)][cin] for the channels-last implicit GEMM. */
-int s2v_vae_load_weight(s2v_vae* vae, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
+S2V_API int s2v_vae_load_weight(s2v_vae* vae, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
                         int32_t src_dtype, s2v_stream stream);
-int s2v_vae_finalize(s2v_vae* vae);
+S2V_API int s2v_vae_finalize(s2v_vae* vae);
 /* Replicas ("11.14 GB transformer + 0.25 GB VAE decoder" are broadcast rank0 -> all): every weight of
  * a handle (decoder, or encoder for an s2v_vae_enc_create handle) lives in ONE device range; the receiving rank copies into
  * it and calls s2v_vae_mark_weights_loaded instead of s2v_vae_load_weight + s2v_vae_finalize.  Stands where the reference
  * would call .to(device) on every rank after from_pretrained (src/inference.py:191-215). */
-int s2v_vae_weight_arena(s2v_vae* vae, void** dev_ptr, int64_t* bytes);
-int s2v_vae_mark_weights_loaded(s2v_vae* vae);
+S2V_API int s2v_vae_weight_arena(s2v_vae* vae, void** dev_ptr, int64_t* bytes);
+S2V_API int s2v_vae_mark_weights_loaded(s2v_vae* vae);
 /* output extent of s2v_vae_decode for latents [1,F,C,h,w] */
-int s2v_vae_out_shape(s2v_vae* vae, int32_t F, int32_t h, int32_t w, int32_t tiling, int32_t* Fo, int32_t* Ho, int32_t* Wo);
+S2V_API int s2v_vae_out_shape(s2v_vae* vae, int32_t F, int32_t h, int32_t w, int32_t tiling, int32_t* Fo, int32_t* Ho, int32_t* Wo);
 /* CogVideoXPipeline.decode_latents (pipeline_cogvideox.py:346-351) = 1/scaling_factor * latents, then
  * AutoencoderKLCogVideoX.decode (:1259-1282): frame batches (3,2,2,...) with conv_cache, GroupNorm statistics per
  * frame batch (and per tile when tiling != 0: tiled_decode :1374-1455 incl. its raster-order in-place blends).
@@ -177,15 +184,15 @@ int s2v_vae_out_shape(s2v_vae* vae, int32_t F, int32_t h, int32_t w, int32_t til
  * 1/scaling_factor here), scaled == 0: already z = latents/scaling_factor (the argument of vae.decode);
  * out [1,out_channels,Fo,Ho,Wo] model dtype.
  * Buffers are (re)allocated when a larger geometry is seen for the first time, never otherwise. */
-int s2v_vae_decode(s2v_vae* vae, const void* latents, int32_t F, int32_t h, int32_t w, int32_t tiling, int32_t scaled,
+S2V_API int s2v_vae_decode(s2v_vae* vae, const void* latents, int32_t F, int32_t h, int32_t w, int32_t tiling, int32_t scaled,
                    void* out, s2v_stream stream);
 /* VideoProcessor.postprocess_video(output_type="np") (video_processor.py:89-113, image_processor.py:227-240):
  * video [C,F,H,W] -> float32 [F,H,W,C], clamp(x/2 + 0.5, 0, 1) */
-int s2v_vae_postprocess(const void* video, int32_t C, int32_t F, int32_t H, int32_t W, float* out, int32_t dtype,
+S2V_API int s2v_vae_postprocess(const void* video, int32_t C, int32_t F, int32_t H, int32_t W, float* out, int32_t dtype,
                         s2v_stream stream);
 /* the same followed by export_to_video's frame conversion `(frame * 255).astype(np.uint8)` (utils/export_utils.py:175;
  * src/video_generate.py:65-66): video [C,F,H,W] -> uint8 [F,H,W,C], what the mp4 writer consumes (4x less D2H traffic) */
-int s2v_vae_postprocess_u8(const void* video, int32_t C, int32_t F, int32_t H, int32_t W, uint8_t* out, int32_t dtype,
+S2V_API int s2v_vae_postprocess_u8(const void* video, int32_t C, int32_t F, int32_t H, int32_t W, uint8_t* out, int32_t dtype,
                            s2v_stream stream);
 
 /* ---- reference-image encode (the step in front of the denoise loop) ------------------------------------------
@@ -196,16 +203,16 @@ int s2v_vae_postprocess_u8(const void* video, int32_t C, int32_t F, int32_t H, i
  * s2v_vae_enc_create builds an s2v_vae handle that holds the ENCODER; its weights are loaded with s2v_vae_load_weight
  * under the reference's "encoder.*" state-dict keys, then s2v_vae_finalize; s2v_vae_destroy frees it.
  * cfg: same struct as the decoder (out_channels = image channels 3, latent_channels = 16). */
-int s2v_vae_enc_create(const s2v_vae_config* cfg, s2v_vae** out);
+S2V_API int s2v_vae_enc_create(const s2v_vae_config* cfg, s2v_vae** out);
 /* latent extent of s2v_vae_encode for an H x W image */
-int s2v_vae_encode_shape(s2v_vae* enc, int32_t H, int32_t W, int32_t tiling, int32_t* h, int32_t* w);
+S2V_API int s2v_vae_encode_shape(s2v_vae* enc, int32_t H, int32_t W, int32_t tiling, int32_t* h, int32_t* w);
 /* image [3,1,H,W] (model dtype, values in [-1,1]) -> moments [2*latent_channels,1,h,w] = the `parameters` of the
  * reference's DiagonalGaussianDistribution (mean | logvar); tiling != 0 follows tiled_encode when the image exceeds
  * (sample_height/2, sample_width/2). */
-int s2v_vae_encode(s2v_vae* enc, const void* image, int32_t H, int32_t W, int32_t tiling, void* moments, s2v_stream stream);
+S2V_API int s2v_vae_encode(s2v_vae* enc, const void* image, int32_t H, int32_t W, int32_t tiling, void* moments, s2v_stream stream);
 /* DiagonalGaussianDistribution.sample with the caller's randn: out[c,i] = mean + exp(0.5 * clamp(logvar, -30, 20)) * noise,
  * every operation rounded to `dtype` like the reference's tensor ops; moments [2*C, n_spatial], noise / out [C, n_spatial] */
-int s2v_vae_gaussian_sample(const void* moments, const void* noise, int32_t latent_channels, int64_t n_spatial, void* out,
+S2V_API int s2v_vae_gaussian_sample(const void* moments, const void* noise, int32_t latent_channels, int64_t n_spatial, void* out,
                             int32_t dtype, s2v_stream stream);
 
 /* ---- prompt embeddings: T5 v1.1 encoder (the other caller-side step in front of the denoise loop) ----------------
@@ -227,29 +234,29 @@ typedef struct s2v_t5_config {
     float layer_norm_epsilon;                  /* 1e-6 */
     int32_t reserved[5];
 } s2v_t5_config;
-int s2v_t5_create(const s2v_t5_config* cfg, s2v_t5** out);
-void s2v_t5_destroy(s2v_t5* t5);
-int s2v_t5_load_weight(s2v_t5* t5, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
+S2V_API int s2v_t5_create(const s2v_t5_config* cfg, s2v_t5** out);
+S2V_API void s2v_t5_destroy(s2v_t5* t5);
+S2V_API int s2v_t5_load_weight(s2v_t5* t5, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
                        int32_t src_dtype, s2v_stream stream);
-int s2v_t5_finalize(s2v_t5* t5);
+S2V_API int s2v_t5_finalize(s2v_t5* t5);
 /* the same replica hand-off for the text encoder (9.4 GB in bf16) */
-int s2v_t5_weight_arena(s2v_t5* t5, void** dev_ptr, int64_t* bytes);
-int s2v_t5_mark_weights_loaded(s2v_t5* t5);
+S2V_API int s2v_t5_weight_arena(s2v_t5* t5, void** dev_ptr, int64_t* bytes);
+S2V_API int s2v_t5_mark_weights_loaded(s2v_t5* t5);
 /* device address of the loaded block-0 relative_attention_bias table [num_buckets, num_heads] (model dtype) */
-int s2v_t5_rel_table(s2v_t5* t5, void** dev_ptr);
+S2V_API int s2v_t5_rel_table(s2v_t5* t5, void** dev_ptr);
 /* position_bias [num_heads, T, T] (model dtype) = T5Attention.compute_bias(T, T) of block 0, gathered by the host from
  * s2v_t5_rel_table with the implementation's own bucket function; sizes the workspace for (B, T) */
-int s2v_t5_set_position_bias(s2v_t5* t5, const void* bias_dev, int32_t B, int32_t T, s2v_stream stream);
+S2V_API int s2v_t5_set_position_bias(s2v_t5* t5, const void* bias_dev, int32_t B, int32_t T, s2v_stream stream);
 /* input_ids int64 [B, T] -> last_hidden_state [B, T, d_model] (model dtype) */
-int s2v_t5_encode(s2v_t5* t5, const int64_t* input_ids_dev, int32_t B, int32_t T, void* out, s2v_stream stream);
+S2V_API int s2v_t5_encode(s2v_t5* t5, const int64_t* input_ids_dev, int32_t B, int32_t T, void* out, s2v_stream stream);
 
 /* ---- operator-level entry points (used by the parity tests and micro-benchmarks) ------------------------- */
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic */
-int s2v_op_linear(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
+S2V_API int s2v_op_linear(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
                   int32_t epilogue, int32_t dtype, int32_t impl, s2v_stream stream);
 /* qkv [B*Ntok (+64 rows of slack), 3*H*64] -> out [B*Ntok, H*64]; impl 0 = MFMA flash kernel (needs vt scratch
  * [B*H*64*ceil64(Ntok)] bf16, zero-filled by the caller), 1 = generic */
-int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype,
+S2V_API int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype,
                      int32_t impl, s2v_stream stream);
 
 #ifdef __cplusplus

@@ -110,6 +110,12 @@ def test_library_exports_every_declared_symbol(s2v):
     lib = ctypes.CDLL(s2v._lib.LIB_PATH)
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, missing
+    # ... and nothing else: the library is built with -fvisibility=hidden, diagnostics live in libs2v_hip_diag.so
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", s2v._lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if " T " in ln}
+    assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
     # everything the Python binding uses is declared in the header
     bound = set(s2v._lib._SIGS)
     assert bound <= declared | {"s2v_mark_weights_loaded"}, bound - declared

@@ -36,10 +36,10 @@ def bench_gemm():
         W = (torch.randn(N, K, device=DEV) * 0.02).bfloat16()
         b = torch.zeros(N, device=DEV, dtype=torch.bfloat16)
         C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-        f = lambda: L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, epi, 1, 0, L.stream_ptr()))
+        f = lambda: L.check(L.diag_lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, epi, 1, 0, L.stream_ptr()))
         ref = None
         for impl in IMPLS:
-            L.lib().s2v_set_gemm_impl(impl)
+            L.diag_lib().s2v_set_gemm_impl(impl)
             C.zero_()
             f()
             torch.cuda.synchronize()
@@ -51,7 +51,7 @@ def bench_gemm():
             print(f"gemm[{LABELS[impl]}] {name:9s} M={M} N={N} K={K}: {ms:8.3f} ms  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
         t = timeit(lambda: torch.matmul(A, W.T), iters=5)
         print(f"   (hipBLASLt via torch.matmul: {t:8.3f} ms  {2*M*N*K/t/1e9:8.1f} TFLOP/s)", flush=True)
-        L.lib().s2v_set_gemm_impl(7)
+        L.diag_lib().s2v_set_gemm_impl(7)
         del A, W, C
 
 

@@ -12,11 +12,11 @@ for (M, N, K) in ((4096, 4096, 1024), (4096, 4096, 3072), (4096, 4096, 12288), (
     W = (torch.randn(N, K, device=DEV) * 0.02).bfloat16()
     b = torch.zeros(N, device=DEV, dtype=torch.bfloat16)
     C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-    f = lambda: L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, 0, 1, 0, L.stream_ptr()))
+    f = lambda: L.check(L.diag_lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, 0, 1, 0, L.stream_ptr()))
     tiles = (M // 256) * (N // 256)
     for name, code in (("full", 7), ("no-MFMA", 7 | (3 << 8)), ("no-DMA", 7 | (1 << 8))):
-        L.lib().s2v_set_gemm_impl(code)
+        L.diag_lib().s2v_set_gemm_impl(code)
         ms = timeit(f, iters=20)
         by = tiles * 2 * 256 * K * 2
         print(f"tiles={tiles:5d} K={K:5d} {name:8s}: {ms:7.3f} ms  DMA {by/ms/1e9:7.2f} TB/s = {by/ms/1e6/min(tiles,256)/2.1:6.1f} B/clk/CU@2.1GHz  ({2*M*N*K/ms/1e9:7.1f} TF)", flush=True)
-L.lib().s2v_set_gemm_impl(7)
+L.diag_lib().s2v_set_gemm_impl(7)
