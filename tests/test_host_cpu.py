@@ -181,3 +181,19 @@ def test_seam_cache_keys_on_identity_version_and_engine_epoch():
     c.store(e, t)
     del t
     assert w() is not None              # strong reference held by the key
+
+
+def test_export_to_video_writes_a_readable_file_without_imageio(s2v, tmp_path):
+    """utils/export_utils.py:143-186: the frames handed to export_to_video come back out of the file (frame count, fps, size,
+    content of the first frame up to JPEG loss); without imageio-ffmpeg the container is Motion-JPEG AVI"""
+    vg = s2v.video_generate
+    yy, xx = np.mgrid[0:48, 0:80]
+    frames = np.stack([np.stack([(xx * 3 + 10 * f) % 256, (yy * 5) % 256, np.full_like(xx, 40 * f % 256)], -1) for f in range(9)]).astype(np.uint8)
+    out = vg.export_to_video(frames, str(tmp_path / "clip.mp4"), fps=8)
+    assert os.path.exists(out) and os.path.getsize(out) > 1000
+    if out.endswith(".avi"):
+        n, fps, w, h, first = vg.read_avi_info(out)
+        assert (n, w, h) == (9, 80, 48) and abs(fps - 8.0) < 1e-6
+        assert np.abs(first.astype(int) - frames[0].astype(int)).mean() < 6.0
+    with pytest.raises(ValueError):
+        vg.export_to_video(frames.astype(np.float32) / 255.0, str(tmp_path / "bad.mp4"))
