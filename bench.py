@@ -23,6 +23,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak (block-scaled f8f6f4 instructions), same guide
 CLASSES = ["gemm_qkv", "attention", "gemm_out", "gemm_ff1_gelu", "gemm_ff2", "ln_modulate", "qknorm_rope_vt"]
 
 WORKLOADS = {
@@ -30,8 +31,10 @@ WORKLOADS = {
     "cogvideox-5b-49x480x720": ("cogvideox-5b", 13, 60, 90, 226),
     "cogvideox-2b-49x480x720": ("cogvideox-2b", 13, 60, 90, 226),
     "cogvideox-2b-9x256x256": ("cogvideox-2b", 3, 32, 32, 226),
-    # the geometry of BASELINE configs[4] (49 frames 720x1280, N = 50626 tokens) on the bf16 path; its fp8-weight form is not built
+    # the geometry of BASELINE configs[4] (49 frames 720x1280, N = 50626 tokens): bf16, and with W8A8 fp8 linears (configs[4] itself)
     "cogvideox-5b-49x720x1280": ("cogvideox-5b", 13, 90, 160, 226),
+    "cogvideox-5b-fp8-49x720x1280": ("cogvideox-5b-fp8", 13, 90, 160, 226),
+    "cogvideox-5b-fp8-49x480x720": ("cogvideox-5b-fp8", 13, 60, 90, 226),
 }
 
 
@@ -155,6 +158,7 @@ def main():
 
     preset, F, H, W, T = WORKLOADS[args.workload]
     cfg = s2v.config.PRESETS[preset]()
+    fp8 = cfg.weight_format == "fp8"
     dt = torch.bfloat16
     eng = s2v.S2VEngine(cfg, dt, dev)
     t_load = time.time()
@@ -246,6 +250,8 @@ def main():
             e = {"avg_ms": round(avg, 4), "launches": int(cnt[k]), "share_of_step": round(ms[k] / (prof_elapsed * 1e3), 4)}
             if name in flops:
                 e["tflops"] = round(flops[name] / avg / 1e9, 1)
+                e["peak_tflops"] = PEAK_FP8_TFLOPS if (fp8 and name.startswith("gemm_")) else PEAK_BF16_TFLOPS
+                e["frac_of_peak"] = round(e["tflops"] / e["peak_tflops"], 4)
             per_kernel[name] = e
         dom = max((n for n in per_kernel if n in flops), key=lambda n: per_kernel[n]["avg_ms"] * per_kernel[n]["launches"])
         ach = per_kernel[dom]["tflops"]
@@ -317,7 +323,7 @@ def main():
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
+            "dtype": "fp8 (e4m3 W8A8 block linears) + bf16" if fp8 else "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
             "config": {"workload": args.workload, "latent_frames": F, "latent_hw": [H, W], "tokens": T + (F + 1) * (H // 2) * (W // 2),
                        "cfg_pair": 2, "scheduler": "ddim-trailing-50", "parallelism": f"replicas x{args.gpus}",
                        "hipgraph": bool(args.graph), "graph_ms_per_step": None if graph_ms is None else round(graph_ms, 2),
@@ -328,7 +334,7 @@ def main():
             "roofline": roofline,
             "wall_clock_per_video": video,
         }
-        if not args.no_cpu_baseline and args.gpus == 1:
+        if not args.no_cpu_baseline and args.gpus == 1 and not fp8:
             out["cpu_baseline"] = cpu_baseline(s2v, cfg, F, H, W, T, dev)
         print(json.dumps(out), flush=True)
     if world > 1:

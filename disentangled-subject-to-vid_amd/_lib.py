@@ -18,7 +18,8 @@ class ModelConfigC(ctypes.Structure):
         ("num_layers", ctypes.c_int32), ("num_heads", ctypes.c_int32), ("in_channels", ctypes.c_int32),
         ("out_channels", ctypes.c_int32), ("patch_size", ctypes.c_int32), ("time_embed_dim", ctypes.c_int32),
         ("text_embed_dim", ctypes.c_int32), ("use_rope", ctypes.c_int32), ("dtype", ctypes.c_int32),
-        ("norm_eps", ctypes.c_float), ("force_simple", ctypes.c_int32), ("reserved", ctypes.c_int32 * 5),
+        ("norm_eps", ctypes.c_float), ("force_simple", ctypes.c_int32), ("weight_format", ctypes.c_int32),
+        ("reserved", ctypes.c_int32 * 4),
     ]
 
 
@@ -56,6 +57,7 @@ _SIGS = {
     "s2v_profile_read": [_P, ctypes.POINTER(_F), ctypes.POINTER(_I32), _I32],
     "s2v_op_linear": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "s2v_op_attention": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "s2v_op_linear_fp8": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P],
 }
 # VAE entry points are registered by vae.py through register_sigs()
 

@@ -22,6 +22,8 @@ class TransformerConfig:
     temporal_interpolation_scale: float = 1.0
     snr_shift_scale: float = 3.0          # scheduler config that ships with the model
     vae_scaling_factor: float = 1.15258426
+    # "fp8": W8A8 on the fp8 matrix cores for the four big linears of every block (BASELINE configs[4]); None: model dtype
+    weight_format: str = None
 
     @property
     def inner_dim(self):
@@ -60,4 +62,10 @@ class VAEConfig:
     scaling_factor: float = 1.15258426
 
 
-PRESETS = {"cogvideox-2b": cogvideox_2b, "cogvideox-5b": cogvideox_5b}
+def cogvideox_5b_fp8():
+    cfg = cogvideox_5b()
+    cfg.weight_format = "fp8"
+    return cfg
+
+
+PRESETS = {"cogvideox-2b": cogvideox_2b, "cogvideox-5b": cogvideox_5b, "cogvideox-5b-fp8": cogvideox_5b_fp8}

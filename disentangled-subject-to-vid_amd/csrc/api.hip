@@ -31,6 +31,9 @@ struct LayerW {
     char *ln1_w, *ln1_b, *ln2_w, *ln2_b;
     char *wqkv, *bqkv, *nq_w, *nq_b, *nk_w, *nk_b, *wo, *bo;
     char *w1, *b1, *w2, *b2;
+    // weight_format 1: e4m3 copies [N_pad][K] of the four big linears + per-output-channel scales (quantised at finalize)
+    char *q_qkv = nullptr, *q_o = nullptr, *q_1 = nullptr, *q_2 = nullptr;
+    float *s_qkv = nullptr, *s_o = nullptr, *s_1 = nullptr, *s_2 = nullptr;
 };
 
 struct GraphKey {
@@ -42,6 +45,9 @@ struct s2v_ctx {
     s2v_model_config cfg;
     int D = 0, L = 0, dtype = 0, esz = 0, temb = 0;
     bool mfma = false;
+    bool fp8 = false;            // cfg.weight_format == 1
+    char* aq = nullptr;          // workspace: e4m3 activations [Mpad][4D] of the GEMM being fed
+    float* aq_scale = nullptr;   // workspace: their per-token scales [Mpad]
     bool finalized = false;
     // weights
     int num_cus = 256;
@@ -166,6 +172,17 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     const int64_t o_po_w = carve(rup(Cout, 256) * D), o_po_b = carve(Cout);
     c->mod_rows = 2 * L * 6 * D + 2 * D;
     const int64_t o_mod_w = carve(c->mod_rows * TE), o_mod_b = carve(c->mod_rows);
+    // fp8 copies live in the same arena (one broadcast replicates everything a replica needs)
+    c->fp8 = cfg->weight_format == 1;
+    if (cfg->weight_format != 0 && cfg->weight_format != 1) { delete c; return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format must be 0 or 1", -1); }
+    if (c->fp8 && (!c->mfma || D % 128 != 0)) { delete c; return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format 1 (fp8) needs the bf16 MFMA path and inner_dim % 128 == 0", -1); }
+    struct QOffs { int64_t q_qkv, q_o, q_1, q_2, s_qkv, s_o, s_1, s_2; };
+    std::vector<QOffs> qo(c->fp8 ? L : 0);
+    auto carve_b = [&](int64_t bytes) { int64_t o = off; off += rup(bytes, 256); return o; };
+    for (auto& q : qo) {
+        q.q_qkv = carve_b(rup(3 * D, 256) * D); q.q_o = carve_b(Dp * D); q.q_1 = carve_b(rup(4 * D, 256) * D); q.q_2 = carve_b(Dp * 4 * D);
+        q.s_qkv = carve_b(rup(3 * D, 256) * 4); q.s_o = carve_b(Dp * 4); q.s_1 = carve_b(rup(4 * D, 256) * 4); q.s_2 = carve_b(Dp * 4);
+    }
     c->arena_bytes = off;
     hipError_t e = hipMalloc((void**)&c->arena, c->arena_bytes);
     if (e != hipSuccess) { delete c; return s2v_fail(__FILE__, __LINE__, hipGetErrorString(e), -2); }
@@ -181,6 +198,11 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
         w.wqkv = A + o.wqkv; w.bqkv = A + o.bqkv; w.nq_w = A + o.nq_w; w.nq_b = A + o.nq_b;
         w.nk_w = A + o.nk_w; w.nk_b = A + o.nk_b; w.wo = A + o.wo; w.bo = A + o.bo;
         w.w1 = A + o.w1; w.b1 = A + o.b1; w.w2 = A + o.w2; w.b2 = A + o.b2;
+        if (c->fp8) {
+            const QOffs& q = qo[l];
+            w.q_qkv = A + q.q_qkv; w.q_o = A + q.q_o; w.q_1 = A + q.q_1; w.q_2 = A + q.q_2;
+            w.s_qkv = (float*)(A + q.s_qkv); w.s_o = (float*)(A + q.s_o); w.s_1 = (float*)(A + q.s_1); w.s_2 = (float*)(A + q.s_2);
+        }
 #define NM(fmt) (snprintf(nm, sizeof(nm), "transformer_blocks.%d." fmt, l), std::string(nm))
         add_slot(c, NM("norm1.norm.weight"), w.ln1_w, 1, D, D);
         add_slot(c, NM("norm1.norm.bias"), w.ln1_b, 1, D, D);
@@ -306,6 +328,18 @@ extern "C" int s2v_finalize_weights(s2v_ctx* c, s2v_stream stream) {
             return s2v_fail(__FILE__, __LINE__, m.c_str(), -3);
         }
     }
+    if (c->fp8) {
+        // per-output-channel e4m3 quantisation of the (LoRA-merged) bf16 weights; the zero pad rows get scale 1, bytes 0
+        const int64_t D = c->D, Dp = rup(D, 256);
+        hipStream_t st = (hipStream_t)stream;
+        for (auto& w : c->layers) {
+            S2V_TRY(launch_quant_rows_fp8(w.wqkv, D, rup(3 * D, 256), (int)D, w.q_qkv, w.s_qkv, st));
+            S2V_TRY(launch_quant_rows_fp8(w.wo, D, Dp, (int)D, w.q_o, w.s_o, st));
+            S2V_TRY(launch_quant_rows_fp8(w.w1, D, rup(4 * D, 256), (int)D, w.q_1, w.s_1, st));
+            S2V_TRY(launch_quant_rows_fp8(w.w2, 4 * D, Dp, (int)(4 * D), w.q_2, w.s_2, st));
+        }
+        S2V_CHECK_HIP(hipStreamSynchronize(st));
+    }
     c->finalized = true;
     return 0;
 }
@@ -356,6 +390,7 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     const int64_t onp = carve((int64_t)B * F * c->cfg.out_channels * H * W * E);
     const int64_t ocos = carve((int64_t)(c->R + c->V) * 64 * 4), osin = carve((int64_t)(c->R + c->V) * 64 * 4);
     const int64_t opos = carve((int64_t)c->V * D * E);
+    const int64_t oaq = carve(c->fp8 ? c->Mpad * 4 * D : 0), oaqs = carve(c->fp8 ? c->Mpad * 4 : 0);
     c->ws_bytes = off;
     S2V_CHECK_HIP(hipMalloc((void**)&c->ws, c->ws_bytes));
     S2V_CHECK_HIP(hipMemset(c->ws, 0, c->ws_bytes));
@@ -364,6 +399,7 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     c->patches = w + opat; c->tailn = w + otail; c->proj = w + oproj; c->mod = w + omod; c->tmp_te = w + ote;
     c->emb = w + oemb; c->noise_pred = w + onp; c->rope_cos = (float*)(w + ocos); c->rope_sin = (float*)(w + osin);
     c->pos_tab = w + opos;
+    c->aq = w + oaq; c->aq_scale = (float*)(w + oaqs);
     return 0;
 }
 
@@ -416,6 +452,17 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
     return launch_gemm_simple(g, epi, c->dtype, st);
 }
 
+// weight_format 1: quantise the activation rows (per token, dynamic) and run the fp8 GEMM against the e4m3 weight copy
+static int linear_fp8(s2v_ctx* c, const GemmArgs& g0, int epi, const char* wq, const float* wscale, hipStream_t st) {
+    GemmArgs g = g0;
+    S2V_TRY(launch_quant_rows_fp8(g.A, g.lda, g.M, g.K, c->aq, c->aq_scale, st));
+    g.A = c->aq; g.lda = g.K; g.W = wq; g.ldw = g.K;
+    g.a_scale = c->aq_scale; g.w_scale = wscale;
+    g.a_rows_padded = (int)rup(g.M, 256);
+    g.w_rows_padded = (int)rup(g.N, 256);
+    return launch_gemm_fp8(g, epi, st);
+}
+
 extern "C" int s2v_set_conditioning(s2v_ctx* c, const void* text_dev, const void* ref_latent_dev, s2v_stream stream) {
     S2V_REQUIRE(c && c->ws && c->finalized, "s2v_set_conditioning: geometry and weights must be set first");
     S2V_REQUIRE(text_dev && ref_latent_dev, "s2v_set_conditioning: null input");
@@ -450,7 +497,11 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st) {
     GemmArgs g{};
     g.A = c->Xn; g.lda = D; g.W = w.wqkv; g.ldw = D; g.bias = w.bqkv;
     g.C = c->QKV; g.ldc = 3 * D; g.M = (int)c->M; g.N = 3 * D; g.K = D;
-    { ProfScope ps(c, PK_QKV, st); S2V_TRY(linear(c, g, EPI_BIAS, st)); }
+    {
+        ProfScope ps(c, PK_QKV, st);
+        if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS, w.q_qkv, w.s_qkv, st));
+        else S2V_TRY(linear(c, g, EPI_BIAS, st));
+    }
     QkNormRopeArgs q{};
     q.qkv = c->QKV; q.ld_qkv = 3 * D; q.B = c->B; q.H = c->cfg.num_heads; q.Ntok = c->Ntok; q.text_len = c->T;
     q.nq_w = w.nq_w; q.nq_b = w.nq_b; q.nk_w = w.nk_w; q.nk_b = w.nk_b; q.eps = 1e-6f;
@@ -486,15 +537,21 @@ static int run_block(s2v_ctx* c, int l, const char* mod_base /* [B][mod_stride] 
             S2V_TRY(run_attention(c, l, st));
             g.A = c->Xn; g.lda = D; g.W = w.wo; g.ldw = D; g.bias = w.bo; g.K = D;
             ProfScope ps(c, PK_OUT, st);
-            S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
+            if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS_GATE_RES, w.q_o, w.s_o, st));
+            else S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
         } else {
             GemmArgs f{};
             f.A = c->Xn; f.lda = D; f.W = w.w1; f.ldw = D; f.bias = w.b1; f.C = c->Hb; f.ldc = 4 * D;
             f.M = (int)c->M; f.N = 4 * D; f.K = D;
-            { ProfScope ps(c, PK_FF1, st); S2V_TRY(linear(c, f, EPI_BIAS_GELU, st)); }
+            {
+                ProfScope ps(c, PK_FF1, st);
+                if (c->fp8) S2V_TRY(linear_fp8(c, f, EPI_BIAS_GELU, w.q_1, w.s_1, st));
+                else S2V_TRY(linear(c, f, EPI_BIAS_GELU, st));
+            }
             g.A = c->Hb; g.lda = 4 * D; g.W = w.w2; g.ldw = 4 * D; g.bias = w.b2; g.K = 4 * D;
             ProfScope ps(c, PK_FF2, st);
-            S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
+            if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS_GATE_RES, w.q_2, w.s_2, st));
+            else S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
         }
     }
     return 0;
@@ -711,6 +768,28 @@ extern "C" int s2v_op_linear(const void* A, const void* W, const void* bias, voi
         return launch_gemm_bf16(g, epilogue, (hipStream_t)stream);
     }
     return launch_gemm_simple(g, epilogue, dtype, (hipStream_t)stream);
+}
+
+// C = epilogue(dequant(quant_rows(A) . quant_rows(W)^T) + bias): both bf16 operands are quantised per row to e4m3 (dynamic
+// per-token / per-output-channel scales) into `scratch` and multiplied on the fp8 matrix cores.  M, N multiples of 256, K of 128.
+extern "C" int s2v_op_linear_fp8(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
+                                 int32_t epilogue, void* scratch, int64_t scratch_bytes, s2v_stream stream) {
+    S2V_REQUIRE(A && W && C && scratch, "s2v_op_linear_fp8: null argument");
+    S2V_REQUIRE(epilogue == EPI_BIAS || epilogue == EPI_BIAS_GELU, "s2v_op_linear_fp8: epilogue must be 0 or 1");
+    S2V_REQUIRE(M % 256 == 0 && N % 256 == 0 && K % 128 == 0, "s2v_op_linear_fp8: M, N multiples of 256 and K of 128");
+    const int64_t need = (int64_t)M * K + (int64_t)N * K + 4 * ((int64_t)M + N);
+    S2V_REQUIRE(scratch_bytes >= need, "s2v_op_linear_fp8: scratch too small (M*K + N*K + 4*(M+N) bytes)");
+    hipStream_t st = (hipStream_t)stream;
+    char* aq = (char*)scratch;
+    char* wq = aq + (int64_t)M * K;
+    float* as = (float*)(wq + (int64_t)N * K);
+    float* ws = as + M;
+    S2V_TRY(launch_quant_rows_fp8(A, K, M, K, aq, as, st));
+    S2V_TRY(launch_quant_rows_fp8(W, K, N, K, wq, ws, st));
+    GemmArgs g{};
+    g.A = aq; g.lda = K; g.W = wq; g.ldw = K; g.bias = bias; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    g.a_rows_padded = M; g.w_rows_padded = N; g.a_scale = as; g.w_scale = ws;
+    return launch_gemm_fp8(g, epilogue, st);
 }
 
 extern "C" int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok,

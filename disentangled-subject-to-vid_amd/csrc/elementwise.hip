@@ -530,3 +530,46 @@ int launch_convert2d(const void* src, int sdt, int64_t lds_, void* dst, int ddt,
 int launch_convert(const void* src, int sdt, void* dst, int ddt, int64_t n, hipStream_t st) {
     return launch_convert2d(src, sdt, n, dst, ddt, n, 1, n, st);
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Dynamic per-row fp8 quantisation (W8A8, BASELINE configs[4]): one wave per row, two passes over a row that stays in L2 / registers:
+// amax -> scale = amax / 448 (the largest e4m3 magnitude) -> q = rne_e4m3(x / scale).  Also quantises the weights at load time (a
+// weight row = an output channel).  Rows are padded to the caller's tile by zero scales / zero bytes outside [0, M).
+__global__ __launch_bounds__(256) void quant_rows_fp8_k(const bf16_t* src, int64_t ld, int64_t M, int K, unsigned char* dst, float* scale) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16_t* x = src + row * ld;
+    float amax = 0.f;
+    for (int k = lane * 8; k < K; k += 512) {
+        const u32x4 v = *(const u32x4*)(x + k);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            amax = fmaxf(amax, fabsf(__uint_as_float(v[e] << 16)));
+            amax = fmaxf(amax, fabsf(__uint_as_float(v[e] & 0xffff0000u)));
+        }
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) scale[row] = sc;
+    unsigned char* q = dst + row * (int64_t)K;
+    for (int k = lane * 8; k < K; k += 512) {
+        const u32x4 v = *(const u32x4*)(x + k);
+        u32x2 o;
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(v[0] << 16) * inv, __uint_as_float(v[0] & 0xffff0000u) * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(v[1] << 16) * inv, __uint_as_float(v[1] & 0xffff0000u) * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(v[2] << 16) * inv, __uint_as_float(v[2] & 0xffff0000u) * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(__uint_as_float(v[3] << 16) * inv, __uint_as_float(v[3] & 0xffff0000u) * inv, w1, true);
+        o.x = (unsigned)w0; o.y = (unsigned)w1;
+        *(u32x2*)(q + k) = o;
+    }
+}
+int launch_quant_rows_fp8(const void* src, int64_t ld, int64_t M, int K, void* dst, float* scale, hipStream_t st) {
+    S2V_REQUIRE(K % 8 == 0 && ld % 8 == 0, "quant_rows_fp8: K and the row stride must be multiples of 8");
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(quant_rows_fp8_k, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, (const bf16_t*)src, ld, M, K, (unsigned char*)dst, scale);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}

@@ -138,7 +138,7 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int cl) {
 // 128 B, 16-B chunks XOR-swizzled by row&7) -> read back row-major, 16 B per lane, 8 lanes per 128-B line -> gate /
 // residual in that layout -> full-line global stores.  A row-per-lane epilogue (8-B stores at a row stride) was
 // store-issue bound: ~0.7 ms of a 3.4 ms FF1 launch.
-template <int EPI, int MB>
+template <int EPI, int MB, bool SC = false>
 __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x16 (&acc)[2][MB], int mw, int nw, char* patch, int lane) {
     // MB 32-row blocks: the patch holds MB*32 rows of 128 B (8 KiB for MB = 2, 16 KiB for MB = 4); all accumulator blocks are
     // written first, then read back, so the LDS round trip and the bias loads are paid once per wave tile
@@ -158,12 +158,18 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x16 (&
             bvec[q] = u32x2{(unsigned)t[0] | ((unsigned)t[1] << 16), (unsigned)t[2] | ((unsigned)t[3] << 16)};
         }
     }
+    // SC (fp8 operands): acc * a_scale[row] * w_scale[column] first -- the dequantisation of the per-token / per-channel scales
+    float sa[MB];
+#pragma unroll
+    for (int j = 0; j < MB; ++j) sa[j] = SC ? a.a_scale[min(mw + j * 32 + fr, a.M - 1)] : 1.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int rq = 0; rq < 4; ++rq) {
             const int nl = i * 32 + 8 * rq + 4 * hi;  // local column of 4 consecutive outputs
             const u32x2 bq = bvec[i * 4 + rq];
+            f32x4 sw = {1.f, 1.f, 1.f, 1.f};
+            if (SC) sw = *(const f32x4*)(a.w_scale + nw + nl);  // the scale array is padded to the 256-column tile
             const float bv[4] = {__uint_as_float(bq.x << 16), __uint_as_float(bq.x & 0xffff0000u), __uint_as_float(bq.y << 16),
                                  __uint_as_float(bq.y & 0xffff0000u)};
 #pragma unroll
@@ -171,7 +177,8 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x16 (&
                 float y[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    y[e] = bf2f(f2bf(acc[i][j][rq * 4 + e] + bv[e]));
+                    const float av = SC ? acc[i][j][rq * 4 + e] * (sa[j] * sw[e]) : acc[i][j][rq * 4 + e];
+                    y[e] = bf2f(f2bf(av + bv[e]));
                     if (EPI == EPI_BIAS_GELU) y[e] = gelu_tanh_fast(y[e]);
                 }
                 const int row = j * 32 + fr;
@@ -223,7 +230,7 @@ __device__ __forceinline__ void epilogue_wave64(const GemmArgs& a, const f32x16 
     epilogue_wave<EPI, 2>(a, acc, mw, nw, patch, lane);
 }
 // vectorised epilogue is usable when whole 8-column groups exist and rows are 16-byte aligned
-__device__ __forceinline__ bool epi_vec_ok(const GemmArgs& a, int epi) {
+__host__ __device__ __forceinline__ bool epi_vec_ok(const GemmArgs& a, int epi) {
     if ((a.N & 7) != 0) return false;
     if (epi == EPI_BIAS_GATE_RES) return (a.ldx & 7) == 0 && (a.gate_stride & 7) == 0;
     if (epi == EPI_BIAS_ADD && (a.ldr & 7) != 0) return false;
@@ -635,8 +642,20 @@ extern "C" __attribute__((visibility("default"))) int s2v_debug_read(long long* 
 //   WAR  stage (T+1)&1 held tile T-1: A-lo(T-1) is last read in I_4T-2 (group 0 only), W-*(T-1) and A-hi(T-1) in I_4T-1;
 //        each read's lgkmcnt(0) sits after the next barrier, and one more barrier precedes the DMA issue above.
 //   RAW  tile T+1 is first read in I_4T+4 (A-lo, W-lo, W-hi) and I_4T+5 (A-hi): the waits above sit in I_4T+3 / I_4T+4.
-template <int EPI, int ABL = 0>
+// FP8: the same schedule byte for byte on e4m3 operands -- a K-tile is 128 elements = the same 128-byte rows, a half-step (64 bytes
+// of K) is ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 block (64 cycles, twice the bf16 rate) whose 32-byte operand is the
+// two 16-byte fragments a lane reads for its K half (chunks s*4 + hi*2 + {0, 1}); block scales are unit (E8M0 127), the
+// per-token / per-channel scales are applied by the epilogue.
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef int i32x8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i32x8v cat16(bf16x8 lo, bf16x8 hi) {
+    const i32x4v a = __builtin_bit_cast(i32x4v, lo), b = __builtin_bit_cast(i32x4v, hi);
+    return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+template <int EPI, int ABL = 0, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int ES = FP8 ? 1 : 2;         // bytes per operand element
+    constexpr int BKE = 128 / ES;           // elements per 128-byte K-tile
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const long long tk0 = (ABL >= 4) ? (long long)__builtin_amdgcn_s_memtime() : 0;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -657,25 +676,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
 
     // staging: piece i (0..3) of this wave covers rows g*128 + i*32 + w4*8 + (lane>>3), 8 chunks of 16 B each
     const int srow = g * 128 + w4 * 8 + (lane >> 3);
-    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) * 8;
+    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) * (16 / ES);
     // addresses = wave-uniform tile base (SGPR pair) + per-lane 32-bit byte offset (loop-invariant VGPR): the LDS-DMA takes
     // the saddr + voffset form and the load segment carries no address VALU
     const int64_t rbase0 = a_row_base(a, m0);
-    const char* Abase = (const char*)a.A + 2 * rbase0;
-    const char* Wbase = (const char*)a.W + 2 * (int64_t)n0 * a.ldw;
+    const char* Abase = (const char*)a.A + ES * rbase0;
+    const char* Wbase = (const char*)a.W + ES * (int64_t)n0 * a.ldw;
     unsigned offA[4], offW[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        offA[i] = (unsigned)(2 * (a_row_base(a, m0 + srow + i * 32) - rbase0 + scol));
-        offW[i] = (unsigned)(2 * ((int64_t)(srow + i * 32) * a.ldw + scol));
+        offA[i] = (unsigned)(ES * (a_row_base(a, m0 + srow + i * 32) - rbase0 + scol));
+        offW[i] = (unsigned)(ES * ((int64_t)(srow + i * 32) * a.ldw + scol));
     }
-    const int nT = a.K / BK;
+    const int nT = a.K / BKE;
     const int ldst = (g * 128 + w4 * 8) * 128;  // byte offset of the wave's piece 0 inside an operand image
     auto dma_a = [&](int t) {
         if (ABL == 1 && t > 0) return;
         const int tc = min(t, nT - 1);
-        const int64_t ka = a.conv ? a_k_off(a, tc * BK) : (int64_t)tc * BK;
-        const char* tb = Abase + 2 * ka;
+        const int64_t ka = a.conv ? a_k_off(a, tc * BKE) : (int64_t)tc * BKE;
+        const char* tb = Abase + ES * ka;
         char* base = smem + (t & 1) * 65536 + ldst;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -684,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
     auto dma_w = [&](int t) {
         if (ABL == 1 && t > 0) return;
         const int tc = min(t, nT - 1);
-        const char* tb = Wbase + 2 * (int64_t)tc * BK;
+        const char* tb = Wbase + ES * (int64_t)tc * BKE;
         char* base = smem + (t & 1) * 65536 + 32768 + ldst;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -714,9 +733,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) wf[kk][i] = lds_frag(tW, wn * 64 + i * 32 + fr, s * 4 + kk * 2 + hi);
+            for (int i = 0; i < 2; ++i) wf[kk][i] = lds_frag(tW, wn * 64 + i * 32 + fr, FP8 ? s * 4 + hi * 2 + kk : s * 4 + kk * 2 + hi);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[kk][j] = lds_frag(tA, wm * 128 + j * 32 + fr, s * 4 + kk * 2 + hi);
+            for (int j = 0; j < 4; ++j) af[kk][j] = lds_frag(tA, wm * 128 + j * 32 + fr, FP8 ? s * 4 + hi * 2 + kk : s * 4 + kk * 2 + hi);
         }
     };
     // (ABL >= 4): per-wave stall accounting with s_memtime (diagnostics; totals of block 100 go to g_pp_dbg[8][6])
@@ -731,15 +750,23 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
         const long long t2 = now();
         __builtin_amdgcn_sched_barrier(0);
         if (ABL != 7) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        if (FP8) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (ABL != 3 && ABL != 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
-                    else asm volatile("" ::"v"(wf[kk][i]), "v"(af[kk][j]));
-                }
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat16(wf[0][i], wf[1][i]), cat16(af[0][j], af[1][j]), acc[i][j], 0, 0, 0, 127, 0, 127);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (ABL != 3 && ABL != 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
+                        else asm volatile("" ::"v"(wf[kk][i]), "v"(af[kk][j]));
+                    }
+        }
         if (ABL != 7) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
         const long long t3 = now();
@@ -796,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
 
     char* patch = smem + wave * 16384;
     if (epi_vec_ok(a, EPI)) {
-        epilogue_wave<EPI, 4>(a, acc, m0 + wm * 128, n0 + wn * 64, patch, lane);
+        epilogue_wave<EPI, 4, FP8>(a, acc, m0 + wm * 128, n0 + wn * 64, patch, lane);
         if ((ABL >= 4)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             tacc[3] = now() - te0;  // epilogue incl. store drain (replaces the vmcnt slot)
@@ -870,6 +897,28 @@ extern "C" __attribute__((visibility("default"))) int s2v_set_gemm_impl(int impl
 static constexpr int g_gemm_ablate = 0;
 static constexpr int g_gemm_impl = 7;
 #endif
+
+template <int EPI>
+static int launch_fp8_t(const GemmArgs& a, hipStream_t st) {
+    const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
+    S2V_TRY(ensure_lds_attr((const void*)gemm_bf16_pp64<EPI, 0, true>, 131072));
+    hipLaunchKernelGGL((gemm_bf16_pp64<EPI, 0, true>), dim3(tiles_m * tiles_n), dim3(512), 131072, st, a, tiles_m, tiles_n);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+int launch_gemm_fp8(const GemmArgs& a, int epi, hipStream_t st) {
+    S2V_REQUIRE(!a.conv && a.a_scale && a.w_scale, "gemm_fp8: plain mode with both scale vectors only");
+    S2V_REQUIRE(a.K % 128 == 0 && a.lda % 16 == 0 && a.ldw % 16 == 0, "gemm_fp8: K must be a multiple of 128, rows 16-byte aligned");
+    S2V_REQUIRE(a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM && a.w_rows_padded >= ((a.N + WBN - 1) / WBN) * WBN,
+                "gemm_fp8: operands must be padded to whole 256-row tiles");
+    S2V_REQUIRE(epi_vec_ok(a, epi), "gemm_fp8: output rows must be 16-byte aligned and N a multiple of 8");
+    switch (epi) {
+        case EPI_BIAS: return launch_fp8_t<EPI_BIAS>(a, st);
+        case EPI_BIAS_GELU: return launch_fp8_t<EPI_BIAS_GELU>(a, st);
+        case EPI_BIAS_GATE_RES: return launch_fp8_t<EPI_BIAS_GATE_RES>(a, st);
+        default: return s2v_fail(__FILE__, __LINE__, "gemm_fp8: bad epilogue", -1);
+    }
+}
 
 // the 256-column kernels take N that is not a multiple of 256 when the weight buffer physically holds the padded rows and
 // the last tile is at least half full (N = 1920 / 5760 of the 2B model); narrower outputs go to the 128-column kernels

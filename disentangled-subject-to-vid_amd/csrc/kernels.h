@@ -34,7 +34,16 @@ struct GemmArgs {
     int a_rows_padded;  // plain mode: rows physically present behind A (>= M); the 256-row kernel needs ceil256(M)
     int m_begin;        // first output row of this launch (row-tail launches of a split GEMM; 128-row kernel only)
     int w_rows_padded;  // rows physically present behind W (>= N, zero or don't-care beyond N); 0 = exactly N
+    // fp8 (OCP e4m3) operands, launch_gemm_fp8 only: A [M_pad][K] and W [N_pad][K] are bytes, lda / ldw in elements (= bytes);
+    // C = rnd(a_scale[m] * w_scale[n] * acc + bias) ... : per-token and per-output-channel fp32 scales (weights.py / api.hip)
+    const float* a_scale;
+    const float* w_scale;
 };
+// fp8 x fp8 -> bf16 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; the per-row scales above in the epilogue): the
+// 256 x 256 ping-pong schedule of gemm_bf16_pp64 on K-tiles of 128 bytes.  Plain mode only (no conv), K % 128 == 0, N_pad % 256 == 0.
+int launch_gemm_fp8(const GemmArgs& a, int epi, hipStream_t st);
+// rows [M][K] of bf16 (ld elements apart) -> e4m3 bytes [M][K] + scale[m] = amax(row) / 448 (dynamic per-row quantisation)
+int launch_quant_rows_fp8(const void* src, int64_t ld, int64_t M, int K, void* dst, float* scale, hipStream_t st);
 enum { EPI_BIAS_ADD = 3 };
 
 int launch_gemm_bf16(const GemmArgs& a, int epi, hipStream_t st);              // MFMA path, bf16 only

@@ -33,6 +33,9 @@ class S2VEngine:
         c.dtype = _lib.DTYPE_OF[dtype]
         c.norm_eps = cfg.norm_eps
         c.force_simple = int(force_simple)
+        if cfg.weight_format not in (None, "fp8"):
+            raise _lib.S2VError(f"unknown weight_format {cfg.weight_format!r} (None or 'fp8')")
+        c.weight_format = 1 if cfg.weight_format == "fp8" else 0
         self._h = ctypes.c_void_p()
         _lib.check(_lib.lib().s2v_create(ctypes.byref(c), ctypes.byref(self._h)))
         self.geometry = None

@@ -48,7 +48,11 @@ typedef struct s2v_model_config {
     int32_t dtype;            /* S2V_DTYPE_* : storage + rounding points of the model */
     float norm_eps;           /* 1e-5 */
     int32_t force_simple;     /* 1 = run the bf16 model on the generic (non-MFMA) kernels; cross-check only */
-    int32_t reserved[5];
+    int32_t weight_format;    /* 0 = the model dtype; 1 = W8A8 fp8 (BASELINE configs[4]): the four big linears of every block
+                               * (fused QKV, attention out, FF1, FF2) keep OCP e4m3 weights with per-output-channel scales
+                               * (quantised by s2v_finalize_weights after any LoRA merge) and take per-token e4m3 activations,
+                               * on v_mfma_scale_f32_32x32x64_f8f6f4; bf16 model dtype only, inner_dim % 128 == 0 */
+    int32_t reserved[4];
 } s2v_model_config;
 
 S2V_API const char* s2v_last_error(void);
@@ -256,6 +260,14 @@ S2V_API int s2v_op_linear(const void* A, const void* W, const void* bias, void* 
                   int32_t epilogue, int32_t dtype, int32_t impl, s2v_stream stream);
 /* qkv [B*Ntok (+64 rows of slack), 3*H*64] -> out [B*Ntok, H*64]; impl 0 = MFMA flash kernel (needs vt scratch
  * [B*H*64*ceil64(Ntok)] bf16, zero-filled by the caller), 1 = generic */
+/* W8A8 linear on the fp8 matrix cores (BASELINE configs[4]: "fp8 (CDNA4 fp8 MFMA) weights"): A [M,K] and W [N,K] bf16 are
+ * quantised per row to OCP e4m3 with fp32 scales amax/448 (per token / per output channel) into `scratch`
+ * (>= M*K + N*K + 4*(M+N) bytes), multiplied with v_mfma_scale_f32_32x32x64_f8f6f4 and de-quantised in the epilogue:
+ * C = epilogue(scale_a[m] * scale_w[n] * acc + bias), bf16.  The reference has no fp8 path (diffusers quantizers are
+ * bitsandbytes-only): the contract is stated against this library's own bf16 path (tests/test_gpu_fp8.py).
+ * M, N multiples of 256, K a multiple of 128; epilogue 0 = bias, 1 = bias + GELU(tanh). */
+S2V_API int s2v_op_linear_fp8(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
+                              int32_t epilogue, void* scratch, int64_t scratch_bytes, s2v_stream stream);
 S2V_API int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype,
                      int32_t impl, s2v_stream stream);
 
