@@ -71,6 +71,16 @@ __device__ __forceinline__ void glds16_saddr(const char* sbase, unsigned voff, c
                  : "memory", "m0");
 }
 
+// the same with the LDS destination given as a byte offset into the block's dynamic LDS (lds_off from lds_base_u32()): an
+// address-space cast of a generic pointer costs a null check (s_cmp_lg_u64 + s_cselect) per call, integers do not
+__device__ __forceinline__ unsigned lds_base_u32(char* smem) { return (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem; }
+__device__ __forceinline__ void glds16_saddr_m0(const char* sbase, unsigned voff, unsigned m0val) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0"
+                 :
+                 : "s"(sbase), "v"(voff), "s"(m0val)
+                 : "memory", "m0");
+}
+
 // ---- host side ------------------------------------------------------------
 #ifdef S2V_HOST
 #include <string>

@@ -690,24 +690,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
     }
     const int nT = a.K / BKE;
     const int ldst = (g * 128 + w4 * 8) * 128;  // byte offset of the wave's piece 0 inside an operand image
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base_u32(smem));  // LDS destinations as integers: no null-check SALU per piece
     auto dma_a = [&](int t) {
         if (ABL == 1 && t > 0) return;
         const int tc = min(t, nT - 1);
         const int64_t ka = a.conv ? a_k_off(a, tc * BKE) : (int64_t)tc * BKE;
         const char* tb = Abase + ES * ka;
-        char* base = smem + (t & 1) * 65536 + ldst;
+        const unsigned base = lds0 + (t & 1) * 65536 + ldst;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            glds16_saddr(tb, offA[i], base + i * 4096);
+            glds16_saddr_m0(tb, offA[i], base + i * 4096);
     };
     auto dma_w = [&](int t) {
         if (ABL == 1 && t > 0) return;
         const int tc = min(t, nT - 1);
         const char* tb = Wbase + ES * (int64_t)tc * BKE;
-        char* base = smem + (t & 1) * 65536 + 32768 + ldst;
+        const unsigned base = lds0 + (t & 1) * 65536 + 32768 + ldst;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            glds16_saddr(tb, offW[i], base + i * 4096);
+            glds16_saddr_m0(tb, offW[i], base + i * 4096);
     };
 
     f32x16 acc[2][4];  // [n block][m block]

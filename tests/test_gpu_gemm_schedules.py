@@ -45,3 +45,4 @@ def test_pingpong_matches_ring_bitwise_and_is_repeatable(s2v, M, N, K, epi):
         y = torch.nn.functional.gelu(y.bfloat16().float(), approximate="tanh")
     rel = ((ref.float() - y).norm() / y.norm()).item()
     assert rel <= 1e-2, rel
+
