@@ -24,6 +24,10 @@ class TransformerConfig:
     vae_scaling_factor: float = 1.15258426
     # "fp8": W8A8 on the fp8 matrix cores for the four big linears of every block (BASELINE configs[4]); None: model dtype
     weight_format: str = None
+    # where the subject-LoRA acts inside CogVideoXLayerNormZero: "shipped" (merged into norm{1,2}.linear: what the reference code
+    # computes) or "intended" (base weights for video / text modulation, LoRA only for the reference-image chunks,
+    # normalization.py:468-478)
+    lora_adaln_scope: str = "shipped"
 
     @property
     def inner_dim(self):

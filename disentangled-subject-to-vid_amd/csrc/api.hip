@@ -45,6 +45,8 @@ struct s2v_ctx {
     s2v_model_config cfg;
     int D = 0, L = 0, dtype = 0, esz = 0, temb = 0;
     bool mfma = false;
+    int mc = 6;                  // modulation chunks per norm{1,2}.linear in the stack: 6, or 9 under lora_adaln_scope = 1 (+ the
+                                 // reference-image copy of chunks 0-2: cond_shift, cond_scale, cond_gate)
     bool fp8 = false;            // cfg.weight_format == 1
     char* aq = nullptr;          // workspace: e4m3 activations [Mpad][4D] of the GEMM being fed
     float* aq_scale = nullptr;   // workspace: their per-token scales [Mpad]
@@ -170,7 +172,10 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     const int64_t o_te1_w = carve(TE * D), o_te1_b = carve(TE), o_te2_w = carve(TE * TE), o_te2_b = carve(TE);
     const int64_t o_nf_w = carve(D), o_nf_b = carve(D), o_no_w = carve(D), o_no_b = carve(D);
     const int64_t o_po_w = carve(rup(Cout, 256) * D), o_po_b = carve(Cout);
-    c->mod_rows = 2 * L * 6 * D + 2 * D;
+    if (cfg->lora_adaln_scope != 0 && cfg->lora_adaln_scope != 1) { delete c; return s2v_fail(__FILE__, __LINE__, "s2v_create: lora_adaln_scope must be 0 or 1", -1); }
+    c->mc = cfg->lora_adaln_scope ? 9 : 6;
+    const int64_t MC = c->mc;
+    c->mod_rows = 2 * L * MC * D + 2 * D;
     const int64_t o_mod_w = carve(c->mod_rows * TE), o_mod_b = carve(c->mod_rows);
     // fp8 copies live in the same arena (one broadcast replicates everything a replica needs)
     c->fp8 = cfg->weight_format == 1;
@@ -224,10 +229,10 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
         add_slot(c, NM("ff.net.0.proj.bias"), w.b1, 1, 4 * D, 4 * D);
         add_slot(c, NM("ff.net.2.weight"), w.w2, D, 4 * D, 4 * D);
         add_slot(c, NM("ff.net.2.bias"), w.b2, 1, D, D);
-        add_slot(c, NM("norm1.linear.weight"), A + o_mod_w + (int64_t)(2 * l) * 6 * D * TE * E, 6 * D, TE, TE);
-        add_slot(c, NM("norm1.linear.bias"), A + o_mod_b + (int64_t)(2 * l) * 6 * D * E, 1, 6 * D, 6 * D);
-        add_slot(c, NM("norm2.linear.weight"), A + o_mod_w + (int64_t)(2 * l + 1) * 6 * D * TE * E, 6 * D, TE, TE);
-        add_slot(c, NM("norm2.linear.bias"), A + o_mod_b + (int64_t)(2 * l + 1) * 6 * D * E, 1, 6 * D, 6 * D);
+        add_slot(c, NM("norm1.linear.weight"), A + o_mod_w + (int64_t)(2 * l) * MC * D * TE * E, 6 * D, TE, TE);
+        add_slot(c, NM("norm1.linear.bias"), A + o_mod_b + (int64_t)(2 * l) * MC * D * E, 1, 6 * D, 6 * D);
+        add_slot(c, NM("norm2.linear.weight"), A + o_mod_w + (int64_t)(2 * l + 1) * MC * D * TE * E, 6 * D, TE, TE);
+        add_slot(c, NM("norm2.linear.bias"), A + o_mod_b + (int64_t)(2 * l + 1) * MC * D * E, 1, 6 * D, 6 * D);
 #undef NM
     }
     c->patch_w = A + o_patch_w; c->patch_b = A + o_patch_b; c->text_w = A + o_text_w; c->text_b = A + o_text_b;
@@ -246,8 +251,8 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     add_slot(c, "norm_final.bias", c->nf_b, 1, D, D);
     add_slot(c, "norm_out.norm.weight", c->no_w, 1, D, D);
     add_slot(c, "norm_out.norm.bias", c->no_b, 1, D, D);
-    add_slot(c, "norm_out.linear.weight", c->mod_w + (int64_t)2 * L * 6 * D * TE * E, 2 * D, TE, TE);
-    add_slot(c, "norm_out.linear.bias", c->mod_b + (int64_t)2 * L * 6 * D * E, 1, 2 * D, 2 * D);
+    add_slot(c, "norm_out.linear.weight", c->mod_w + (int64_t)2 * L * MC * D * TE * E, 2 * D, TE, TE);
+    add_slot(c, "norm_out.linear.bias", c->mod_b + (int64_t)2 * L * MC * D * E, 1, 2 * D, 2 * D);
     add_slot(c, "proj_out.weight", c->po_w, Cout, D, D);
     add_slot(c, "proj_out.bias", c->po_b, 1, Cout, Cout);
 
@@ -278,6 +283,12 @@ extern "C" void s2v_destroy(s2v_ctx* c) {
     delete c;
 }
 
+// "transformer_blocks.<l>.norm{1,2}.linear.{weight,bias}"
+static bool is_adaln_linear(const char* name) {
+    const std::string n = name;
+    return n.rfind("transformer_blocks.", 0) == 0 && (n.find(".norm1.linear.") != std::string::npos || n.find(".norm2.linear.") != std::string::npos);
+}
+
 extern "C" int s2v_load_weight(s2v_ctx* c, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
                                int32_t src_dtype, s2v_stream stream) {
     S2V_REQUIRE(c && name && dev_ptr && shape, "s2v_load_weight: null argument");
@@ -297,6 +308,15 @@ extern "C" int s2v_load_weight(s2v_ctx* c, const char* name, const void* dev_ptr
     }
     S2V_TRY(launch_convert2d(dev_ptr, src_dtype, s.cols, s.dst, c->dtype, s.ld, s.rows, s.cols, (hipStream_t)stream));
     s.loaded = true;
+    if (c->mc == 9 && is_adaln_linear(name)) {
+        // lora_adaln_scope 1: the reference-image copy of chunks 0-2 (rows [0, 3D) of the weight, entries [0, 3D) of the bias)
+        // sits right behind the six chunks; it starts as the base values and is what s2v_merge_lora then adds to
+        const int64_t D3 = 3 * (int64_t)c->D;
+        const bool bias = s.rows == 1;
+        const int64_t bytes6 = (bias ? 6 * (int64_t)c->D : 6 * (int64_t)c->D * s.ld) * c->esz, bytes3 = bytes6 / 2;
+        (void)D3;
+        S2V_CHECK_HIP(hipMemcpyAsync(s.dst + bytes6, s.dst, (size_t)bytes3, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    }
     return 0;
 }
 
@@ -309,12 +329,16 @@ extern "C" int s2v_merge_lora(s2v_ctx* c, const char* name, const float* A, cons
     Slot& s = it->second;
     S2V_REQUIRE(s.loaded && s.rows > 1, "s2v_merge_lora: base weight must be a loaded matrix");
     hipStream_t st = (hipStream_t)stream;
+    // lora_adaln_scope 1: on norm{1,2}.linear the LoRA reaches only the reference-image copy of chunks 0-2 (rows [0, 3D) of B)
+    const bool scoped = c->mc == 9 && is_adaln_linear(name);
+    char* dst = scoped ? s.dst + 6 * (int64_t)c->D * s.ld * c->esz : s.dst;
+    const int64_t rows = scoped ? 3 * (int64_t)c->D : s.rows;
     float* tmp = nullptr;
-    S2V_CHECK_HIP(hipMalloc((void**)&tmp, sizeof(float) * s.rows * s.cols));
-    int r = launch_convert2d(s.dst, c->dtype, s.ld, tmp, S2V_F32, s.cols, s.rows, s.cols, st);
+    S2V_CHECK_HIP(hipMalloc((void**)&tmp, sizeof(float) * rows * s.cols));
+    int r = launch_convert2d(dst, c->dtype, s.ld, tmp, S2V_F32, s.cols, rows, s.cols, st);
     // tmp[out][in] += scale * sum_k B[out][k] * A[k][in]
-    if (!r) r = launch_gemm_strided_f32(B, rank, 1, A, 1, s.cols, tmp, s.cols, (int)s.rows, (int)s.cols, rank, scale, st);
-    if (!r) r = launch_convert2d(tmp, S2V_F32, s.cols, s.dst, c->dtype, s.ld, s.rows, s.cols, st);
+    if (!r) r = launch_gemm_strided_f32(B, rank, 1, A, 1, s.cols, tmp, s.cols, (int)rows, (int)s.cols, rank, scale, st);
+    if (!r) r = launch_convert2d(tmp, S2V_F32, s.cols, dst, c->dtype, s.ld, rows, s.cols, st);
     hipStreamSynchronize(st);
     hipFree(tmp);
     return r;
@@ -523,16 +547,18 @@ static int run_block(s2v_ctx* c, int l, const char* mod_base /* [B][mod_stride] 
     const int D = c->D;
     const int64_t E = c->esz;
     for (int half = 0; half < 2; ++half) {
-        const char* mb = mod_base + (int64_t)half * 6 * D * E;
+        const char* mb = mod_base + (int64_t)half * c->mc * D * E;
         LnModArgs n{};
         n.x = c->X; n.ldx = D; n.y = c->Xn; n.ldy = D;
         n.w = half ? w.ln2_w : w.ln1_w; n.b = half ? w.ln2_b : w.ln1_b; n.eps = c->cfg.norm_eps;
         n.shift_vid = mb; n.scale_vid = mb + D * E; n.shift_txt = mb + 3 * D * E; n.scale_txt = mb + 4 * D * E;
         n.mod_stride = (int)mod_stride; n.B = c->B; n.Ntok = c->Ntok; n.text_len = c->T; n.D = D;
+        if (c->mc == 9) { n.shift_ref = mb + 6 * D * E; n.scale_ref = mb + 7 * D * E; n.ref_len = c->R; }
         { ProfScope ps(c, PK_LNMOD, st); S2V_TRY(launch_ln_modulate(n, c->dtype, st)); }
         GemmArgs g{};
         g.X = c->X; g.ldx = D; g.gate_vid = mb + 2 * D * E; g.gate_txt = mb + 5 * D * E; g.gate_stride = (int)mod_stride;
         g.tok_per_batch = c->Ntok; g.text_len = c->T; g.M = (int)c->M; g.N = D;
+        if (c->mc == 9) { g.gate_ref = mb + 8 * D * E; g.ref_len = c->R; }
         if (half == 0) {
             S2V_TRY(run_attention(c, l, st));
             g.A = c->Xn; g.lda = D; g.W = w.wo; g.ldw = D; g.bias = w.bo; g.K = D;
@@ -583,9 +609,9 @@ static int forward_impl(s2v_ctx* c, const void* latents, int64_t lat_bstride, co
     }
     // 3. blocks
     for (int l = 0; l < c->L; ++l)
-        S2V_TRY(run_block(c, l, c->mod + (int64_t)(2 * l) * 6 * D * E, c->mod_rows, st));
+        S2V_TRY(run_block(c, l, c->mod + (int64_t)(2 * l) * c->mc * D * E, c->mod_rows, st));
     // 4. tail
-    const char* mo = c->mod + (int64_t)2 * c->L * 6 * D * E;
+    const char* mo = c->mod + (int64_t)2 * c->L * c->mc * D * E;
     TailNormArgs t{};
     t.x = c->X; t.ldx = D; t.y = c->tailn; t.ldy = D; t.w1 = c->nf_w; t.b1 = c->nf_b; t.w2 = c->no_w; t.b2 = c->no_b;
     t.eps = c->cfg.norm_eps; t.shift = mo; t.scale = mo + D * E; t.mod_stride = (int)c->mod_rows;
@@ -615,16 +641,16 @@ extern "C" int s2v_block_forward(s2v_ctx* c, int32_t layer, const void* hidden, 
     const int D = c->D, B = c->B;
     const int64_t E = c->esz;
     // this layer's two modulation linears are contiguous in the stack: rows [(2l)*6D, (2l+2)*6D)
-    const int64_t r0 = (int64_t)(2 * layer) * 6 * D;
+    const int64_t r0 = (int64_t)(2 * layer) * c->mc * D;
     char* modl = c->mod;  // [B][12D]
-    S2V_TRY(launch_mod_gemv(temb, B, c->temb, c->mod_w + r0 * c->temb * E, c->mod_b + r0 * E, 12 * D, modl, c->dtype, st));
+    S2V_TRY(launch_mod_gemv(temb, B, c->temb, c->mod_w + r0 * c->temb * E, c->mod_b + r0 * E, 2 * c->mc * D, modl, c->dtype, st));
     for (int b = 0; b < B; ++b) {
         char* xb = c->X + (int64_t)b * c->Ntok * D * E;
         if (c->T) S2V_TRY(launch_copy_rows((const char*)enc0 + (int64_t)b * c->T * D * E, D, nullptr, 0, xb, D, c->T, D, c->dtype, st));
         S2V_TRY(launch_copy_rows((const char*)enc1 + (int64_t)b * c->R * D * E, D, nullptr, 0, xb + (int64_t)c->T * D * E, D, c->R, D, c->dtype, st));
         S2V_TRY(launch_copy_rows((const char*)hidden + (int64_t)b * c->V * D * E, D, nullptr, 0, xb + (int64_t)(c->T + c->R) * D * E, D, c->V, D, c->dtype, st));
     }
-    S2V_TRY(run_block(c, layer, modl, 12 * D, st));
+    S2V_TRY(run_block(c, layer, modl, 2 * c->mc * D, st));
     for (int b = 0; b < B; ++b) {
         const char* xb = c->X + (int64_t)b * c->Ntok * D * E;
         if (c->T) S2V_TRY(launch_copy_rows(xb, D, nullptr, 0, (char*)out_enc0 + (int64_t)b * c->T * D * E, D, c->T, D, c->dtype, st));

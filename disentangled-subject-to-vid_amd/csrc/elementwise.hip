@@ -125,8 +125,9 @@ __global__ __launch_bounds__(256) void ln_modulate_k(const LnModArgs a) {
     row_load<T>((const T*)a.x + (size_t)row * a.ldx, a.D, lane, v, nch);
     row_layernorm<T>(v, a.D, lane, (const T*)a.w, (const T*)a.b, a.eps);
     const bool txt = r < a.text_len;
-    const T* shift = (const T*)(txt ? a.shift_txt : a.shift_vid) + (size_t)b * a.mod_stride;
-    const T* scale = (const T*)(txt ? a.scale_txt : a.scale_vid) + (size_t)b * a.mod_stride;
+    const bool ref = a.shift_ref != nullptr && !txt && r < a.text_len + a.ref_len;
+    const T* shift = (const T*)(txt ? a.shift_txt : ref ? a.shift_ref : a.shift_vid) + (size_t)b * a.mod_stride;
+    const T* scale = (const T*)(txt ? a.scale_txt : ref ? a.scale_ref : a.scale_vid) + (size_t)b * a.mod_stride;
     row_modulate_store<T>(v, a.D, lane, shift, scale, (T*)a.y + (size_t)row * a.ldy);
 }
 int launch_ln_modulate(const LnModArgs& a, int dtype, hipStream_t st) {

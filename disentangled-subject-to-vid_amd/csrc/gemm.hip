@@ -34,7 +34,8 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, const
     if (EPI == EPI_BIAS_GATE_RES) {
         const int b = m / a.tok_per_batch;
         const int r = m - b * a.tok_per_batch;
-        const T* gate = (const T*)(r < a.text_len ? a.gate_txt : a.gate_vid) + (size_t)b * a.gate_stride;
+        const void* gsel = r < a.text_len ? a.gate_txt : (a.gate_ref != nullptr && r < a.text_len + a.ref_len) ? a.gate_ref : a.gate_vid;
+        const T* gate = (const T*)gsel + (size_t)b * a.gate_stride;
         T* x = (T*)a.X + (size_t)m * a.ldx + n;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -200,7 +201,8 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x16 (&
         if (EPI == EPI_BIAS_GATE_RES) {
             const int b = m / a.tok_per_batch;
             const int r = m - b * a.tok_per_batch;
-            const bf16_t* gate = (const bf16_t*)(r < a.text_len ? a.gate_txt : a.gate_vid) + (size_t)b * a.gate_stride + n;
+            const void* gsel = r < a.text_len ? a.gate_txt : (a.gate_ref != nullptr && r < a.text_len + a.ref_len) ? a.gate_ref : a.gate_vid;
+            const bf16_t* gate = (const bf16_t*)gsel + (size_t)b * a.gate_stride + n;
             bf16_t* x = (bf16_t*)a.X + (size_t)m * a.ldx + n;
             const u32x4 g = *(const u32x4*)gate;
             const u32x4 xo = *(const u32x4*)x;

@@ -22,6 +22,9 @@ struct GemmArgs {
     void* X; int ldx;
     const void* gate_vid; const void* gate_txt; int gate_stride;
     int tok_per_batch; int text_len;
+    // optional third gate for the reference-image rows [text_len, text_len + ref_len) of every sample (null: they take gate_vid,
+    // which is what the shipped reference computes; set under lora_adaln_scope = 1, normalization.py:468-478)
+    const void* gate_ref; int ref_len;
     // EPI_BIAS_ADD: C = rnd(rnd(acc + bias) + R[m][n])  (resnet skip, autoencoder_kl_cogvideox.py:318)
     const void* R; int ldr;
     // Implicit-GEMM convolution addressing of A (conv != 0).  A is a zero-bordered channels-last tensor
@@ -74,6 +77,7 @@ struct LnModArgs {
     const void* w; const void* b; float eps;
     const void* shift_vid; const void* scale_vid; const void* shift_txt; const void* scale_txt; int mod_stride;
     int B, Ntok, text_len, D;
+    const void* shift_ref; const void* scale_ref; int ref_len;  // optional set for rows [text_len, text_len + ref_len); null: vid
 };
 int launch_ln_modulate(const LnModArgs& a, int dtype, hipStream_t st);
 

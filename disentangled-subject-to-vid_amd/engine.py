@@ -36,6 +36,9 @@ class S2VEngine:
         if cfg.weight_format not in (None, "fp8"):
             raise _lib.S2VError(f"unknown weight_format {cfg.weight_format!r} (None or 'fp8')")
         c.weight_format = 1 if cfg.weight_format == "fp8" else 0
+        if cfg.lora_adaln_scope not in ("shipped", "intended"):
+            raise _lib.S2VError(f"unknown lora_adaln_scope {cfg.lora_adaln_scope!r} ('shipped' or 'intended')")
+        c.lora_adaln_scope = 1 if cfg.lora_adaln_scope == "intended" else 0
         self._h = ctypes.c_void_p()
         _lib.check(_lib.lib().s2v_create(ctypes.byref(c), ctypes.byref(self._h)))
         self.geometry = None

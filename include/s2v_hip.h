@@ -52,7 +52,14 @@ typedef struct s2v_model_config {
                                * (fused QKV, attention out, FF1, FF2) keep OCP e4m3 weights with per-output-channel scales
                                * (quantised by s2v_finalize_weights after any LoRA merge) and take per-token e4m3 activations,
                                * on v_mfma_scale_f32_32x32x64_f8f6f4; bf16 model dtype only, inner_dim % 128 == 0 */
-    int32_t reserved[4];
+    int32_t lora_adaln_scope; /* where the subject-LoRA acts inside CogVideoXLayerNormZero (normalization.py:467-484):
+                               * 0 = as shipped: `enable_lora([self.linear], False)` sets an attribute nothing reads, so the LoRA
+                               *     is active on both evaluations of norm{1,2}.linear and is merged into it (SURVEY preamble 6);
+                               * 1 = as the authors' comments intend (:470-476): base weights for the video / text modulation, the
+                               *     LoRA only for the reference-image chunks (cond_shift, cond_scale, cond_gate): the context keeps
+                               *     a second copy of rows [0, 3D) of each norm{1,2}.linear, s2v_merge_lora on those names merges
+                               *     into that copy only, and the reference-image rows are modulated / gated with it */
+    int32_t reserved[3];
 } s2v_model_config;
 
 S2V_API const char* s2v_last_error(void);

@@ -139,10 +139,22 @@ def attn_forward(sd, p, heads, hidden, enc, rope, ref_rope, ref_start, ref_end):
     return o[:, tl:], o[:, :tl]
 
 
-def layernorm_zero(sd, p, h, e0, e1, temb, eps):
-    """CogVideoXLayerNormZero.forward, models/normalization.py:467-484 (ref stream takes the VIDEO chunks)."""
+def layernorm_zero(sd, p, h, e0, e1, temb, eps, cond_sd=None):
+    """CogVideoXLayerNormZero.forward, models/normalization.py:467-484.  As shipped the second evaluation of self.linear equals
+    the first (the `enable_lora` context sets an attribute nothing reads), so the ref stream takes the VIDEO chunks.  cond_sd (the
+    "intended" reading of :468-478): the first evaluation uses the BASE linear (sd), the second -- cond_shift, cond_scale,
+    cond_gate for the reference-image stream -- the LoRA-merged linear given in cond_sd."""
     m = F.linear(F.silu(temb), sd[p + "linear.weight"], sd[p + "linear.bias"])
     shift, scale, gate, eshift, escale, egate = m.chunk(6, dim=1)
+    if cond_sd is not None:
+        mc = F.linear(F.silu(temb), cond_sd[p + "linear.weight"], cond_sd[p + "linear.bias"])
+        cshift, cscale, cgate = mc.chunk(6, dim=1)[:3]
+        w, b = sd[p + "norm.weight"], sd[p + "norm.bias"]
+        D = h.shape[-1]
+        nh = F.layer_norm(h, (D,), w, b, eps) * (1 + scale)[:, None, :] + shift[:, None, :]
+        ne0 = F.layer_norm(e0, (D,), w, b, eps) * (1 + escale)[:, None, :] + eshift[:, None, :]
+        ne1 = F.layer_norm(e1, (D,), w, b, eps) * (1 + cscale)[:, None, :] + cshift[:, None, :]
+        return nh, ne0, ne1, gate[:, None, :], egate[:, None, :], cgate[:, None, :]
     w, b = sd[p + "norm.weight"], sd[p + "norm.bias"]
     D = h.shape[-1]
     nh = F.layer_norm(h, (D,), w, b, eps) * (1 + scale)[:, None, :] + shift[:, None, :]
@@ -151,15 +163,15 @@ def layernorm_zero(sd, p, h, e0, e1, temb, eps):
     return nh, ne0, ne1, gate[:, None, :], egate[:, None, :], gate[:, None, :]
 
 
-def block_forward(sd, p, heads, h, e0, e1, temb, rope, ref_rope, eps=1e-5):
+def block_forward(sd, p, heads, h, e0, e1, temb, rope, ref_rope, eps=1e-5, cond_sd=None):
     """CogVideoXBlock.forward, models/transformers/cogvideox_transformer_3d.py:122-186."""
     T, R = e0.size(1), e1.size(1)
-    nh, ne0, ne1, g, ge, gc = layernorm_zero(sd, p + "norm1.", h, e0, e1, temb, eps)
+    nh, ne0, ne1, g, ge, gc = layernorm_zero(sd, p + "norm1.", h, e0, e1, temb, eps, cond_sd)
     ah, ae = attn_forward(sd, p + "attn1.", heads, nh, torch.cat([ne0, ne1], dim=1), rope, ref_rope, T, T + R)
     h = h + g * ah
     e0 = e0 + ge * ae[:, :T]
     e1 = e1 + gc * ae[:, T:]
-    nh, ne0, ne1, g, ge, gc = layernorm_zero(sd, p + "norm2.", h, e0, e1, temb, eps)
+    nh, ne0, ne1, g, ge, gc = layernorm_zero(sd, p + "norm2.", h, e0, e1, temb, eps, cond_sd)
     x = torch.cat([ne0, ne1, nh], dim=1)
     x = F.linear(x, sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"])
     x = F.gelu(x, approximate="tanh")  # models/activations.py:65-90
@@ -179,7 +191,7 @@ def patch_tokens(sd, lat):
 
 
 def transformer_forward(sd, cfg, hidden_states, encoder_hidden_states, ref_img_states, timestep, rope=None,
-                        ref_rope=None):
+                        ref_rope=None, cond_sd=None):
     """CogVideoXTransformer3DModel.forward with eval=True, cogvideox_transformer_3d.py:450-560.
     cfg: dict(num_heads, num_layers, use_rope, norm_eps, spatial_scale, temporal_scale)."""
     heads = cfg["num_heads"]
@@ -198,7 +210,7 @@ def transformer_forward(sd, cfg, hidden_states, encoder_hidden_states, ref_img_s
         h = h + pe[None].to(dt)  # embeddings.py:440-446 (text rows of the joint table are zero and dropped)
     for i in range(cfg["num_layers"]):
         h, e0, e1 = block_forward(sd, f"transformer_blocks.{i}.", heads, h, e0, e1, emb, rope, ref_rope,
-                                  cfg.get("norm_eps", 1e-5))
+                                  cfg.get("norm_eps", 1e-5), cond_sd)
     h = F.layer_norm(h, (D,), sd["norm_final.weight"], sd["norm_final.bias"], cfg.get("norm_eps", 1e-5))
     m = F.linear(F.silu(emb), sd["norm_out.linear.weight"], sd["norm_out.linear.bias"])
     shift, scale = m.chunk(2, dim=1)  # normalization.py:72-82: shift FIRST
@@ -218,3 +230,15 @@ def merge_lora(sd, lora, scale=0.5):
         delta = (Bm.float() @ A.float().reshape(A.shape[0], -1)).reshape(w.shape)
         out[name] = (w + scale * delta).to(sd[name].dtype)
     return out
+
+
+def merge_lora_scoped(sd, lora, scale=0.5):
+    """the "intended" reading of normalization.py:468-478: every LoRA target is merged EXCEPT norm{1,2}.linear, whose merged form
+    is returned separately (cond_sd) and reaches only the reference-image modulation.  Returns (sd_main, cond_sd)."""
+    adaln = {k: v for k, v in lora.items() if ".norm1.linear." in k or ".norm2.linear." in k}
+    main = merge_lora(sd, {k: v for k, v in lora.items() if k not in adaln}, scale)
+    merged = merge_lora(sd, adaln, scale)
+    cond = {k: merged[k] for k in adaln}
+    for k in adaln:
+        cond[k.replace(".weight", ".bias")] = sd[k.replace(".weight", ".bias")]
+    return main, cond

@@ -321,3 +321,51 @@ def test_op_attention_strongly_negative_and_positive_scores(s2v):
         exp = exp.transpose(1, 2).reshape(B * N, D)
         rel = ((out.float().cpu() - exp).norm() / exp.norm()).item()
         assert rel <= 3e-2, (sign, rel)
+
+
+@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+def test_lora_adaln_scope_intended_vs_oracle(s2v, dt_name):
+    """lora_adaln_scope = "intended" (normalization.py:468-478 as its comments read: base weights for the video / text
+    modulation, the LoRA only for the reference-image chunks) against the oracle's restatement of that reading; the shipped
+    semantics (LoRA merged into norm{1,2}.linear) must give a visibly different answer on the same weights"""
+    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    cfg = s2v.tiny(use_rope=True, heads=3, layers=2, text_dim=128, temb=64)
+    cfg.max_text_seq_length = 7
+    cfg.lora_adaln_scope = "intended"
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=5, parity=True)
+    lora = s2v.weights.synthetic_lora(cfg, rank=8, seed=6, std=0.3)
+    g = torch.Generator().manual_seed(17)
+    B, F, C, H, W, T = 2, 3, 16, 16, 24, 7
+    lat = torch.randn(B, F, C, H, W, generator=g).to(dt)
+    text = torch.randn(B, T, 128, generator=g).to(dt)
+    ref = (torch.randn(1, 1, C, H, W, generator=g) * 0.7).to(dt)
+    ts = torch.tensor([500, 500])
+    ocfg = dict(num_heads=3, num_layers=2, use_rope=True, norm_eps=1e-5)
+    ref_rope, rope = tr.pipeline_rope(H * 8, W * 8, F)
+    kw = dict(image_rotary_emb=tuple(x.to(DEV) for x in rope), ref_image_rotary_emb=tuple(x.to(DEV) for x in ref_rope))
+    main, cond = tr.merge_lora_scoped(sd, lora, 0.5)
+    with torch.no_grad():
+        exp = tr.transformer_forward({k: v.to(dt) for k, v in main.items()}, ocfg, lat, text, ref, ts, rope, ref_rope,
+                                     cond_sd={k: v.to(dt) for k, v in cond.items()})
+        shipped = tr.transformer_forward({k: v.to(dt) for k, v in tr.merge_lora(sd, lora, 0.5).items()}, ocfg, lat, text, ref, ts,
+                                         rope, ref_rope)
+    assert rel_l2(shipped, exp) > 5e-2  # the two readings differ by far more than any tolerance below
+    m = s2v.HipCogVideoXTransformer3DModel(cfg, dt, DEV)
+    m.load_state_dict(sd, lora=lora, lora_scale=0.5)
+    y = m(hidden_states=lat.to(DEV), encoder_hidden_states=text.to(DEV), ref_img_states=ref.to(DEV), timestep=ts.to(DEV),
+          return_dict=False, eval=True, **kw)[0]
+    torch.cuda.synchronize()
+    assert_close(y, exp, dt_name, "intended LoRA scope")
+    # the block seam carries the same semantics (its modulation rows are computed per call)
+    h = torch.randn(1, F * (H // 2) * (W // 2), 192, generator=g).to(dt)
+    e0, e1 = torch.randn(1, T, 192, generator=g).to(dt), torch.randn(1, (H // 2) * (W // 2), 192, generator=g).to(dt)
+    temb = torch.randn(1, 64, generator=g).to(dt)
+    with torch.no_grad():
+        eb = tr.block_forward({k: v.to(dt) for k, v in main.items()}, "transformer_blocks.1.", 3, h, e0, e1, temb, rope, ref_rope,
+                              cond_sd={k: v.to(dt) for k, v in cond.items()})
+    got = m.transformer_blocks[1](hidden_states=h.to(DEV), encoder_hidden_states=e0.to(DEV), temb=temb.to(DEV),
+                                  enc_hidden_states1=e1.to(DEV), embed_ref_img=True, ref_img_seq_start=T,
+                                  ref_img_seq_end=T + e1.shape[1], position_delta=0, timestep=None, layer=1, **kw)
+    torch.cuda.synchronize()
+    for a_, b_, nm in zip(got, eb, ("video", "text", "ref")):
+        assert_close(a_, b_, dt_name, "intended scope, block seam " + nm)
