@@ -47,6 +47,8 @@ struct s2v_ctx {
     bool mfma = false;
     int mc = 6;                  // modulation chunks per norm{1,2}.linear in the stack: 6, or 9 under lora_adaln_scope = 1 (+ the
                                  // reference-image copy of chunks 0-2: cond_shift, cond_scale, cond_gate)
+    float* lora_tmp = nullptr;   // fp32 scratch of s2v_merge_lora
+    size_t lora_tmp_bytes = 0;
     bool fp8 = false;            // cfg.weight_format == 1
     char* aq = nullptr;          // workspace: e4m3 activations [Mpad][4D] of the GEMM being fed
     float* aq_scale = nullptr;   // workspace: their per-token scales [Mpad]
@@ -280,6 +282,7 @@ extern "C" void s2v_destroy(s2v_ctx* c) {
     if (c->t_dev) hipFree(c->t_dev);
     if (c->ws) hipFree(c->ws);
     if (c->arena) hipFree(c->arena);
+    if (c->lora_tmp) hipFree(c->lora_tmp);
     delete c;
 }
 
@@ -333,15 +336,20 @@ extern "C" int s2v_merge_lora(s2v_ctx* c, const char* name, const float* A, cons
     const bool scoped = c->mc == 9 && is_adaln_linear(name);
     char* dst = scoped ? s.dst + 6 * (int64_t)c->D * s.ld * c->esz : s.dst;
     const int64_t rows = scoped ? 3 * (int64_t)c->D : s.rows;
-    float* tmp = nullptr;
-    S2V_CHECK_HIP(hipMalloc((void**)&tmp, sizeof(float) * rows * s.cols));
+    // one fp32 scratch for all merges of a load (grown to the largest slot, freed by s2v_finalize_weights / s2v_destroy): no
+    // allocation or synchronisation per key
+    const size_t need = sizeof(float) * (size_t)rows * (size_t)s.cols;
+    if (need > c->lora_tmp_bytes) {
+        if (c->lora_tmp) { S2V_CHECK_HIP(hipStreamSynchronize(st)); (void)hipFree(c->lora_tmp); c->lora_tmp = nullptr; c->lora_tmp_bytes = 0; }
+        S2V_CHECK_HIP(hipMalloc((void**)&c->lora_tmp, need));
+        c->lora_tmp_bytes = need;
+    }
+    float* tmp = c->lora_tmp;
     int r = launch_convert2d(dst, c->dtype, s.ld, tmp, S2V_F32, s.cols, rows, s.cols, st);
     // tmp[out][in] += scale * sum_k B[out][k] * A[k][in]
     if (!r) r = launch_gemm_strided_f32(B, rank, 1, A, 1, s.cols, tmp, s.cols, (int)rows, (int)s.cols, rank, scale, st);
     if (!r) r = launch_convert2d(tmp, S2V_F32, s.cols, dst, c->dtype, s.ld, rows, s.cols, st);
-    hipStreamSynchronize(st);
-    hipFree(tmp);
-    return r;
+    return r;  // stream-ordered: the caller keeps A and B alive until the stream has passed (as for s2v_load_weight)
 }
 
 extern "C" int s2v_finalize_weights(s2v_ctx* c, s2v_stream stream) {
@@ -363,6 +371,12 @@ extern "C" int s2v_finalize_weights(s2v_ctx* c, s2v_stream stream) {
             S2V_TRY(launch_quant_rows_fp8(w.w2, 4 * D, Dp, (int)(4 * D), w.q_2, w.s_2, st));
         }
         S2V_CHECK_HIP(hipStreamSynchronize(st));
+    }
+    if (c->lora_tmp) {
+        S2V_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+        (void)hipFree(c->lora_tmp);
+        c->lora_tmp = nullptr;
+        c->lora_tmp_bytes = 0;
     }
     c->finalized = true;
     return 0;

@@ -77,11 +77,23 @@ class S2VEngine:
             if "pos_embedding" in k:
                 continue  # non-persistent buffer, rebuilt by tables.sincos_table
             self.load_weight(k, v)
+        known = None
+        self.unexpected_lora_keys = []
         for k, (A, B) in (lora or {}).items():
+            if known is None:
+                from .weights import state_dict_shapes
+                known = set(state_dict_shapes(self.cfg))
+            if k not in known:
+                # the reference only reports adapter keys it cannot place (src/inference.py:96-105) and carries on
+                self.unexpected_lora_keys.append(k)
+                continue
             A2 = A.to(self.device).float().reshape(A.shape[0], -1).contiguous()
             B2 = B.to(self.device).float().contiguous()
             _lib.check(_lib.lib().s2v_merge_lora(self._h, k.encode(), _lib.ptr(A2), _lib.ptr(B2), A2.shape[0],
                                                  float(lora_scale), _lib.stream_ptr()))
+            self._keep += [A2, B2]  # the merge is stream-ordered
+        if self.unexpected_lora_keys:
+            print(f"Loading adapter weights led to unexpected keys not found in the model: {self.unexpected_lora_keys}")
         _lib.check(_lib.lib().s2v_finalize_weights(self._h, _lib.stream_ptr()))
         torch.cuda.synchronize(self.device)
         self._keep.clear()

@@ -107,3 +107,19 @@ def test_vae_decoder_ingest_from_safetensors(s2v, tmp_path):
     with torch.no_grad():
         exp = vae_ref.decode_latents(dict(sd), cfgd, lat, False).float()
     assert (y1.float().cpu() - exp).abs().max().item() <= 1e-3
+
+
+def test_unknown_lora_keys_are_reported_not_fatal(s2v, capsys):
+    """src/inference.py:96-105 prints adapter keys it cannot place and continues; so does the ingest"""
+    cfg = s2v.tiny(use_rope=True, heads=2, layers=1)
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=1, parity=True)
+    lora = s2v.weights.synthetic_lora(cfg, rank=4, seed=2, std=0.1)
+    lora["transformer_blocks.0.attn1.to_z.weight"] = (torch.zeros(4, 128), torch.zeros(128, 4))
+    eng = s2v.S2VEngine(cfg, torch.float32, DEV)
+    eng.load_state_dict(sd, lora=lora, lora_scale=0.5)
+    assert eng.unexpected_lora_keys == ["transformer_blocks.0.attn1.to_z.weight"]
+    assert "unexpected keys" in capsys.readouterr().out
+    eng2 = s2v.S2VEngine(cfg, torch.float32, DEV)
+    del lora["transformer_blocks.0.attn1.to_z.weight"]
+    eng2.load_state_dict(sd, lora=lora, lora_scale=0.5)
+    assert torch.equal(eng.weight_arena(), eng2.weight_arena())

@@ -277,3 +277,28 @@ def test_t5_bucket_table_host_equals_oracle():
         assert torch.equal(t5.position_buckets(T), t5_ref.relative_position_bucket(mem - ctx))
     b = t5.position_buckets(226)
     assert int(b.min()) == 0 and int(b.max()) == 31 and int(b[0, 225]) == 31 and int(b[225, 0]) == 15
+
+
+def test_lora_merge_equals_runtime_adapter_within_bf16_rounding():
+    """the PEFT runtime path of the reference computes base(x) + scaling * lora_B(lora_A(x)) with every Linear output rounded
+    to bf16 (peft is not installed here: this is the library's documented forward); the build merges W' = W + scaling * B A
+    and rounds W' once.  The two differ by bf16 rounding only -- bounded here on a 5B-width projection."""
+    from oracle import transformer_ref as tr
+
+    g = torch.Generator().manual_seed(0)
+    D, r, n, scaling = 3072, 128, 64, 0.5
+    W = (torch.randn(D, D, generator=g) * 0.02).bfloat16()
+    A = (torch.randn(r, D, generator=g) * 0.02).bfloat16()
+    B = (torch.randn(D, r, generator=g) * 0.02).bfloat16()
+    x = torch.randn(n, D, generator=g).bfloat16()
+    merged = tr.merge_lora({"w": W}, {"w": (A.float(), B.float())}, scaling)["w"]
+    y_merged = (x.float() @ merged.float().T).bfloat16().float()
+    base = (x.float() @ W.float().T).bfloat16()
+    low = (x.float() @ A.float().T).bfloat16()
+    up = (low.float() @ B.float().T).bfloat16()
+    y_runtime = (base.float() + (up.float() * scaling).bfloat16().float()).bfloat16().float()
+    exact = x.double() @ (W.double() + scaling * B.double() @ A.double()).T
+    e_merged = ((y_merged.double() - exact).norm() / exact.norm()).item()
+    e_runtime = ((y_runtime.double() - exact).norm() / exact.norm()).item()
+    assert e_merged <= 6e-3 and e_runtime <= 8e-3, (e_merged, e_runtime)      # both are bf16-rounding close to the exact result
+    assert ((y_merged - y_runtime).norm() / y_runtime.norm()).item() <= 1e-2  # and to each other
