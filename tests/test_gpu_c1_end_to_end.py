@@ -38,7 +38,13 @@ def case(s2v):
     VAE = dict(block_out_channels=tuple(vcfg.block_out_channels), layers_per_block=vcfg.layers_per_block,
                norm_num_groups=vcfg.norm_num_groups, latent_channels=16, sample_height=vcfg.sample_height,
                sample_width=vcfg.sample_width, scaling_factor=vcfg.scaling_factor, temporal_compression_ratio=4)
-    # ---- CPU oracle: the whole loop in fp32
+    # ---- CPU oracle: the whole loop in fp32 (N = 1250 tokens is a small problem: a moderate thread count beats all 256 cores)
+    import os
+    import time
+
+    threads0 = torch.get_num_threads()
+    torch.set_num_threads(min(48, os.cpu_count() or 8))
+    t_or = time.time()
     ocfg = dict(num_heads=cfg.num_attention_heads, num_layers=cfg.num_layers, use_rope=False, norm_eps=1e-5)
     ac = sched_ref.alphas_cumprod(cfg.snr_shift_scale)
     text = torch.cat([ne, pe], dim=0)
@@ -50,7 +56,10 @@ def case(s2v):
             npred = tr.transformer_forward(sd, ocfg, torch.cat([lat, lat]), text, ref, tt).float()
             lat = sched_ref.ddim_step(ac, STEPS, sched_ref.cfg_combine(npred, GS), int(t), lat)[0]
             per_step.append(lat.clone())
+        t_tr = time.time() - t_or
         video = vae_ref.decode_latents(sdv, VAE, lat, False)
+    print(f"C1 oracle: 10 transformer steps {t_tr:.1f} s, VAE decode {time.time() - t_or - t_tr:.1f} s on {torch.get_num_threads()} threads")
+    torch.set_num_threads(threads0)
     return dict(cfg=cfg, sd=sd, lat0=lat0, pe=pe, ne=ne, ref=ref, vcfg=vcfg, sdv=sdv, per_step=per_step, video=video)
 
 
