@@ -16,8 +16,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned int)h) << 16); }
 // round-to-nearest-even, lowers to v_cvt_pk_bf16_f32 on gfx950
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two floats -> one packed pair, ONE v_cvt_pk_bf16_f32 (the shift/or form costs three more VALU slots per pair)
 __device__ __forceinline__ unsigned int pack2bf(float lo, float hi) {
-    return (unsigned int)f2bf(lo) | ((unsigned int)f2bf(hi) << 16);
+    bf16x2_t v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned int, v);
 }
 
 // Element-type traits: T is the model's storage dtype (float or bf16_t).
@@ -79,6 +84,16 @@ __device__ __forceinline__ void glds16_saddr_m0(const char* sbase, unsigned voff
                  :
                  : "s"(sbase), "v"(voff), "s"(m0val)
                  : "memory", "m0");
+}
+
+// the same with compile-time displacements: M0 = m0base + m0add (one SALU), global address + off (instruction immediate, 13-bit
+// signed).  m0add / off must fold to constants after inlining and unrolling ("i" constraints)
+__device__ __forceinline__ void glds16_saddr_m0_imm(const char* sbase, unsigned voff, unsigned m0base, int m0add, int off) {
+    // the instruction offset displaces the LDS address as well as the global one (LDS = M0 + offset + lane * 16): taken back out of M0
+    asm volatile("s_add_i32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %0 offset:%4"
+                 :
+                 : "s"(sbase), "v"(voff), "s"(m0base), "i"(m0add - off), "i"(off)
+                 : "memory", "m0", "scc");
 }
 
 // ---- host side ------------------------------------------------------------

@@ -14,6 +14,8 @@
 #define S2V_HOST
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
+#include <algorithm>
 
 // ---------------------------------------------------------------------------------------------------
 // shared epilogue: 4 consecutive columns n..n+3 of row m
@@ -134,31 +136,38 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + off);
 }
 
+// bias of a wave's 64 columns, 4 per lane and (i, rq).  The whole-tile case is ONE clause of eight independent loads (a per-load
+// bounds branch serialised them: eight global latencies, ~6000 cycles of a 128 x 64 epilogue)
+__device__ __forceinline__ void load_bias64(const GemmArgs& a, int nw, int hi, u32x2 (&bvec)[8]) {
+    const bf16_t* bias = (const bf16_t*)a.bias;
+    if (bias && nw + 64 <= a.N) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) bvec[q] = *(const u32x2*)(bias + nw + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi);  // 8-byte aligned
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int nl = (q >> 2) * 32 + 8 * (q & 3) + 4 * hi;
+            unsigned short t[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (bias && nw + nl + e < a.N) t[e] = ((const unsigned short*)bias)[nw + nl + e];
+            bvec[q] = u32x2{(unsigned)t[0] | ((unsigned)t[1] << 16), (unsigned)t[2] | ((unsigned)t[3] << 16)};
+        }
+    }
+}
+
 // Epilogue of one wave's 64(m) x 64(n) accumulator tile (2x2 MFMA 32x32 blocks, D[i = n][j = m]).
 // Accumulator layout -> +bias, (GELU), round to bf16 in registers -> the wave's private 8 KiB LDS patch (rows of
 // 128 B, 16-B chunks XOR-swizzled by row&7) -> read back row-major, 16 B per lane, 8 lanes per 128-B line -> gate /
 // residual in that layout -> full-line global stores.  A row-per-lane epilogue (8-B stores at a row stride) was
 // store-issue bound: ~0.7 ms of a 3.4 ms FF1 launch.
-template <int EPI, int MB, bool SC = false>
-__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x16 (&acc)[2][MB], int mw, int nw, char* patch, int lane) {
+// GRP = rows-of-8 groups whose patch reads and gate / residual loads are in flight together (one memory latency per GRP groups)
+template <int EPI, int MB, bool SC = false, int GRP = 4>
+__device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 (&acc)[2][MB], int mw, int nw, char* patch, int lane,
+                                                const u32x2 (&bvec)[8]) {
     // MB 32-row blocks: the patch holds MB*32 rows of 128 B (8 KiB for MB = 2, 16 KiB for MB = 4); all accumulator blocks are
-    // written first, then read back, so the LDS round trip and the bias loads are paid once per wave tile
+    // written first, then read back, so the LDS round trip is paid once per wave tile
     const int fr = lane & 31, hi = lane >> 5;
-    const bf16_t* bias = (const bf16_t*)a.bias;
-    u32x2 bvec[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int nl = (q >> 2) * 32 + 8 * (q & 3) + 4 * hi;
-        bvec[q] = u32x2{0u, 0u};
-        if (bias && nw + nl + 3 < a.N) bvec[q] = *(const u32x2*)(bias + nw + nl);  // 8-byte aligned: nw % 64 == 0, nl % 4 == 0
-        else if (bias) {
-            unsigned short t[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (nw + nl + e < a.N) t[e] = ((const unsigned short*)bias)[nw + nl + e];
-            bvec[q] = u32x2{(unsigned)t[0] | ((unsigned)t[1] << 16), (unsigned)t[2] | ((unsigned)t[3] << 16)};
-        }
-    }
     // SC (fp8 operands): acc * a_scale[row] * w_scale[column] first -- the dequantisation of the per-token / per-channel scales
     float sa[MB];
 #pragma unroll
@@ -177,54 +186,71 @@ __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x16 (&
             for (int j = 0; j < MB; ++j) {
                 float y[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float av = SC ? acc[i][j][rq * 4 + e] * (sa[j] * sw[e]) : acc[i][j][rq * 4 + e];
-                    y[e] = bf2f(f2bf(av + bv[e]));
-                    if (EPI == EPI_BIAS_GELU) y[e] = gelu_tanh_fast(y[e]);
-                }
+                for (int e = 0; e < 4; ++e) y[e] = (SC ? acc[i][j][rq * 4 + e] * (sa[j] * sw[e]) : acc[i][j][rq * 4 + e]) + bv[e];
                 const int row = j * 32 + fr;
                 u32x2 p;
-                p.x = pack2bf(y[0], y[1]);
-                p.y = pack2bf(y[2], y[3]);
+                p.x = pack2bf(y[0], y[1]);  // the linear's bf16 output (one rounding; a single wave per SIMD issues a VALU
+                p.y = pack2bf(y[2], y[3]);  // instruction every ~5 cycles, so the instruction count of this loop is its time)
+                if (EPI == EPI_BIAS_GELU) {  // GELU of the ROUNDED linear output, rounded again
+                    p.x = pack2bf(gelu_tanh_fast(__uint_as_float(p.x << 16)), gelu_tanh_fast(__uint_as_float(p.x & 0xffff0000u)));
+                    p.y = pack2bf(gelu_tanh_fast(__uint_as_float(p.y << 16)), gelu_tanh_fast(__uint_as_float(p.y & 0xffff0000u)));
+                }
                 *(u32x2*)(patch + row * 128 + ((((nl >> 3) ^ (row & 7))) << 4) + (nl & 4) * 2) = p;
             }
         }
     // same-wave LDS accesses are ordered; the compiler inserts the lgkmcnt wait for the dependent reads
     const int c16 = lane & 7;
     const int n = nw + c16 * 8;
+    const bool n_ok = n < a.N;            // epi_vec_ok: N % 8 == 0, so a started 8-column group is whole
+    const int nc = n_ok ? n : 0;          // loads stay in range (and unconditional: four rows' worth in flight at a time)
 #pragma unroll
-    for (int it = 0; it < MB * 4; ++it) {
-        const int row = it * 8 + (lane >> 3);
-        const int m = mw + row;
-        u32x4 v = *(const u32x4*)(patch + row * 128 + ((c16 ^ (row & 7)) << 4));
-        if (m >= a.M || n >= a.N) continue;
-        if (EPI == EPI_BIAS_GATE_RES) {
-            const int b = m / a.tok_per_batch;
-            const int r = m - b * a.tok_per_batch;
-            const void* gsel = r < a.text_len ? a.gate_txt : (a.gate_ref != nullptr && r < a.text_len + a.ref_len) ? a.gate_ref : a.gate_vid;
-            const bf16_t* gate = (const bf16_t*)gsel + (size_t)b * a.gate_stride + n;
-            bf16_t* x = (bf16_t*)a.X + (size_t)m * a.ldx + n;
-            const u32x4 g = *(const u32x4*)gate;
-            const u32x4 xo = *(const u32x4*)x;
-            u32x4 o;
+    for (int it0 = 0; it0 < MB * 4; it0 += GRP) {
+        u32x4 v[GRP], g[GRP], xo[GRP];
+        int mrow[GRP];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float t0 = bf2f(f2bf(__uint_as_float(g[e] << 16) * __uint_as_float(v[e] << 16)));
-                const float t1 = bf2f(f2bf(__uint_as_float(g[e] & 0xffff0000u) * __uint_as_float(v[e] & 0xffff0000u)));
-                o[e] = pack2bf(__uint_as_float(xo[e] << 16) + t0, __uint_as_float(xo[e] & 0xffff0000u) + t1);
+        for (int u = 0; u < GRP; ++u) {
+            const int row = (it0 + u) * 8 + (lane >> 3);
+            mrow[u] = mw + row;
+            v[u] = *(const u32x4*)(patch + row * 128 + ((c16 ^ (row & 7)) << 4));
+            const int m = min(mrow[u], a.M - 1);
+            if (EPI == EPI_BIAS_GATE_RES) {
+                const int b = m / a.tok_per_batch;
+                const int r = m - b * a.tok_per_batch;
+                const void* gsel = r < a.text_len ? a.gate_txt : (a.gate_ref != nullptr && r < a.text_len + a.ref_len) ? a.gate_ref : a.gate_vid;
+                g[u] = *(const u32x4*)((const bf16_t*)gsel + (size_t)b * a.gate_stride + nc);
+                xo[u] = *(const u32x4*)((const bf16_t*)a.X + (size_t)m * a.ldx + nc);
+            } else if (EPI == EPI_BIAS_ADD) {
+                xo[u] = *(const u32x4*)((const bf16_t*)a.R + (size_t)m * a.ldr + nc);
             }
-            *(u32x4*)x = o;
-        } else {
-            if (EPI == EPI_BIAS_ADD) {
-                const u32x4 rr = *(const u32x4*)((const bf16_t*)a.R + (size_t)m * a.ldr + n);
+        }
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            u32x4 o = v[u];
+            if (EPI == EPI_BIAS_GATE_RES) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t0 = bf2f(f2bf(__uint_as_float(g[u][e] << 16) * __uint_as_float(v[u][e] << 16)));
+                    const float t1 = bf2f(f2bf(__uint_as_float(g[u][e] & 0xffff0000u) * __uint_as_float(v[u][e] & 0xffff0000u)));
+                    o[e] = pack2bf(__uint_as_float(xo[u][e] << 16) + t0, __uint_as_float(xo[u][e] & 0xffff0000u) + t1);
+                }
+            } else if (EPI == EPI_BIAS_ADD) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    v[e] = pack2bf(__uint_as_float(v[e] << 16) + __uint_as_float(rr[e] << 16),
-                                   __uint_as_float(v[e] & 0xffff0000u) + __uint_as_float(rr[e] & 0xffff0000u));
+                    o[e] = pack2bf(__uint_as_float(v[u][e] << 16) + __uint_as_float(xo[u][e] << 16),
+                                   __uint_as_float(v[u][e] & 0xffff0000u) + __uint_as_float(xo[u][e] & 0xffff0000u));
             }
-            *(u32x4*)((bf16_t*)a.C + (size_t)m * a.ldc + n) = v;
+            if (mrow[u] < a.M && n_ok) {
+                if (EPI == EPI_BIAS_GATE_RES) *(u32x4*)((bf16_t*)a.X + (size_t)mrow[u] * a.ldx + n) = o;
+                else *(u32x4*)((bf16_t*)a.C + (size_t)mrow[u] * a.ldc + n) = o;
+            }
         }
     }
+}
+template <int EPI, int MB, bool SC = false>
+__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x16 (&acc)[2][MB], int mw, int nw, char* patch, int lane) {
+    u32x2 bvec[8];
+    load_bias64(a, nw, lane >> 5, bvec);
+    epilogue_wave_b<EPI, MB, SC, 4>(a, acc, mw, nw, patch, lane, bvec);
 }
 template <int EPI>
 __device__ __forceinline__ void epilogue_wave64(const GemmArgs& a, const f32x16 (&acc)[2][2], int mw, int nw, char* patch,
@@ -628,6 +654,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_w8(const GemmArgs a, int til
 // ---------------------------------------------------------------------------------------------------
 #ifdef S2V_DIAG
 __device__ long long g_pp_dbg[64];  // diagnostics (ABL == 4)
+__device__ long long g_blk_times[2048];  // [launch parity][workgroup]: s_memrealtime at entry / exit, cycles, output tiles (gemm_q4 ACCT)
+__device__ int g_launch_no;
+extern "C" __attribute__((visibility("default"))) int s2v_debug_read_blocks(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_blk_times), sizeof(long long) * 2048) == hipSuccess ? 0 : -1; }
 extern "C" __attribute__((visibility("default"))) int s2v_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_pp_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
 #endif
 
@@ -851,6 +880,407 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
         }
 }
 
+// ---------------------------------------------------------------------------------------------------
+#ifdef S2V_DIAG  // an experiment kept for the record ("four-wave persistent form"): it equals gemm_bf16_pp64, it does
+                 // not beat it, and it serves two epilogues only -- libs2v_hip_diag.so / tools/stall_q4.py / tools/check_q4.py
+// gemm_q4: PERSISTENT 256 x 256 block tile, FOUR waves (2 x 2) of 128 x 128 wave tiles = ONE wave per SIMD, K-tiles of 128 bytes
+// in two 64-KiB LDS stages.  A 128 x 128 wave tile reads 8 fragments per 16 MFMA where the 128 x 64 tiles of the eight-wave kernels
+// read 12: gemm_bf16_pp64 moves 256 KiB through the LDS per K-tile of 2048 MFMA cycles (125 of the 128 B/clk the LDS has), this
+// kernel 192 KiB.  One instruction stream per wave, written in issue order with a fence per MFMA slot:
+// { MFMA, one fragment read of the NEXT K16 step (first 8 slots), one LDS-DMA piece (every second slot of steps 0 and 3), at most
+// two or three instructions of the PREVIOUS output tile's epilogue }.
+//
+// One workgroup per CU walks its XCD's share of the output tiles; the K-tiles of successive output tiles form ONE stream through the
+// two stages, so the LDS-DMA of the next output tile's first K-tiles is issued in the last steps of this one (a workgroup per tile
+// paid ~2800 cycles of exposed prologue, ~2 % of a K = 3072 tile).
+//
+// Epilogue.  With one wave per SIMD nothing hides an epilogue: written after the K loop it cost 12 700 of a tile's 125 000 cycles
+// (7 000 of them the 128 KiB of stores, which leave a CU at ~18 B/clk), and GELU would add ~2 500 VALU instructions per wave at
+// ~5 cycles each.  So the tile is only CONVERTED after its K loop -- accumulators + bias -> 128 registers of packed bf16 (~650 VALU
+// instructions, the part that stays exposed) -- and everything else TRICKLES through the MFMA slots of the next tile's K loop, one
+// 32-row x 64-column unit (16 of the 128 registers) per five K-tiles: GELU two VALU instructions per slot, the LDS transposition
+// (8 ds_write_b64 + 4 ds_read_b128 through the wave's private 4-KiB patch), the gate / residual loads and arithmetic, 4 full-line
+// stores, then the 128 registers rotate down by one unit so that ONE set of five K-tile bodies serves all eight units.  Loads and
+// stores of the trickle are issued right after a K-tile's barrier, so the vmcnt(0) of the next barrier finds them complete.  The
+// last tile's epilogue runs the same micro-op sequence once without MFMAs.
+//
+// The LDS-DMA of a K-tile is issued as EARLY as its stage allows -- three to four steps (>= 1500 cycles) before its first use.
+// ONE barrier per K-tile, at the start of its last step (s = 3):
+//   RAW  K-tile g+1 (A half issued in step 3 of K-tile g-1, W half in step 0 of K-tile g): vmcnt(0) + barrier before step 3 of
+//        K-tile g, whose fragment prefetch is the first read of K-tile g+1;
+//   WAR  K-tile g+2 overwrites the stage of K-tile g from step 3 of K-tile g on, i.e. after that same barrier; the last fragment
+//        reads of K-tile g are issued in its step 2 and waited for (lgkmcnt(0)) before the barrier.
+// Plain (non-conv) operands, K >= 43 K-tiles, N % 64 == 0, vector epilogue (epi_vec_ok) only; launch_gemm_bf16 checks.
+template <int EPI, int ACCT = 0>
+__global__ __launch_bounds__(256, 1) void gemm_q4(const GemmArgs a, int tiles_m, int tiles_n) {
+    constexpr int ES = 2, BKE = 64, NSTEP = 4, NRD = 8, GM = 4;
+    static_assert(EPI == EPI_BIAS || EPI == EPI_BIAS_GELU, "gemm_q4: bias / bias + GELU only (the register file has no room for gate and residual rows)");
+    constexpr bool GELU = EPI == EPI_BIAS_GELU, GATE = false, ADDR = false, HAS_LD = false;
+    constexpr int PH_ST = EPI == EPI_BIAS ? 0 : 3, NPH = GELU ? 4 : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem_all[];
+    char* smem = smem_all + 32768;  // [0, 32 KiB): the four epilogue patches; the stages above them, so that M0 minus an instruction
+                                    // offset (glds16_saddr_m0_imm) never drops below the workgroup's LDS base
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int fr = lane & 31, hi = lane >> 5;
+
+    // this workgroup's output tiles: XCD x owns a contiguous range of the (GM-grouped) tile order, its workgroups take every
+    // nslots-th tile of it, so at any time the CUs of an XCD work on neighbouring tiles (shared A / W panels in that XCD's L2)
+    const int T = tiles_m * tiles_n;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int q = T >> 3, r = T & 7;
+    const int first = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    const int cnt = q + (xcd < r ? 1 : 0);
+    if (slot >= cnt) return;
+    auto tile_origin = [&](int local, int& m0, int& n0) {
+        const int wg = first + min(local, cnt - 1);  // past the end: the last tile again (its loads land in dead stages)
+        const int per_group = GM * tiles_n;
+        const int group = wg / per_group;
+        const int first_m = group * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        const int in_g = wg - group * per_group;
+        m0 = (first_m + in_g % gsz) * WBM;
+        n0 = (in_g / gsz) * WBN;
+    };
+
+    // staging: piece p (0..7) of an operand = rows p*32 + wave*8 + (lane >> 3); the chunk XOR depends on row bits 1-3 only, so ONE
+    // per-lane offset serves every piece; the piece displacement goes on the SGPR base (advanced once per K-tile), the K-tile
+    // displacement in the instruction's immediate, the LDS destination in M0 = stage base + immediate: five instructions per piece
+    // (s_add_u32, s_addc_u32, s_add m0, s_nop, global_load_lds) and no VGPR beyond the two offsets -- the register file is full.
+    const int srow = wave * 8 + (lane >> 3);
+    const int scol = ((lane & 7) ^ ((srow >> 1) & 7)) * (16 / ES);
+    const unsigned offA = (unsigned)(ES * ((int64_t)srow * a.lda + scol));
+    const unsigned offW = (unsigned)(ES * ((int64_t)srow * a.ldw + scol));
+    const int64_t pstrideA = (int64_t)ES * 32 * a.lda, pstrideW = (int64_t)ES * 32 * a.ldw;  // piece p: + p * pstride on the SGPR base
+    const int nT = a.K / BKE;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base_u32(smem)) + wave * 1024;
+    int m0, n0, m1, n1;
+    tile_origin(slot, m0, n0);
+    tile_origin(slot + nslots, m1, n1);
+    const char* AK = (const char*)a.A + ES * (int64_t)m0 * a.lda;  // K-tile t of the current output tile
+    const char* WK = (const char*)a.W + ES * (int64_t)n0 * a.ldw;
+    const char* Anxt = (const char*)a.A + ES * (int64_t)m1 * a.lda;  // K-tile 0 of the next output tile
+    const char* Wnxt = (const char*)a.W + ES * (int64_t)n1 * a.ldw;
+    unsigned so = 0;  // byte offset of the stage that holds K-tile t (0 / 65536); the stream of K-tiles never resets it
+
+    f32x16 acc[4][4];           // [n block][m block]
+    bf16x8 wf[2][4], af[2][4];  // fragment registers, double-buffered by step parity
+    auto rd = [&](bool other, int s, int buf, int n) {  // the n-th fragment read of step s of K-tile t (other: of K-tile t+1)
+        const char* tA = smem + (other ? so ^ 65536u : so);
+        const char* tW = tA + 32768;
+        if (n >> 2) af[buf][n & 3] = lds_frag(tA, wm * 128 + (n & 3) * 32 + fr, s * 2 + hi);
+        else wf[buf][n & 3] = lds_frag(tW, wn * 128 + (n & 3) * 32 + fr, s * 2 + hi);
+    };
+    auto fence = [&]() { __builtin_amdgcn_sched_barrier(0); };
+    auto now2 = [&]() -> long long { return ACCT ? (long long)__builtin_amdgcn_s_memtime() : 0; };
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long tk0 = now2(), tr0 = ACCT ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+#ifdef S2V_DIAG
+    const int launch_no = ACCT ? g_launch_no : 0;
+#endif
+
+    // ---- the trickled epilogue of the PREVIOUS output tile ------------------------------------------------------------------
+    // Its 128 x 128 wave tile as packed bf16 pairs, unit-major: unit u = h * 4 + j (h: 64-column half, j: 32-row block); within a unit
+    // register (i2 * 4 + rq) * 2 + e holds columns i2*32 + 8 rq + 4 hi + 2 e + {0, 1} of row fr -- the accumulator layout.  Units 0
+    // and 1 go straight into the wave's two 4-KiB LDS patches at conversion time, units 2..7 wait in pk[16 (u - 2) ..]: 96 registers
+    // are what is left beside 256 accumulators and 64 fragment registers (with 128 the compiler spilled 81).
+    unsigned pk[96];
+#pragma unroll
+    for (int i = 0; i < 96; ++i) pk[i] = 0u;
+    u32x4 rb[4] = {}, gl[4] = {}, xl[4] = {};  // the unit's 32 rows read back row-major (16 B per lane), their gates, their residuals
+    float ga = 0.f, gb = 0.f, ta = 0.f, tb = 0.f;
+    int mp = 0, np = 0;       // top-left corner of the previous tile's wave tile
+    bool have_prev = false;  // no stores while pk holds nothing (first tile)
+    char* patch = smem_all + wave * 8192;
+    const int c16 = lane & 7, rl = lane >> 3;
+    const float inv_tok = GATE ? 1.0f / (float)a.tok_per_batch : 0.f;
+    auto trk = [&](int PH, int s, int k, int u) {  // the trickle's micro-ops of slot (s, k) of the K-tile with phase PH of unit u
+        const int sq = s * 16 + k;
+        const int mu = mp + (u & 3) * 32, nu = np + (u >> 2) * 64;  // the unit's corner
+        const int n = nu + c16 * 8;
+        const bool n_ok = n < a.N;
+        const int nc = n_ok ? n : 0;
+        if (PH == 0 && s == 1 && k == 8) {  // accumulator layout -> patch (rows of 128 B, 16-B chunks XOR-swizzled by row & 7).  The ONLY
+            // unit-specific instructions of the trickle: eight ds_write_b64 behind one wave-uniform switch (this slot overruns its MFMA
+            // by ~100 cycles, once per unit); everything after the transposition works on the read-back registers
+            char* wp = patch + (u & 1) * 4096 + fr * 128 + hi * 8;
+            const int x7 = fr & 7;
+#define S2V_Q4_WR(U)                                                                                                          \
+    case U:                                                                                                                   \
+        _Pragma("unroll") for (int w = 0; w < 8; ++w)                                                                        \
+            *(u32x2*)(wp + ((((w >> 2) * 4 + (w & 3)) ^ x7) << 4)) = u32x2{pk[(U - 2) * 16 + 2 * w], pk[(U - 2) * 16 + 2 * w + 1]}; \
+        break;
+            switch (u) {
+                S2V_Q4_WR(2) S2V_Q4_WR(3) S2V_Q4_WR(4) S2V_Q4_WR(5) S2V_Q4_WR(6) S2V_Q4_WR(7)
+                default: break;  // units 0 and 1 are in their patches since the conversion
+            }
+#undef S2V_Q4_WR
+        }
+        if (PH == 0 && s == 2 && k >= 8 && k < 12) {  // read back row-major: row it*8 + lane/8, 16 B at column chunk lane%8
+            const int it = k - 8, row = it * 8 + rl;
+            rb[it] = *(const u32x4*)(patch + (u & 1) * 4096 + row * 128 + ((c16 ^ (row & 7)) << 4));
+        }
+        if (GELU && ((PH == 0 && s == 3) || PH == 1 || PH == 2 || (PH == 3 && s < 2))) {  // x * sigmoid(2u) as in gelu_tanh_fast() on the
+            // read-back rows, two elements (one packed register) per eleven slots, two VALU instructions per slot
+            const int qq = PH * 64 + sq - 48, pr = qq / 11, st = qq % 11, it = pr >> 2, e = pr & 3;
+            if (pr < 16) {
+                if (st == 0) { ga = __uint_as_float(rb[it][e] << 16); gb = __uint_as_float(rb[it][e] & 0xffff0000u); }
+                if (st == 1) { ta = 0.044715f * ga; tb = 0.044715f * gb; }
+                if (st == 2) { ta = ta * ga; tb = tb * gb; }
+                if (st == 3) { ta = ta * ga + ga; tb = tb * gb + gb; }
+                if (st == 4) { ta = 1.5957691216057308f * ta; tb = 1.5957691216057308f * tb; }
+                if (st == 5) { ta = -1.4426950408889634f * ta; tb = -1.4426950408889634f * tb; }
+                if (st == 6) { ta = __builtin_amdgcn_exp2f(ta); tb = __builtin_amdgcn_exp2f(tb); }
+                if (st == 7) { ta = 1.0f + ta; tb = 1.0f + tb; }
+                if (st == 8) { ta = __builtin_amdgcn_rcpf(ta); tb = __builtin_amdgcn_rcpf(tb); }
+                if (st == 9) { ta = ga * ta; tb = gb * tb; }
+                if (st == 10) rb[it][e] = pack2bf(ta, tb);
+            }
+        }
+        if (HAS_LD && PH == 0 && s == 3 && (k & 1)) {  // residual / gate rows, right after the barrier (complete by the next one)
+            const int it = (k >> 1) & 3, m = min(mu + it * 8 + rl, a.M - 1);
+            if (k < 8) {
+                xl[it] = GATE ? *(const u32x4*)((const bf16_t*)a.X + (size_t)m * a.ldx + nc) : *(const u32x4*)((const bf16_t*)a.R + (size_t)m * a.ldr + nc);
+            } else if (GATE) {
+                int b = (int)((float)m * inv_tok);  // m / tok_per_batch without the integer division (corrected below)
+                int rr = m - b * a.tok_per_batch;
+                if (rr < 0) { rr += a.tok_per_batch; --b; }
+                if (rr >= a.tok_per_batch) { rr -= a.tok_per_batch; ++b; }
+                const void* gsel = rr < a.text_len ? a.gate_txt : (a.gate_ref != nullptr && rr < a.text_len + a.ref_len) ? a.gate_ref : a.gate_vid;
+                gl[it] = *(const u32x4*)((const bf16_t*)gsel + (size_t)b * a.gate_stride + nc);
+            }
+        }
+        if (HAS_LD && ((PH == 1 && s == 3) || PH == 2 || (PH == 3 && s < 3))) {  // first use after the barrier of PH 1: loads are complete
+            const int qq = (PH - 1) * 64 + sq - 48;  // 0 .. 127
+            if (GATE) {  // rnd(x + rnd(gate * v)), one bf16 pair per eight slots
+                const int pr = qq >> 3, st = qq & 7, it = pr >> 2, e = pr & 3;
+                if (st == 0) { ga = __uint_as_float(gl[it][e] << 16); gb = __uint_as_float(gl[it][e] & 0xffff0000u); }
+                if (st == 1) { ta = __uint_as_float(rb[it][e] << 16); tb = __uint_as_float(rb[it][e] & 0xffff0000u); }
+                if (st == 2) { ta = ga * ta; tb = gb * tb; }
+                if (st == 3) rb[it][e] = pack2bf(ta, tb);
+                if (st == 4) { ta = __uint_as_float(rb[it][e] << 16); tb = __uint_as_float(rb[it][e] & 0xffff0000u); }
+                if (st == 5) { ga = __uint_as_float(xl[it][e] << 16); gb = __uint_as_float(xl[it][e] & 0xffff0000u); }
+                if (st == 6) { ta = ga + ta; tb = gb + tb; }
+                if (st == 7) rb[it][e] = pack2bf(ta, tb);
+            } else if (qq < 64) {  // rnd(v + r), one pair per four slots
+                const int pr = qq >> 2, st = qq & 3, it = pr >> 2, e = pr & 3;
+                if (st == 0) { ta = __uint_as_float(rb[it][e] << 16); tb = __uint_as_float(rb[it][e] & 0xffff0000u); }
+                if (st == 1) { ga = __uint_as_float(xl[it][e] << 16); gb = __uint_as_float(xl[it][e] & 0xffff0000u); }
+                if (st == 2) { ta = ga + ta; tb = gb + tb; }
+                if (st == 3) rb[it][e] = pack2bf(ta, tb);
+            }
+        }
+        if (PH == PH_ST && s == 3 && (k & 1) && k < 8) {  // four full-line stores, right after the barrier
+            const int it = k >> 1, m = mu + it * 8 + rl;
+            if (have_prev && m < a.M && n_ok) {
+                if (GATE) *(u32x4*)((bf16_t*)a.X + (size_t)m * a.ldx + n) = rb[it];
+                else *(u32x4*)((bf16_t*)a.C + (size_t)m * a.ldc + n) = rb[it];
+            }
+        }
+    };
+
+    // one K-tile: 4 steps of 16 MFMA.  MODE 1: first K-tile of an output tile (accumulators start from the inline constant 0, no
+    // 256-instruction clear); MODE 2 / 3: the last two, whose LDS-DMA belongs to the next output tile (K-tiles 0 and 1 of it).
+    // PH >= 0: the K-tile carries phase PH of the trickle for unit u
+    auto ktile = [&](auto mode_tag, auto ph_tag, int u) {
+        constexpr int MODE = decltype(mode_tag)::value, PH = decltype(ph_tag)::value;
+        const unsigned stg = lds0 + so, stgo = lds0 + (so ^ 65536u);
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s == NSTEP - 1) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                fence();
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int i = k >> 2, j = k & 3;
+                if (MODE == 1 && s == 0) {
+                    const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], af[cur][j], z, 0, 0, 0);
+                } else {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cur][i], af[cur][j], acc[i][j], 0, 0, 0);
+                }
+                if (k < NRD) {  // fragments of the next step (of the next K-tile after the last step)
+                    if (s < NSTEP - 1) rd(false, s + 1, nxt, k);
+                    else rd(true, 0, nxt, k);
+                }
+                if ((k & 1) == 0) {
+                    const int p = k >> 1;
+                    if (s == 0) {  // W half of K-tile t+1 -> the other stage
+                        if (MODE == 3) glds16_saddr_m0_imm(Wnxt + p * pstrideW, offW, stgo, 32768 + p * 4096, 0);
+                        else glds16_saddr_m0_imm(WK + p * pstrideW, offW, stgo, 32768 + p * 4096, 128);
+                    }
+                    if (s == NSTEP - 1) {  // A half of K-tile t+2 -> this stage (its reads ended before the barrier above)
+                        if (MODE == 2) glds16_saddr_m0_imm(Anxt + p * pstrideA, offA, stg, p * 4096, 0);
+                        else if (MODE == 3) glds16_saddr_m0_imm(Anxt + p * pstrideA, offA, stg, p * 4096, 128);
+                        else glds16_saddr_m0_imm(AK + p * pstrideA, offA, stg, p * 4096, 256);
+                    }
+                }
+                if (PH >= 0) trk(PH, s, k, u);
+                fence();
+            }
+        }
+        if (!(ACCT & 4)) {  // ablation 4: every K-tile re-reads K-tile 0 (cache-resident operands: the loop without memory latency)
+            AK += ES * BKE;
+            WK += ES * BKE;
+        }
+        so ^= 65536u;
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using CN = std::integral_constant<int, -1>;
+
+    {  // K-tile 0 whole, A half of K-tile 1
+        const unsigned stg = lds0, stgo = lds0 + 65536u;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) glds16_saddr_m0_imm(AK + p * pstrideA, offA, stg, p * 4096, 0);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) glds16_saddr_m0_imm(WK + p * pstrideW, offW, stg, 32768 + p * 4096, 0);
+#pragma unroll
+        for (int p = 0; p < 8; ++p) glds16_saddr_m0_imm(AK + p * pstrideA, offA, stgo, p * 4096, 128);
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // K-tile 0 landed; the A half of K-tile 1 stays in flight
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int n = 0; n < NRD; ++n) rd(false, 0, 0, n);
+    fence();
+    if (ACCT) tacc[4] = now2() - tk0;
+
+    for (int local = slot; local < cnt; local += nslots) {
+        const long long tl0 = now2();
+        ktile(std::integral_constant<int, 1>{}, CN{}, 0);
+        for (int u = 0; u < 8; ++u) {  // 8 * NPH K-tiles carry the previous tile's epilogue, one unit after the other
+            ktile(C0{}, std::integral_constant<int, 0>{}, u);
+            if (NPH > 1) {
+                ktile(C0{}, std::integral_constant<int, 1>{}, u);
+                ktile(C0{}, std::integral_constant<int, 2>{}, u);
+                ktile(C0{}, std::integral_constant<int, 3>{}, u);
+            }
+        }
+        for (int t = 1 + 8 * NPH; t < nT - 2; ++t) ktile(C0{}, CN{}, 0);
+        ktile(std::integral_constant<int, 2>{}, CN{}, 0);
+        // bias: ONE more K step whose W fragment holds bias[n] at k = 0 and whose A fragment holds 1.0 at k = 0 -- the matrix pipe adds
+        // acc + bias * 1 in fp32 (exact product, one rounding, after the last real K step: the order of the plain epilogue) for 16
+        // MFMAs per tile instead of 32 bias registers and 256 v_add on a wave that issues one VALU instruction per ~5 cycles
+        unsigned short bz[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int nb = min(n0 + wn * 128 + i * 32, a.N - 32) + fr;
+            bz[i] = (a.bias && hi == 0) ? ((const unsigned short*)a.bias)[nb] : (unsigned short)0;
+        }
+        ktile(std::integral_constant<int, 3>{}, CN{}, 0);
+        {
+            bf16x8 one = {0, 0, 0, 0, 0, 0, 0, 0};
+            one[0] = hi == 0 ? (__bf16)1.0f : (__bf16)0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x8 bw = {0, 0, 0, 0, 0, 0, 0, 0};
+                bw[0] = __builtin_bit_cast(__bf16, bz[i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bw, one, acc[i][j], 0, 0, 0);
+            }
+        }
+        const long long te0 = now2();
+        if (ACCT) tacc[3] += te0 - tl0;
+
+        // conversion: rnd_bf16(accumulator) -> pk (the only part of the epilogue that is not hidden)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int un = (i >> 1) * 4 + j, w = (i & 1) * 4 + rq;
+                    const unsigned p0 = pack2bf(acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1]);
+                    const unsigned p1 = pack2bf(acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]);
+                    if (un < 2) {
+                        *(u32x2*)(patch + un * 4096 + fr * 128 + hi * 8 + ((((w >> 2) * 4 + (w & 3)) ^ (fr & 7)) << 4)) = u32x2{p0, p1};
+                    } else {
+                        pk[(un - 2) * 16 + 2 * w] = p0;
+                        pk[(un - 2) * 16 + 2 * w + 1] = p1;
+                    }
+                }
+        mp = m0 + wm * 128;
+        np = n0 + wn * 128;
+        have_prev = true;
+        fence();
+        if (ACCT) tacc[0] += now2() - te0;
+
+        // the stream moves on: the K-tiles nT, nT+1 issued above are K-tiles 0, 1 of the next output tile
+        m0 = m1;
+        n0 = n1;
+        AK = Anxt;
+        WK = Wnxt;
+        tile_origin(local + 2 * nslots, m1, n1);
+        Anxt = (const char*)a.A + ES * (int64_t)m1 * a.lda;
+        Wnxt = (const char*)a.W + ES * (int64_t)n1 * a.ldw;
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // LDS-DMA of the (unused) K-tiles past the last output tile
+    const long long tf0 = now2();
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {  // the last tile's epilogue, unit by unit through the same patches, nothing to hide behind
+        const int mu = mp + (u & 3) * 32, nu = np + (u >> 2) * 64;
+        const int n = nu + c16 * 8;
+        char* pu = patch + (u & 1) * 4096;
+        if (u >= 2) {
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+                *(u32x2*)(pu + fr * 128 + hi * 8 + ((((w >> 2) * 4 + (w & 3)) ^ (fr & 7)) << 4)) = u32x2{pk[(u - 2) * 16 + 2 * w], pk[(u - 2) * 16 + 2 * w + 1]};
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = it * 8 + rl, m = mu + row;
+            u32x4 v = *(const u32x4*)(pu + row * 128 + ((c16 ^ (row & 7)) << 4));
+            if (GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    v[e] = pack2bf(gelu_tanh_fast(__uint_as_float(v[e] << 16)), gelu_tanh_fast(__uint_as_float(v[e] & 0xffff0000u)));
+            }
+            if (have_prev && m < a.M && n < a.N) *(u32x4*)((bf16_t*)a.C + (size_t)m * a.ldc + n) = v;
+        }
+    }
+#ifdef S2V_DIAG
+    if (ACCT) {
+        tacc[1] = now2() - tf0;                                         // final flush
+        tacc[5] = now2() - tk0;                                         // whole workgroup
+        tacc[6] = (long long)__builtin_amdgcn_s_memrealtime() - tr0;    // the same in 100 MHz ticks
+        tacc[7] = (cnt - slot + nslots - 1) / nslots;                   // output tiles of this workgroup
+        if (blockIdx.x == 100 && lane == 0)
+            for (int e = 0; e < 8; ++e) g_pp_dbg[wave * 8 + e] = tacc[e];
+        if (tid == 0 && blockIdx.x < 256) {
+            long long* o = g_blk_times + (launch_no & 1) * 1024 + blockIdx.x * 4;
+            o[0] = tr0;
+            o[1] = tr0 + tacc[6];
+            o[2] = tacc[5];
+            o[3] = tacc[7];
+            if (blockIdx.x == 0) g_launch_no = launch_no + 1;
+        }
+    }
+#endif
+}
+
+template <int EPI>
+static int launch_q4_t(const GemmArgs& a, hipStream_t st) {
+    const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
+    const void* fn = (const void*)gemm_q4<EPI, 0>;
+    if (EPI == EPI_BIAS) switch (a.ablate) {  // stall accounting
+            case 5: fn = (const void*)gemm_q4<EPI_BIAS, 2>; break;
+            case 6: fn = (const void*)gemm_q4<EPI_BIAS, 2 | 4>; break;
+            default: break;
+        }
+    S2V_TRY(ensure_lds_attr(fn, 163840));
+    int dev = 0, ncu = 256;
+    S2V_CHECK_HIP(hipGetDevice(&dev));
+    S2V_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int grid = std::min((ncu / 8) * 8, ((tiles_m * tiles_n + 7) / 8) * 8);
+    void* args[] = {(void*)&a, (void*)&tiles_m, (void*)&tiles_n};
+    S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(grid), dim3(256), args, 163840, st));
+    return 0;
+}
+#endif
+
 template <int EPI>
 static int launch_pp64_t(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
@@ -949,7 +1379,13 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
         return 0;
     }
     S2V_REQUIRE(a.K % BK == 0, "gemm_bf16: K must be a multiple of 64");
-    if (g_gemm_impl == 7 && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+#ifdef S2V_DIAG
+    if (g_gemm_impl == 8 && !a.conv && (epi == EPI_BIAS || epi == EPI_BIAS_GELU) && w_tile_ok(a) && a.N % 64 == 0 && a.K >= 36 * 64 &&
+        epi_vec_ok(a, epi) && a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM && a.lda % 8 == 0 && a.ldw % 8 == 0) {
+        return epi == EPI_BIAS ? launch_q4_t<EPI_BIAS>(a, st) : launch_q4_t<EPI_BIAS_GELU>(a, st);
+    }
+#endif
+    if ((g_gemm_impl == 7 || g_gemm_impl == 8) && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
             case EPI_BIAS: return launch_pp64_t<EPI_BIAS>(a, st);

@@ -14,7 +14,7 @@ for sub in "abc":
     for db in glob.glob(f"{out}/{sub}/*.db"):
         c = sqlite3.connect(db)
         q = "select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"
-        rows = [r for r in c.execute(q) if any(k in r[0] for k in ("gemm_bf16", "attn_", "Cijk"))]
+        rows = [r for r in c.execute(q) if any(k in r[0] for k in ("gemm_", "attn_", "Cijk"))]
         for n, ctr, cnt, avg in rows:
             print(f"{n.replace('void ','').split('(')[0][:28]:28s} {ctr:34s} n={cnt:4d} avg={avg:16.1f}")
 PY
