@@ -235,6 +235,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
 // worth its precondition).
 #ifdef S2V_DIAG
 __device__ long long g_attn_dbg[64];  // ACCT: per-wave s_memtime totals of block 100
+__device__ long long g_attn_blk[2 * 8192];  // ACCT: s_memrealtime at entry / exit of every workgroup (timeline of a launch)
+extern "C" __attribute__((visibility("default"))) int s2v_attn_debug_read_blocks(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_blk), sizeof(long long) * 2 * 8192) == hipSuccess ? 0 : -1; }
 extern "C" __attribute__((visibility("default"))) int s2v_attn_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
 #endif
 template <bool ACCT>
@@ -245,6 +247,12 @@ __global__ __launch_bounds__(512, 2) void attn_pp_k(const AttnArgs a, int nqb) {
     const int grp = wave >> 2;
     const int fr = lane & 31, hi = lane >> 5;
 
+#ifdef S2V_DIAG
+    if (ACCT && tid == 0 && blockIdx.x < 8192) g_attn_blk[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
+#ifdef S2V_DIAG
+    if (ACCT && tid == 0 && blockIdx.x < 8192) g_attn_blk[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
     // XCD-aware order: all q-blocks of one (b,h) run on one XCD so its K/V stay in that XCD's L2
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
@@ -466,6 +474,9 @@ __global__ __launch_bounds__(512, 2) void attn_pp_k(const AttnArgs a, int nqb) {
         u32x4 v = {rx[0], ry[0], rx[1], ry[1]};
         if (q_row < a.Ntok) *(u32x4*)(o + 8 * g) = v;
     }
+#ifdef S2V_DIAG
+    if (ACCT && tid == 0 && blockIdx.x < 8192) g_attn_blk[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 #ifdef S2V_DIAG

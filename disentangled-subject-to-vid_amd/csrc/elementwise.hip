@@ -37,135 +37,151 @@ template <> struct Vec16<bf16_t> {
 
 // ---------------------------------------------------------------------------------------------------
 // Row LayerNorm helpers: one wave per row, row cached in registers (D <= 4096, D % (16/sizeof(T)) == 0)
+// NR = rounds of 64 lanes x 16 bytes that cover the row (compile time: 6 for D = 3072 in bf16).  Every load is UNCONDITIONAL on a
+// clamped address and the lane mask is applied to the value: with a per-chunk bounds branch the compiler closed each load with its
+// own s_waitcnt vmcnt(0), i.e. a wave fetched its row in NR dependent memory round trips (3.1 TB/s on the C3 step).
 #define LN_MAX_FLOATS 64
-template <typename T>
-__device__ __forceinline__ void row_load(const T* x, int D, int lane, float* v, int& nch) {
+template <typename T, int NR>
+__device__ __forceinline__ void row_load(const T* x, int D, int lane, float* v) {
     constexpr int VN = Vec16<T>::N;
     const int chunks = D / VN;
-    nch = 0;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_FLOATS / VN; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int c = lane + 64 * i;
-        if (c < chunks) {
-            Vec16<T>::ld(x + c * VN, v + i * VN);
-            nch = i + 1;
-        } else {
+        const bool ok = c < chunks;
+        Vec16<T>::ld(x + (ok ? c : 0) * VN, v + i * VN);
 #pragma unroll
-            for (int e = 0; e < VN; ++e) v[i * VN + e] = 0.f;
-        }
+        for (int e = 0; e < VN; ++e) v[i * VN + e] = ok ? v[i * VN + e] : 0.f;
     }
 }
 // normalise the register-resident row in place: v = rnd((v-mean)*rstd*w + b)
-template <typename T>
+template <typename T, int NR>
 __device__ __forceinline__ void row_layernorm(float* v, int D, int lane, const T* w, const T* b, float eps) {
     constexpr int VN = Vec16<T>::N;
     const int chunks = D / VN;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_FLOATS; ++i) s += v[i];
+    for (int i = 0; i < NR * VN; ++i) s += v[i];
     const float mean = wave_sum(s) / (float)D;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_FLOATS / VN; ++i) {
-        const int c = lane + 64 * i;
-        if (c < chunks) {
+    for (int i = 0; i < NR; ++i) {
+        const bool ok = lane + 64 * i < chunks;
 #pragma unroll
-            for (int e = 0; e < VN; ++e) {
-                const float d = v[i * VN + e] - mean;
-                q += d * d;
-            }
+        for (int e = 0; e < VN; ++e) {
+            const float d = v[i * VN + e] - mean;
+            q += ok ? d * d : 0.f;
         }
     }
     const float var = wave_sum(q) / (float)D;
     const float rstd = 1.0f / sqrtf(var + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAX_FLOATS / VN; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int c = lane + 64 * i;
-        if (c < chunks) {
-            float wv[VN], bv[VN];
-            Vec16<T>::ld(w + c * VN, wv);
-            Vec16<T>::ld(b + c * VN, bv);
+        const bool ok = c < chunks;
+        const int cc = ok ? c : 0;
+        float wv[VN], bv[VN];
+        Vec16<T>::ld(w + cc * VN, wv);
+        Vec16<T>::ld(b + cc * VN, bv);
 #pragma unroll
-            for (int e = 0; e < VN; ++e) v[i * VN + e] = ET<T>::rnd((v[i * VN + e] - mean) * rstd * wv[e] + bv[e]);
-        }
+        for (int e = 0; e < VN; ++e) v[i * VN + e] = ok ? ET<T>::rnd((v[i * VN + e] - mean) * rstd * wv[e] + bv[e]) : 0.f;  // lanes past the row stay 0 (tail_norm normalises twice)
     }
 }
 // v = rnd(rnd(v * rnd(1+scale)) + shift), then store
-template <typename T>
+template <typename T, int NR>
 __device__ __forceinline__ void row_modulate_store(float* v, int D, int lane, const T* shift, const T* scale, T* y) {
     constexpr int VN = Vec16<T>::N;
     const int chunks = D / VN;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_FLOATS / VN; ++i) {
+    for (int i = 0; i < NR; ++i) {
         const int c = lane + 64 * i;
-        if (c < chunks) {
-            float sc[VN], sh[VN], o[VN];
-            Vec16<T>::ld(scale + c * VN, sc);
-            Vec16<T>::ld(shift + c * VN, sh);
+        const bool ok = c < chunks;
+        const int cc = ok ? c : 0;
+        float sc[VN], sh[VN], o[VN];
+        Vec16<T>::ld(scale + cc * VN, sc);
+        Vec16<T>::ld(shift + cc * VN, sh);
 #pragma unroll
-            for (int e = 0; e < VN; ++e) {
-                const float s1 = ET<T>::rnd(1.0f + sc[e]);
-                const float p = ET<T>::rnd(v[i * VN + e] * s1);
-                o[e] = p + sh[e];
-            }
-            Vec16<T>::st(y + c * VN, o);
+        for (int e = 0; e < VN; ++e) {
+            const float s1 = ET<T>::rnd(1.0f + sc[e]);
+            const float p = ET<T>::rnd(v[i * VN + e] * s1);
+            o[e] = p + sh[e];
         }
+        if (ok) Vec16<T>::st(y + c * VN, o);
     }
 }
+// rounds needed for D elements of T, rounded up to an instantiated count
+template <typename T> static int ln_rounds(int D) {
+    const int need = (D / Vec16<T>::N + 63) / 64;
+    for (int r : {1, 2, 3, 4, 6, 8, 12, 16})
+        if (r >= need) return r;
+    return -1;
+}
+#define S2V_LN_DISPATCH(T, D, ...)                                                   \
+    switch (ln_rounds<T>(D)) {                                                        \
+        case 1: { constexpr int NR = 1; __VA_ARGS__; } break;                                \
+        case 2: { constexpr int NR = 2; __VA_ARGS__; } break;                                \
+        case 3: { constexpr int NR = 3; __VA_ARGS__; } break;                                \
+        case 4: { constexpr int NR = 4; __VA_ARGS__; } break;                                \
+        case 6: { constexpr int NR = 6; __VA_ARGS__; } break;                                \
+        case 8: { constexpr int NR = 8; __VA_ARGS__; } break;                                \
+        case 12: if constexpr (sizeof(T) == 4) { constexpr int NR = 12; __VA_ARGS__; } break; \
+        case 16: if constexpr (sizeof(T) == 4) { constexpr int NR = 16; __VA_ARGS__; } break; \
+        default: return s2v_fail(__FILE__, __LINE__, "layer norm: row too long", -1); \
+    }
 
 // CogVideoXLayerNormZero.forward (normalization.py:467-484): LN(x)*(1+scale)+shift, three token ranges
-template <typename T>
+template <typename T, int NR>
 __global__ __launch_bounds__(256) void ln_modulate_k(const LnModArgs a) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= a.B * a.Ntok) return;
     const int b = row / a.Ntok, r = row - b * a.Ntok;
-    float v[LN_MAX_FLOATS];
-    int nch;
-    row_load<T>((const T*)a.x + (size_t)row * a.ldx, a.D, lane, v, nch);
-    row_layernorm<T>(v, a.D, lane, (const T*)a.w, (const T*)a.b, a.eps);
+    float v[NR * Vec16<T>::N];
+    row_load<T, NR>((const T*)a.x + (size_t)row * a.ldx, a.D, lane, v);
+    row_layernorm<T, NR>(v, a.D, lane, (const T*)a.w, (const T*)a.b, a.eps);
     const bool txt = r < a.text_len;
     const bool ref = a.shift_ref != nullptr && !txt && r < a.text_len + a.ref_len;
     const T* shift = (const T*)(txt ? a.shift_txt : ref ? a.shift_ref : a.shift_vid) + (size_t)b * a.mod_stride;
     const T* scale = (const T*)(txt ? a.scale_txt : ref ? a.scale_ref : a.scale_vid) + (size_t)b * a.mod_stride;
-    row_modulate_store<T>(v, a.D, lane, shift, scale, (T*)a.y + (size_t)row * a.ldy);
+    row_modulate_store<T, NR>(v, a.D, lane, shift, scale, (T*)a.y + (size_t)row * a.ldy);
 }
 int launch_ln_modulate(const LnModArgs& a, int dtype, hipStream_t st) {
     S2V_REQUIRE(a.D <= 4096 && a.D % 8 == 0, "ln_modulate: D must be <= 4096 and a multiple of 8");
     const int rows = a.B * a.Ntok;
     dim3 grid((rows + 3) / 4);
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(ln_modulate_k<bf16_t>, grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL(ln_modulate_k<float>, grid, dim3(256), 0, st, a);
+    if (dtype == S2V_BF16) {
+        S2V_LN_DISPATCH(bf16_t, a.D, hipLaunchKernelGGL((ln_modulate_k<bf16_t, NR>), grid, dim3(256), 0, st, a))
+    } else {
+        S2V_LN_DISPATCH(float, a.D, hipLaunchKernelGGL((ln_modulate_k<float, NR>), grid, dim3(256), 0, st, a))
+    }
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 // norm_final -> norm_out (AdaLayerNorm, shift first) on the video rows (cogvideox_transformer_3d.py:536-542)
-template <typename T>
+template <typename T, int NR>
 __global__ __launch_bounds__(256) void tail_norm_k(const TailNormArgs a) {
     const int lane = threadIdx.x & 63;
     const int idx = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (idx >= a.B * a.V) return;
     const int b = idx / a.V, vr = idx - b * a.V;
     const size_t xrow = (size_t)b * a.Ntok + a.row0 + vr;
-    float v[LN_MAX_FLOATS];
-    int nch;
-    row_load<T>((const T*)a.x + xrow * a.ldx, a.D, lane, v, nch);
-    row_layernorm<T>(v, a.D, lane, (const T*)a.w1, (const T*)a.b1, a.eps);
-    row_layernorm<T>(v, a.D, lane, (const T*)a.w2, (const T*)a.b2, a.eps);
+    float v[NR * Vec16<T>::N];
+    row_load<T, NR>((const T*)a.x + xrow * a.ldx, a.D, lane, v);
+    row_layernorm<T, NR>(v, a.D, lane, (const T*)a.w1, (const T*)a.b1, a.eps);
+    row_layernorm<T, NR>(v, a.D, lane, (const T*)a.w2, (const T*)a.b2, a.eps);
     const T* shift = (const T*)a.shift + (size_t)b * a.mod_stride;
     const T* scale = (const T*)a.scale + (size_t)b * a.mod_stride;
-    row_modulate_store<T>(v, a.D, lane, shift, scale, (T*)a.y + (size_t)idx * a.ldy);
+    row_modulate_store<T, NR>(v, a.D, lane, shift, scale, (T*)a.y + (size_t)idx * a.ldy);
 }
 int launch_tail_norm(const TailNormArgs& a, int dtype, hipStream_t st) {
     S2V_REQUIRE(a.D <= 4096 && a.D % 8 == 0, "tail_norm: D must be <= 4096 and a multiple of 8");
     dim3 grid((a.B * a.V + 3) / 4);
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(tail_norm_k<bf16_t>, grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL(tail_norm_k<float>, grid, dim3(256), 0, st, a);
+    if (dtype == S2V_BF16) {
+        S2V_LN_DISPATCH(bf16_t, a.D, hipLaunchKernelGGL((tail_norm_k<bf16_t, NR>), grid, dim3(256), 0, st, a))
+    } else {
+        S2V_LN_DISPATCH(float, a.D, hipLaunchKernelGGL((tail_norm_k<float, NR>), grid, dim3(256), 0, st, a))
+    }
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }

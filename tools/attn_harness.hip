@@ -18,6 +18,7 @@ extern "C" {
 int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype, int32_t impl, void* stream);
 int s2v_set_attn_variant(int v);
 int s2v_attn_debug_read(long long* out);
+int s2v_attn_debug_read_blocks(long long* out);
 const char* s2v_last_error(void);
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -155,6 +156,25 @@ int main(int argc, char** argv) {
                 const double nt = (N + 63) / 64;
                 printf("variant %d: cycles per KV tile per wave [softmax seg | vmcnt | barrier after S | matrix seg | barrier after M | loop total]\n", vars[vi]);
                 for (int w = 0; w < 8; ++w) printf("   wave %d: %7.1f %7.1f %7.1f %7.1f %7.1f | %7.1f\n", w, d[w * 8] / nt, d[w * 8 + 1] / nt, d[w * 8 + 2] / nt, d[w * 8 + 3] / nt, d[w * 8 + 4] / nt, d[w * 8 + 5] / nt);
+                // timeline of the launch: how many workgroups are resident over time (the tail of a 14.06-round grid)
+                static long long blk[2 * 8192];
+                s2v_attn_debug_read_blocks(blk);
+                const int nwg = std::min(8192, ((N + 255) / 256) * B * H);
+                long long t0 = blk[0], t1 = 0;
+                for (int i = 0; i < nwg; ++i) { t0 = std::min(t0, blk[2 * i]); t1 = std::max(t1, blk[2 * i + 1]); }
+                const double span = double(t1 - t0);
+                double busy = 0, mean_dur = 0;
+                for (int i = 0; i < nwg; ++i) { busy += double(blk[2 * i + 1] - blk[2 * i]); mean_dur += double(blk[2 * i + 1] - blk[2 * i]) / nwg; }
+                std::vector<long long> ends(nwg);
+                for (int i = 0; i < nwg; ++i) ends[i] = blk[2 * i + 1];
+                std::sort(ends.begin(), ends.end());
+                printf("   timeline (100 MHz ticks): span %.0f, mean workgroup %.0f, slot occupancy %.1f %% of 512 slots; the last 512 workgroups end between %.1f %% and 100 %% of the span; the last 32 after %.1f %%\n",
+                       span, mean_dur, 100.0 * busy / (span * 512.0), 100.0 * double(ends[nwg - 512] - t0) / span, 100.0 * double(ends[nwg - 32] - t0) / span);
+                for (int x = 0; x < 8; ++x) {
+                    long long e = 0; double dsum = 0; int cnt = 0;
+                    for (int i = x; i < nwg; i += 8) { e = std::max(e, blk[2 * i + 1]); dsum += double(blk[2 * i + 1] - blk[2 * i]); ++cnt; }
+                    printf("   xcd %d: last workgroup ends at %.1f %% of the span, mean workgroup %.0f ticks\n", x, 100.0 * double(e - t0) / span, dsum / cnt);
+                }
             }
             std::sort(ms[vi].begin(), ms[vi].end());
             const float med = ms[vi][ms[vi].size() / 2], mn = ms[vi][0];
