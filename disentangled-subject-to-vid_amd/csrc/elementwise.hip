@@ -189,24 +189,44 @@ int launch_tail_norm(const TailNormArgs& a, int dtype, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------
 // per-head LN(64) on q and k + RoPE (attention_processor.py:2060-2080, embeddings.py:759-778).
 // 8 lanes per 64-wide head vector (8 contiguous elements per lane); one thread-task = (row, q|k, head, octet)
+// Grid: x = row, y = 256-task slices of the row's 2 * H * 8 tasks (no division by the task count); the rotary tables of the row are
+// requested together with its q / k chunk (clamped address for text rows), so a thread pays ONE memory latency, not two.
 template <typename T>
 __global__ __launch_bounds__(256) void qk_norm_rope_k(const QkNormRopeArgs a) {
     const int D = a.H * 64;
-    const size_t tasks_per_row = (size_t)2 * a.H * 8;
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t row = gid / tasks_per_row;
-    if (row >= (size_t)a.B * a.Ntok) return;  // whole 8-lane groups exit together (tasks_per_row % 8 == 0)
-    const int t = (int)(gid - row * tasks_per_row);
-    const int which = t / (a.H * 8);  // 0 = q, 1 = k
-    const int hh = (t >> 3) % a.H;
+    const int row = blockIdx.x;
+    const int t = blockIdx.y * 256 + threadIdx.x;
+    if (t >= 2 * a.H * 8) return;  // whole 8-lane groups exit together
+    const int which = t >= a.H * 8;  // 0 = q, 1 = k
+    const int hh = (t >> 3) - which * a.H;
     const int oct = t & 7;
-    T* p = (T*)a.qkv + row * a.ld_qkv + which * D + hh * 64 + oct * 8;
-    float v[8];
+    T* p = (T*)a.qkv + (size_t)row * a.ld_qkv + which * D + hh * 64 + oct * 8;
+    const int r = row % a.Ntok;
+    const bool rope = a.cos != nullptr && r >= a.text_len;
+    const size_t tab = (size_t)(rope ? r - a.text_len : 0) * 64 + oct * 8;
+    float v[8], cs[8], sn[8], wv[8], bv[8];
     if constexpr (sizeof(T) == 2) {
         Vec16<T>::ld(p, v);
     } else {
         Vec16<T>::ld(p, v);
         Vec16<T>::ld(p + 4, v + 4);
+    }
+    if (a.cos != nullptr) {
+        Vec16<float>::ld(a.cos + tab, cs);
+        Vec16<float>::ld(a.cos + tab + 4, cs + 4);
+        Vec16<float>::ld(a.sin + tab, sn);
+        Vec16<float>::ld(a.sin + tab + 4, sn + 4);
+    }
+    const T* w = (const T*)(which ? a.nk_w : a.nq_w) + oct * 8;
+    const T* bb = (const T*)(which ? a.nk_b : a.nq_b) + oct * 8;
+    if constexpr (sizeof(T) == 2) {
+        Vec16<T>::ld(w, wv);
+        Vec16<T>::ld(bb, bv);
+    } else {
+        Vec16<T>::ld(w, wv);
+        Vec16<T>::ld(w + 4, wv + 4);
+        Vec16<T>::ld(bb, bv);
+        Vec16<T>::ld(bb + 4, bv + 4);
     }
     float s = 0.f;
 #pragma unroll
@@ -218,14 +238,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_k(const QkNormRopeArgs a) {
     for (int e = 0; e < 8; ++e) { const float d = v[e] - mean; q += d * d; }
     q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
     const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + a.eps);
-    const T* w = (const T*)(which ? a.nk_w : a.nq_w) + oct * 8;
-    const T* bb = (const T*)(which ? a.nk_b : a.nq_b) + oct * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = ET<T>::rnd((v[e] - mean) * rstd * ET<T>::ld(w + e) + ET<T>::ld(bb + e));
-    const int r = (int)(row % a.Ntok);
-    if (a.cos != nullptr && r >= a.text_len) {
-        const float* cs = a.cos + (size_t)(r - a.text_len) * 64 + oct * 8;
-        const float* sn = a.sin + (size_t)(r - a.text_len) * 64 + oct * 8;
+    for (int e = 0; e < 8; ++e) v[e] = ET<T>::rnd((v[e] - mean) * rstd * wv[e] + bv[e]);
+    if (rope) {
 #pragma unroll
         for (int e = 0; e < 8; e += 2) {
             const float x0 = v[e], x1 = v[e + 1];
@@ -273,8 +288,7 @@ __global__ __launch_bounds__(256) void v_transpose_k(const bf16_t* qkv, int ld_q
 }
 
 int launch_qk_norm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t st) {
-    const size_t total = (size_t)a.B * a.Ntok * 2 * a.H * 8;
-    dim3 grid((unsigned)((total + 255) / 256));
+    dim3 grid((unsigned)(a.B * a.Ntok), (unsigned)((2 * a.H * 8 + 255) / 256));
     if (dtype == S2V_BF16)
         hipLaunchKernelGGL(qk_norm_rope_k<bf16_t>, grid, dim3(256), 0, st, a);
     else
