@@ -535,17 +535,33 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st) {
     GemmArgs g{};
     g.A = c->Xn; g.lda = D; g.W = w.wqkv; g.ldw = D; g.bias = w.bqkv;
     g.C = c->QKV; g.ldc = 3 * D; g.M = (int)c->M; g.N = 3 * D; g.K = D;
+    // MFMA path: the per-head LayerNorm + rotary embedding of q and k run in the projection's epilogue (EPI_BIAS_QKNORM), on the
+    // rounded projection as the stand-alone kernel does; only the V^T production remains a pass of its own
+    const bool fused_qk = c->mfma && D % 64 == 0;
+    if (fused_qk) {
+        g.tok_per_batch = c->Ntok; g.text_len = c->T;
+        g.qk_w[0] = w.nq_w; g.qk_b[0] = w.nq_b; g.qk_w[1] = w.nk_w; g.qk_b[1] = w.nk_b;
+        g.qk_cos = c->have_rope ? c->rope_cos : nullptr; g.qk_sin = c->have_rope ? c->rope_sin : nullptr;
+        g.qk_D = D; g.qk_eps = 1e-6f;
+    }
     {
         ProfScope ps(c, PK_QKV, st);
-        if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS, w.q_qkv, w.s_qkv, st));
-        else S2V_TRY(linear(c, g, EPI_BIAS, st));
+        const int epi = fused_qk ? EPI_BIAS_QKNORM : EPI_BIAS;
+        if (c->fp8) S2V_TRY(linear_fp8(c, g, epi, w.q_qkv, w.s_qkv, st));
+        else S2V_TRY(linear(c, g, epi, st));
     }
-    QkNormRopeArgs q{};
-    q.qkv = c->QKV; q.ld_qkv = 3 * D; q.B = c->B; q.H = c->cfg.num_heads; q.Ntok = c->Ntok; q.text_len = c->T;
-    q.nq_w = w.nq_w; q.nq_b = w.nq_b; q.nk_w = w.nk_w; q.nk_b = w.nk_b; q.eps = 1e-6f;
-    q.cos = c->have_rope ? c->rope_cos : nullptr; q.sin = c->have_rope ? c->rope_sin : nullptr;
-    q.vt = c->mfma ? c->VT : nullptr; q.ntok_pad = c->ntok_pad;
-    { ProfScope ps(c, PK_QKNORM, st); S2V_TRY(launch_qk_norm_rope(q, c->dtype, st)); }
+    if (fused_qk) {
+        ProfScope ps(c, PK_QKNORM, st);
+        S2V_TRY(launch_v_transpose(c->QKV, 3 * D, c->B, c->cfg.num_heads, c->Ntok, c->VT, c->ntok_pad, st));
+    } else {
+        QkNormRopeArgs q{};
+        q.qkv = c->QKV; q.ld_qkv = 3 * D; q.B = c->B; q.H = c->cfg.num_heads; q.Ntok = c->Ntok; q.text_len = c->T;
+        q.nq_w = w.nq_w; q.nq_b = w.nq_b; q.nk_w = w.nk_w; q.nk_b = w.nk_b; q.eps = 1e-6f;
+        q.cos = c->have_rope ? c->rope_cos : nullptr; q.sin = c->have_rope ? c->rope_sin : nullptr;
+        q.vt = c->mfma ? c->VT : nullptr; q.ntok_pad = c->ntok_pad;
+        ProfScope ps(c, PK_QKNORM, st);
+        S2V_TRY(launch_qk_norm_rope(q, c->dtype, st));
+    }
     AttnArgs a{};
     a.qkv = c->QKV; a.ld_qkv = 3 * D; a.vt = c->VT; a.ntok_pad = c->ntok_pad; a.out = c->Xn; a.ld_out = D;
     a.B = c->B; a.H = c->cfg.num_heads; a.Ntok = c->Ntok; a.scale = 0.125f;

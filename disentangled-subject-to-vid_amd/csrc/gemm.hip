@@ -203,9 +203,25 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
     const int n = nw + c16 * 8;
     const bool n_ok = n < a.N;            // epi_vec_ok: N % 8 == 0, so a started 8-column group is whole
     const int nc = n_ok ? n : 0;          // loads stay in range (and unconditional: four rows' worth in flight at a time)
+    // EPI_BIAS_QKNORM: this wave's 64 columns are ONE head of q, k or v (nw % 64 == 0); 8 lanes hold a row of it
+    const bool qk_head = EPI == EPI_BIAS_QKNORM && nw < 2 * a.qk_D;
+    float qw[8], qb[8];
+    float inv_tok = 0.f;
+    if (EPI == EPI_BIAS_QKNORM) {
+        const int which = nw >= a.qk_D;
+        const u32x4 w4 = *(const u32x4*)((const bf16_t*)a.qk_w[which] + c16 * 8), b4 = *(const u32x4*)((const bf16_t*)a.qk_b[which] + c16 * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qw[2 * e] = __uint_as_float(w4[e] << 16); qw[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+            qb[2 * e] = __uint_as_float(b4[e] << 16); qb[2 * e + 1] = __uint_as_float(b4[e] & 0xffff0000u);
+        }
+        inv_tok = 1.0f / (float)a.tok_per_batch;
+    }
 #pragma unroll
     for (int it0 = 0; it0 < MB * 4; it0 += GRP) {
         u32x4 v[GRP], g[GRP], xo[GRP];
+        f32x4 cs[GRP][2], sn[GRP][2];
+        bool rope[GRP];
         int mrow[GRP];
 #pragma unroll
         for (int u = 0; u < GRP; ++u) {
@@ -213,6 +229,18 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
             mrow[u] = mw + row;
             v[u] = *(const u32x4*)(patch + row * 128 + ((c16 ^ (row & 7)) << 4));
             const int m = min(mrow[u], a.M - 1);
+            if (EPI == EPI_BIAS_QKNORM) {  // rotary tables of the row, requested with the read-back (clamped for text rows)
+                int b = (int)((float)m * inv_tok);  // m / tok_per_batch without the integer division (corrected below)
+                int r = m - b * a.tok_per_batch;
+                if (r < 0) r += a.tok_per_batch;
+                if (r >= a.tok_per_batch) r -= a.tok_per_batch;
+                rope[u] = qk_head && a.qk_cos != nullptr && r >= a.text_len;
+                const size_t tab = (size_t)(rope[u] ? r - a.text_len : 0) * 64 + c16 * 8;
+                if (qk_head && a.qk_cos != nullptr) {
+                    cs[u][0] = *(const f32x4*)(a.qk_cos + tab); cs[u][1] = *(const f32x4*)(a.qk_cos + tab + 4);
+                    sn[u][0] = *(const f32x4*)(a.qk_sin + tab); sn[u][1] = *(const f32x4*)(a.qk_sin + tab + 4);
+                }
+            }
             if (EPI == EPI_BIAS_GATE_RES) {
                 const int b = m / a.tok_per_batch;
                 const int r = m - b * a.tok_per_batch;
@@ -226,6 +254,34 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
 #pragma unroll
         for (int u = 0; u < GRP; ++u) {
             u32x4 o = v[u];
+            if (EPI == EPI_BIAS_QKNORM && qk_head) {  // qk_norm_rope_k's arithmetic on the rounded projection, lane = (row, octet)
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(v[u][e] << 16); x[2 * e + 1] = __uint_as_float(v[u][e] & 0xffff0000u); }
+                float s = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += x[e];
+                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+                const float mean = s * (1.0f / 64.0f);
+                float q = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = x[e] - mean; q += d * d; }
+                q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+                const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + a.qk_eps);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = bf2f(f2bf((x[e] - mean) * rstd * qw[e] + qb[e]));
+                if (rope[u]) {
+#pragma unroll
+                    for (int e = 0; e < 8; e += 2) {
+                        const float x0 = x[e], x1 = x[e + 1];
+                        const float c0 = cs[u][e >> 2][e & 3], c1 = cs[u][e >> 2][(e & 3) + 1], s0 = sn[u][e >> 2][e & 3], s1 = sn[u][e >> 2][(e & 3) + 1];
+                        x[e] = bf2f(f2bf(x0 * c0 + (-x1) * s0));
+                        x[e + 1] = bf2f(f2bf(x1 * c1 + x0 * s1));
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = pack2bf(x[2 * e], x[2 * e + 1]);
+            }
             if (EPI == EPI_BIAS_GATE_RES) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -1349,6 +1405,7 @@ int launch_gemm_fp8(const GemmArgs& a, int epi, hipStream_t st) {
         case EPI_BIAS: return launch_fp8_t<EPI_BIAS>(a, st);
         case EPI_BIAS_GELU: return launch_fp8_t<EPI_BIAS_GELU>(a, st);
         case EPI_BIAS_GATE_RES: return launch_fp8_t<EPI_BIAS_GATE_RES>(a, st);
+        case EPI_BIAS_QKNORM: return launch_fp8_t<EPI_BIAS_QKNORM>(a, st);
         default: return s2v_fail(__FILE__, __LINE__, "gemm_fp8: bad epilogue", -1);
     }
 }
@@ -1363,6 +1420,17 @@ static bool w_tile_ok(const GemmArgs& a) {
 int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     GemmArgs a = a0;
     a.ablate = g_gemm_ablate;
+    if (epi == EPI_BIAS_QKNORM) {  // only the vector epilogue of the 256- and 128-row kernels implements it
+        S2V_REQUIRE(!a.conv && epi_vec_ok(a, epi) && a.qk_D > 0 && a.qk_D % 64 == 0 && a.N == 3 * a.qk_D && a.tok_per_batch > 0 && a.qk_w[0] && a.qk_w[1] &&
+                        a.qk_b[0] && a.qk_b[1],
+                    "gemm_bf16: fused qk-norm needs the vector epilogue, N = 3 * qk_D and the LayerNorm parameters");
+        if (!(a.m_begin > 0) && !(w_tile_ok(a) && a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+            const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+            hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_QKNORM>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, st, a, tiles_m, tiles_n);
+            S2V_CHECK_HIP(hipGetLastError());
+            return 0;
+        }
+    }
     if (a.m_begin > 0) {  // row tail of a split GEMM: the 128 x 128 kernel on rows [m_begin, M)
         S2V_REQUIRE(!a.conv && a.K % BK == 0 && a.lda % 8 == 0 && a.ldw % 8 == 0, "gemm_bf16: bad tail launch");
         const int tiles_m = (a.M - a.m_begin + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
@@ -1373,6 +1441,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_GELU>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
             case EPI_BIAS_GATE_RES: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_GATE_RES>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
             case EPI_BIAS_ADD: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_ADD>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
+            case EPI_BIAS_QKNORM: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_QKNORM>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
         S2V_CHECK_HIP(hipGetLastError());
@@ -1392,6 +1461,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             case EPI_BIAS_GELU: return launch_pp64_t<EPI_BIAS_GELU>(a, st);
             case EPI_BIAS_GATE_RES: return launch_pp64_t<EPI_BIAS_GATE_RES>(a, st);
             case EPI_BIAS_ADD: return launch_pp64_t<EPI_BIAS_ADD>(a, st);
+            case EPI_BIAS_QKNORM: return launch_pp64_t<EPI_BIAS_QKNORM>(a, st);
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }
@@ -1433,6 +1503,9 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             break;
         case EPI_BIAS_ADD:
             hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_ADD>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            break;
+        case EPI_BIAS_QKNORM:
+            hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_QKNORM>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
             break;
         default:
             return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);

@@ -41,6 +41,11 @@ struct GemmArgs {
     // C = rnd(a_scale[m] * w_scale[n] * acc + bias) ... : per-token and per-output-channel fp32 scales (weights.py / api.hip)
     const float* a_scale;
     const float* w_scale;
+    // EPI_BIAS_QKNORM only: LayerNorm(64) weights / biases of q and k ([64] each), rotary tables [positions][64] fp32 (null: none),
+    // width of the q (= k = v) range, LayerNorm epsilon; tok_per_batch and text_len above give the position of a row
+    const void* qk_w[2]; const void* qk_b[2];
+    const float* qk_cos; const float* qk_sin;
+    int qk_D; float qk_eps;
 };
 // fp8 x fp8 -> bf16 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; the per-row scales above in the epilogue): the
 // 256 x 256 ping-pong schedule of gemm_bf16_pp64 on K-tiles of 128 bytes.  Plain mode only (no conv), K % 128 == 0, N_pad % 256 == 0.
@@ -48,6 +53,11 @@ int launch_gemm_fp8(const GemmArgs& a, int epi, hipStream_t st);
 // rows [M][K] of bf16 (ld elements apart) -> e4m3 bytes [M][K] + scale[m] = amax(row) / 448 (dynamic per-row quantisation)
 int launch_quant_rows_fp8(const void* src, int64_t ld, int64_t M, int K, void* dst, float* scale, hipStream_t st);
 enum { EPI_BIAS_ADD = 3 };
+// EPI_BIAS_QKNORM: the fused QKV projection.  C = rnd(acc + bias); then, on the 64-column heads of the q and k ranges (columns
+// < 2 * qk_D), the per-head LayerNorm(64) + affine and the rotary embedding of attention_processor.py:2060-2080 /
+// embeddings.py:759-778, with the same arithmetic and rounding points as qk_norm_rope_k (which it replaces on the MFMA path: one
+// pass over 2/3 of the QKV buffer less per layer).  Rows are tokens: r = m % tok_per_batch, rotary for r >= text_len.
+enum { EPI_BIAS_QKNORM = 4 };
 
 int launch_gemm_bf16(const GemmArgs& a, int epi, hipStream_t st);              // MFMA path, bf16 only
 int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st);  // any dtype, any shape
