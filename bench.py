@@ -103,8 +103,8 @@ def cpu_baseline(s2v, cfg, F, H, W, T, dev):
 
 
 # kernel names as rocprofv3 prints them (template arguments included)
-KERNEL_OF_CLASS = {"attention": "attn_pp_k<false>", "gemm_qkv": "gemm_bf16_pp64<0>", "gemm_ff1_gelu": "gemm_bf16_pp64<1>",
-                   "gemm_out": "gemm_bf16_pp64<2>", "gemm_ff2": "gemm_bf16_pp64<2>"}
+KERNEL_OF_CLASS = {"attention": "attn_pp_k<false>", "gemm_qkv": "gemm_bf16_pp64<4>", "gemm_ff1_gelu": "gemm_bf16_pp64<1>",
+                   "gemm_out": "gemm_bf16_pp64<2>", "gemm_ff2": "gemm_bf16_pp64<2>"}  # <4>: QKV with the fused q/k norm + rotary epilogue
 
 
 def pmc_traffic_bytes(kernel_class):
@@ -123,7 +123,7 @@ def pmc_traffic_bytes(kernel_class):
     def mean_kb(path):
         tot = cnt = 0.0
         for row in csv.reader(open(path)):
-            got = row[0].replace("void ", "").replace(", 0>", ">").replace(" ", "") if row else ""
+            got = row[0].replace("void ", "").replace(", 0, false>", ">").replace(", 0>", ">").replace(" ", "") if row else ""
             if got == name.replace(" ", ""):  # default template arguments and the return type are printed too
                 tot += float(row[2]) * float(row[1])
                 cnt += float(row[1])

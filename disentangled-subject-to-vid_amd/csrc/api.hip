@@ -528,6 +528,10 @@ extern "C" int s2v_set_conditioning(s2v_ctx* c, const void* text_dev, const void
 }
 
 // ---- one transformer block on the packed residual buffer X ------------------------------------------------
+#ifdef S2V_DIAG
+static int g_fused_qk = 1;
+extern "C" __attribute__((visibility("default"))) int s2v_set_fused_qk(int on) { g_fused_qk = on; return 0; }
+#endif
 static int run_attention(s2v_ctx* c, int l, hipStream_t st) {
     // Xn -> QKV -> (qk-norm, rope, V^T) -> attention -> Xn (reused as the attention output buffer)
     const LayerW& w = c->layers[l];
@@ -537,7 +541,11 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st) {
     g.C = c->QKV; g.ldc = 3 * D; g.M = (int)c->M; g.N = 3 * D; g.K = D;
     // MFMA path: the per-head LayerNorm + rotary embedding of q and k run in the projection's epilogue (EPI_BIAS_QKNORM), on the
     // rounded projection as the stand-alone kernel does; only the V^T production remains a pass of its own
+#ifdef S2V_DIAG
+    const bool fused_qk = c->mfma && D % 64 == 0 && g_fused_qk;  // A/B switch of the diagnostics build (tests/test_gpu_gemm_schedules.py)
+#else
     const bool fused_qk = c->mfma && D % 64 == 0;
+#endif
     if (fused_qk) {
         g.tok_per_batch = c->Ntok; g.text_len = c->T;
         g.qk_w[0] = w.nq_w; g.qk_b[0] = w.nq_b; g.qk_w[1] = w.nk_w; g.qk_b[1] = w.nk_b;

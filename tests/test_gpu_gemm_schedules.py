@@ -46,3 +46,53 @@ def test_pingpong_matches_ring_bitwise_and_is_repeatable(s2v, M, N, K, epi):
     rel = ((ref.float() - y).norm() / y.norm()).item()
     assert rel <= 1e-2, rel
 
+
+
+@pytest.mark.parametrize("epi", [0, 1])
+def test_four_wave_persistent_kernel_matches_pingpong(s2v, epi):
+    """gemm_q4 (diagnostics build only: persistent 4-wave kernel whose epilogue trickles through the next tile's K loop): 1536
+    output tiles = six per workgroup, so the in-loop epilogue, the tile hand-over and the final flush all run.  Bias goes through
+    the matrix pipe there (one more K step) and GELU is evaluated in other slots, so the comparison is to one bf16 ulp."""
+    L = s2v._lib
+    M, N, K = 8192, 12288, 2304
+    g = torch.Generator().manual_seed(7)
+    A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).bfloat16().to(DEV)
+    ref = run(L, A, W, b, M, N, K, epi, None).float()
+    out = run(L, A, W, b, M, N, K, epi, 8).float()
+    assert torch.isfinite(out).all()
+    bad = ((out - ref).abs() > 2.0 ** -7 * ref.abs().clamp_min(1.0)).sum().item()
+    assert bad == 0, f"{bad} elements differ by more than one bf16 ulp (max {(out - ref).abs().max().item()})"
+    assert (out != ref).float().mean().item() < 2e-2
+
+
+def test_fused_qk_norm_rope_epilogue_is_bit_identical_to_the_separate_kernel(s2v):
+    """EPI_BIAS_QKNORM (QKV projection + per-head LayerNorm + rotary embedding in the GEMM epilogue) against the plain projection
+    followed by qk_norm_rope_k: the diagnostics build can switch the fusion off, everything else being equal the two forwards must
+    agree bit for bit -- with rotary tables (5B-style) and without (2B-style), ragged token count, text rows in the middle of a tile."""
+    L = s2v._lib
+    diag = L.diag_lib()
+    prev = L._lib
+    L.lib()
+    try:
+        L._lib = diag  # engines created below bind the diagnostics library
+        for use_rope in (True, False):
+            cfg = s2v.tiny(use_rope=use_rope)
+            sd = s2v.weights.synthetic_state_dict(cfg, seed=11, parity=True)
+            outs = []
+            for fused in (1, 0):
+                diag.s2v_set_fused_qk(fused)
+                eng = s2v.S2VEngine(cfg, torch.bfloat16, DEV)
+                eng.load_state_dict(sd)
+                eng.set_geometry(2, 5, 3, 10, 14)
+                eng.prepare_tables(80, 112)
+                gq = torch.Generator().manual_seed(12)
+                eng.set_conditioning(torch.randn(2, 5, cfg.text_embed_dim, generator=gq), torch.randn(1, 1, 16, 10, 14, generator=gq))
+                outs.append(eng.forward(torch.randn(2, 3, 16, 10, 14, generator=gq), torch.tensor([300.0, 300.0])).clone())
+                torch.cuda.synchronize()
+            assert torch.isfinite(outs[0].float()).all()
+            assert torch.equal(outs[0], outs[1]), f"rope={use_rope}: max diff {(outs[0].float() - outs[1].float()).abs().max().item()}"
+    finally:
+        diag.s2v_set_fused_qk(1)
+        L._lib = prev
