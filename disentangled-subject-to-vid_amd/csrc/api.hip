@@ -72,6 +72,8 @@ struct s2v_ctx {
     int64_t ws_bytes = 0;
     char *X, *Xn, *QKV, *Hb, *VT, *e0, *e1, *patches, *tailn, *proj, *mod, *tmp_te, *emb, *noise_pred;
     float *rope_cos, *rope_sin;
+    float* rope_pk = nullptr;                // [positions][cos pair 0..31 | sin pair 0..31] when the tables repeat every value twice
+    bool rope_paired = false;                // (get_3d_rotary_pos_embed: repeat_interleave(2)); the fused QKV epilogue needs it
     char* pos_tab;
     bool have_rope = false, have_pos = false, have_cond = false;
     float* t_dev = nullptr;
@@ -427,6 +429,7 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     const int64_t ote = carve(((int64_t)B * D + (int64_t)B * c->temb) * E), oemb = carve((int64_t)B * c->temb * E);
     const int64_t onp = carve((int64_t)B * F * c->cfg.out_channels * H * W * E);
     const int64_t ocos = carve((int64_t)(c->R + c->V) * 64 * 4), osin = carve((int64_t)(c->R + c->V) * 64 * 4);
+    const int64_t opk = carve((int64_t)(c->R + c->V) * 64 * 4);
     const int64_t opos = carve((int64_t)c->V * D * E);
     const int64_t oaq = carve(c->fp8 ? c->Mpad * 4 * D : 0), oaqs = carve(c->fp8 ? c->Mpad * 4 : 0);
     c->ws_bytes = off;
@@ -436,7 +439,7 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     c->X = w + oX; c->Xn = w + oXn; c->QKV = w + oQKV; c->Hb = w + oH; c->VT = w + oVT; c->e0 = w + oe0; c->e1 = w + oe1;
     c->patches = w + opat; c->tailn = w + otail; c->proj = w + oproj; c->mod = w + omod; c->tmp_te = w + ote;
     c->emb = w + oemb; c->noise_pred = w + onp; c->rope_cos = (float*)(w + ocos); c->rope_sin = (float*)(w + osin);
-    c->pos_tab = w + opos;
+    c->pos_tab = w + opos; c->rope_pk = (float*)(w + opk); c->rope_paired = false;
     c->aq = w + oaq; c->aq_scale = (float*)(w + oaqs);
     return 0;
 }
@@ -448,6 +451,25 @@ extern "C" int s2v_set_rope(s2v_ctx* c, const float* cos_dev, const float* sin_d
     S2V_CHECK_HIP(hipMemcpyAsync(c->rope_cos, cos_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     S2V_CHECK_HIP(hipMemcpyAsync(c->rope_sin, sin_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     c->have_rope = true;
+    // The reference builds its tables with repeat_interleave(2) (embeddings.py:get_3d_rotary_pos_embed): cos[2k] == cos[2k+1].  When
+    // that holds (checked, once per geometry, on the host) a packed copy [position][32 cos | 32 sin] halves what the fused QKV
+    // epilogue has to fetch per row; tables without that structure take the stand-alone qk_norm_rope_k pass instead.
+    const size_t n = (size_t)(c->R + c->V) * 64;
+    std::vector<float> hc(n), hs(n), pk(n);
+    S2V_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    S2V_CHECK_HIP(hipMemcpy(hc.data(), c->rope_cos, bytes, hipMemcpyDeviceToHost));
+    S2V_CHECK_HIP(hipMemcpy(hs.data(), c->rope_sin, bytes, hipMemcpyDeviceToHost));
+    bool paired = true;
+    for (size_t i = 0; i < n && paired; i += 2) paired = hc[i] == hc[i + 1] && hs[i] == hs[i + 1];
+    c->rope_paired = paired;
+    if (paired) {
+        for (size_t p = 0; p < n / 64; ++p)
+            for (int k = 0; k < 32; ++k) {
+                pk[p * 64 + k] = hc[p * 64 + 2 * k];
+                pk[p * 64 + 32 + k] = hs[p * 64 + 2 * k];
+            }
+        S2V_CHECK_HIP(hipMemcpy(c->rope_pk, pk.data(), bytes, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -542,14 +564,14 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st) {
     // MFMA path: the per-head LayerNorm + rotary embedding of q and k run in the projection's epilogue (EPI_BIAS_QKNORM), on the
     // rounded projection as the stand-alone kernel does; only the V^T production remains a pass of its own
 #ifdef S2V_DIAG
-    const bool fused_qk = c->mfma && D % 64 == 0 && g_fused_qk;  // A/B switch of the diagnostics build (tests/test_gpu_gemm_schedules.py)
+    const bool fused_qk = c->mfma && D % 64 == 0 && (!c->have_rope || c->rope_paired) && g_fused_qk;  // A/B switch of the diagnostics build
 #else
-    const bool fused_qk = c->mfma && D % 64 == 0;
+    const bool fused_qk = c->mfma && D % 64 == 0 && (!c->have_rope || c->rope_paired);
 #endif
     if (fused_qk) {
         g.tok_per_batch = c->Ntok; g.text_len = c->T;
         g.qk_w[0] = w.nq_w; g.qk_b[0] = w.nq_b; g.qk_w[1] = w.nk_w; g.qk_b[1] = w.nk_b;
-        g.qk_cos = c->have_rope ? c->rope_cos : nullptr; g.qk_sin = c->have_rope ? c->rope_sin : nullptr;
+        g.qk_cs = c->have_rope ? c->rope_pk : nullptr;
         g.qk_D = D; g.qk_eps = 1e-6f;
     }
     {

@@ -168,6 +168,42 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
     // MB 32-row blocks: the patch holds MB*32 rows of 128 B (8 KiB for MB = 2, 16 KiB for MB = 4); all accumulator blocks are
     // written first, then read back, so the LDS round trip is paid once per wave tile
     const int fr = lane & 31, hi = lane >> 5;
+    const int c16 = lane & 7;
+    // EPI_BIAS_QKNORM: this wave's 64 columns are ONE head of q, k or v (nw % 64 == 0); 8 lanes hold a row of it.  The rotary
+    // values of a row group (4 cos + 4 sin per lane: the table stores every duplicated pair once) are requested one group AHEAD of
+    // their use -- fetched with the read-back they cost the epilogue a memory latency per group (0.16 ms per QKV launch at C3)
+    const bool qk_head = EPI == EPI_BIAS_QKNORM && nw < 2 * a.qk_D;
+    const bool qk_rot = qk_head && a.qk_cs != nullptr;
+    float qw[8], qb[8];
+    f32x4 rc[2][GRP], rs[2][GRP];
+    bool rope[2][GRP];
+    auto rot_load = [&](int it0, int buf) {
+        const float inv_tok = 1.0f / (float)a.tok_per_batch;
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            const int m = min(mw + (it0 + u) * 8 + (lane >> 3), a.M - 1);
+            int b = (int)((float)m * inv_tok);  // m / tok_per_batch without the integer division (corrected below)
+            int r = m - b * a.tok_per_batch;
+            if (r < 0) r += a.tok_per_batch;
+            if (r >= a.tok_per_batch) r -= a.tok_per_batch;
+            rope[buf][u] = qk_rot && r >= a.text_len;
+            const float* tp = a.qk_cs + (size_t)(rope[buf][u] ? r - a.text_len : 0) * 64 + c16 * 4;
+            if (qk_rot) {
+                rc[buf][u] = *(const f32x4*)tp;
+                rs[buf][u] = *(const f32x4*)(tp + 32);
+            }
+        }
+    };
+    if (EPI == EPI_BIAS_QKNORM) {
+        const int which = nw >= a.qk_D;
+        const u32x4 w4 = *(const u32x4*)((const bf16_t*)a.qk_w[which] + c16 * 8), b4 = *(const u32x4*)((const bf16_t*)a.qk_b[which] + c16 * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qw[2 * e] = __uint_as_float(w4[e] << 16); qw[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
+            qb[2 * e] = __uint_as_float(b4[e] << 16); qb[2 * e + 1] = __uint_as_float(b4[e] & 0xffff0000u);
+        }
+        rot_load(0, 0);
+    }
     // SC (fp8 operands): acc * a_scale[row] * w_scale[column] first -- the dequantisation of the per-token / per-channel scales
     float sa[MB];
 #pragma unroll
@@ -199,48 +235,21 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
             }
         }
     // same-wave LDS accesses are ordered; the compiler inserts the lgkmcnt wait for the dependent reads
-    const int c16 = lane & 7;
     const int n = nw + c16 * 8;
     const bool n_ok = n < a.N;            // epi_vec_ok: N % 8 == 0, so a started 8-column group is whole
     const int nc = n_ok ? n : 0;          // loads stay in range (and unconditional: four rows' worth in flight at a time)
-    // EPI_BIAS_QKNORM: this wave's 64 columns are ONE head of q, k or v (nw % 64 == 0); 8 lanes hold a row of it
-    const bool qk_head = EPI == EPI_BIAS_QKNORM && nw < 2 * a.qk_D;
-    float qw[8], qb[8];
-    float inv_tok = 0.f;
-    if (EPI == EPI_BIAS_QKNORM) {
-        const int which = nw >= a.qk_D;
-        const u32x4 w4 = *(const u32x4*)((const bf16_t*)a.qk_w[which] + c16 * 8), b4 = *(const u32x4*)((const bf16_t*)a.qk_b[which] + c16 * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            qw[2 * e] = __uint_as_float(w4[e] << 16); qw[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
-            qb[2 * e] = __uint_as_float(b4[e] << 16); qb[2 * e + 1] = __uint_as_float(b4[e] & 0xffff0000u);
-        }
-        inv_tok = 1.0f / (float)a.tok_per_batch;
-    }
 #pragma unroll
     for (int it0 = 0; it0 < MB * 4; it0 += GRP) {
         u32x4 v[GRP], g[GRP], xo[GRP];
-        f32x4 cs[GRP][2], sn[GRP][2];
-        bool rope[GRP];
         int mrow[GRP];
+        const int cur = (it0 / GRP) & 1;
+        if (EPI == EPI_BIAS_QKNORM && it0 + GRP < MB * 4) rot_load(it0 + GRP, cur ^ 1);
 #pragma unroll
         for (int u = 0; u < GRP; ++u) {
             const int row = (it0 + u) * 8 + (lane >> 3);
             mrow[u] = mw + row;
             v[u] = *(const u32x4*)(patch + row * 128 + ((c16 ^ (row & 7)) << 4));
             const int m = min(mrow[u], a.M - 1);
-            if (EPI == EPI_BIAS_QKNORM) {  // rotary tables of the row, requested with the read-back (clamped for text rows)
-                int b = (int)((float)m * inv_tok);  // m / tok_per_batch without the integer division (corrected below)
-                int r = m - b * a.tok_per_batch;
-                if (r < 0) r += a.tok_per_batch;
-                if (r >= a.tok_per_batch) r -= a.tok_per_batch;
-                rope[u] = qk_head && a.qk_cos != nullptr && r >= a.text_len;
-                const size_t tab = (size_t)(rope[u] ? r - a.text_len : 0) * 64 + c16 * 8;
-                if (qk_head && a.qk_cos != nullptr) {
-                    cs[u][0] = *(const f32x4*)(a.qk_cos + tab); cs[u][1] = *(const f32x4*)(a.qk_cos + tab + 4);
-                    sn[u][0] = *(const f32x4*)(a.qk_sin + tab); sn[u][1] = *(const f32x4*)(a.qk_sin + tab + 4);
-                }
-            }
             if (EPI == EPI_BIAS_GATE_RES) {
                 const int b = m / a.tok_per_batch;
                 const int r = m - b * a.tok_per_batch;
@@ -270,13 +279,13 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
                 const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + a.qk_eps);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = bf2f(f2bf((x[e] - mean) * rstd * qw[e] + qb[e]));
-                if (rope[u]) {
+                if (rope[cur][u]) {
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         const float x0 = x[e], x1 = x[e + 1];
-                        const float c0 = cs[u][e >> 2][e & 3], c1 = cs[u][e >> 2][(e & 3) + 1], s0 = sn[u][e >> 2][e & 3], s1 = sn[u][e >> 2][(e & 3) + 1];
-                        x[e] = bf2f(f2bf(x0 * c0 + (-x1) * s0));
-                        x[e + 1] = bf2f(f2bf(x1 * c1 + x0 * s1));
+                        const float cc = rc[cur][u][e >> 1], ss = rs[cur][u][e >> 1];  // cos / sin of the pair (e, e + 1)
+                        x[e] = bf2f(f2bf(x0 * cc + (-x1) * ss));
+                        x[e + 1] = bf2f(f2bf(x1 * cc + x0 * ss));
                     }
                 }
 #pragma unroll

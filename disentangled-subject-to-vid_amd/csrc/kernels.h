@@ -41,10 +41,11 @@ struct GemmArgs {
     // C = rnd(a_scale[m] * w_scale[n] * acc + bias) ... : per-token and per-output-channel fp32 scales (weights.py / api.hip)
     const float* a_scale;
     const float* w_scale;
-    // EPI_BIAS_QKNORM only: LayerNorm(64) weights / biases of q and k ([64] each), rotary tables [positions][64] fp32 (null: none),
-    // width of the q (= k = v) range, LayerNorm epsilon; tok_per_batch and text_len above give the position of a row
+    // EPI_BIAS_QKNORM only: LayerNorm(64) weights / biases of q and k ([64] each), the PAIRED rotary table [positions][32 cos | 32 sin]
+    // fp32 (value k = cos / sin of dims 2k and 2k+1; null: no rotary embedding), width of the q (= k = v) range, LayerNorm epsilon;
+    // tok_per_batch and text_len above give the position of a row
     const void* qk_w[2]; const void* qk_b[2];
-    const float* qk_cos; const float* qk_sin;
+    const float* qk_cs;
     int qk_D; float qk_eps;
 };
 // fp8 x fp8 -> bf16 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; the per-row scales above in the epilogue): the
