@@ -55,6 +55,7 @@ struct s2v_ctx {
     bool finalized = false;
     // weights
     int num_cus = 256;
+    int* attn_queue = nullptr;               // nine counters of the persistent attention launch (zero between launches)
     hipStream_t side = nullptr;              // fork/join stream for the row-tail launches of split GEMMs
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     char* arena = nullptr;
@@ -151,6 +152,10 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
         return s2v_fail(__FILE__, __LINE__, "s2v_create: stream / event creation failed", -2);
     }
     c->mfma = (cfg->dtype == S2V_DTYPE_BF16) && !cfg->force_simple;
+    if (hipMalloc((void**)&c->attn_queue, 64) != hipSuccess || hipMemset(c->attn_queue, 0, 64) != hipSuccess) {
+        delete c;
+        return s2v_fail(__FILE__, __LINE__, "s2v_create: attention queue allocation failed", -2);
+    }
     if (c->D > 4096) { delete c; return s2v_fail(__FILE__, __LINE__, "s2v_create: D > 4096 unsupported", -1); }
     if (c->temb % 8 != 0 || c->D % 8 != 0) { delete c; return s2v_fail(__FILE__, __LINE__, "bad dims", -1); }
 
@@ -283,6 +288,7 @@ extern "C" void s2v_destroy(s2v_ctx* c) {
     if (c->coef_dev) hipFree(c->coef_dev);
     if (c->t_dev) hipFree(c->t_dev);
     if (c->ws) hipFree(c->ws);
+    if (c->attn_queue) hipFree(c->attn_queue);
     if (c->arena) hipFree(c->arena);
     if (c->lora_tmp) hipFree(c->lora_tmp);
     delete c;
@@ -595,6 +601,7 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st) {
     AttnArgs a{};
     a.qkv = c->QKV; a.ld_qkv = 3 * D; a.vt = c->VT; a.ntok_pad = c->ntok_pad; a.out = c->Xn; a.ld_out = D;
     a.B = c->B; a.H = c->cfg.num_heads; a.Ntok = c->Ntok; a.scale = 0.125f;
+    a.queue = c->attn_queue; a.num_cus = c->num_cus;  // launches of one context are ordered on its stream: one queue suffices
     ProfScope ps(c, PK_ATTN, st);
     if (c->mfma) S2V_TRY(launch_attn_bf16(a, st));
     else S2V_TRY(launch_attn_simple(a, c->dtype, st));

@@ -239,24 +239,16 @@ __device__ long long g_attn_blk[2 * 8192];  // ACCT: s_memrealtime at entry / ex
 extern "C" __attribute__((visibility("default"))) int s2v_attn_debug_read_blocks(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_blk), sizeof(long long) * 2 * 8192) == hipSuccess ? 0 : -1; }
 extern "C" __attribute__((visibility("default"))) int s2v_attn_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
 #endif
+// one work item = the 256 query rows (wg % nqb) of (sample, head) wg / nqb; all eight waves enter and leave it together
 template <bool ACCT>
-__global__ __launch_bounds__(512, 2) void attn_pp_k(const AttnArgs a, int nqb) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 slots][K tile | VT tile]
+__device__ __forceinline__ void attn_pp_item(const AttnArgs& a, int nqb, int wg, char* smem) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
     const int fr = lane & 31, hi = lane >> 5;
-
 #ifdef S2V_DIAG
-    if (ACCT && tid == 0 && blockIdx.x < 8192) g_attn_blk[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (ACCT && tid == 0 && wg < 8192) g_attn_blk[2 * wg] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
-#ifdef S2V_DIAG
-    if (ACCT && tid == 0 && blockIdx.x < 8192) g_attn_blk[2 * blockIdx.x] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
-    // XCD-aware order: all q-blocks of one (b,h) run on one XCD so its K/V stay in that XCD's L2
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int qq = nwg >> 3, rr = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int wg = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + idx;
     const int bh = wg / nqb, qb = wg - bh * nqb;
     const int b = bh / a.H, h = bh - b * a.H;
     const int D = a.H * 64;
@@ -447,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_k(const AttnArgs a, int nqb) {
 #ifdef S2V_DIAG
     if (ACCT) {
         tacc[5] = now() - tl0;
-        if (blockIdx.x == 100 && lane == 0)
+        if (wg == 100 && lane == 0)
             for (int e = 0; e < 6; ++e) g_attn_dbg[wave * 8 + e] = tacc[e];
     }
 #endif
@@ -475,27 +467,101 @@ __global__ __launch_bounds__(512, 2) void attn_pp_k(const AttnArgs a, int nqb) {
         if (q_row < a.Ntok) *(u32x4*)(o + 8 * g) = v;
     }
 #ifdef S2V_DIAG
-    if (ACCT && tid == 0 && blockIdx.x < 8192) g_attn_blk[2 * blockIdx.x + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    if (ACCT && tid == 0 && wg < 8192) g_attn_blk[2 * wg + 1] = (long long)__builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// XCD-aware order of the work items: XCD x owns a contiguous range, so all q-blocks of one (sample, head) run on one XCD and its
+// K / V stay in that XCD's L2
+__device__ __forceinline__ void attn_xcd_range(int total, int x, int& first, int& cnt) {
+    const int q = total >> 3, r = total & 7;
+    first = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    cnt = q + (x < r ? 1 : 0);
+}
+// one workgroup per work item (the op-level entry point: no per-launch state)
+template <bool ACCT>
+__global__ __launch_bounds__(512, 2) void attn_pp_k(const AttnArgs a, int nqb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 slots][K tile | VT tile]
+    int first, cnt;
+    attn_xcd_range((int)gridDim.x, blockIdx.x & 7, first, cnt);
+    attn_pp_item<ACCT>(a, nqb, first + (int)(blockIdx.x >> 3), smem);
+}
+// PERSISTENT form (the engine's launches): one workgroup per CU pulls items from its XCD's queue and, when that is empty, from the
+// other XCDs' queues.  The hardware hands every XCD exactly 1/8 of a grid, but the XCDs of one launch run a few percent apart in
+// clock: with static shares the launch ended 95-100 % apart per XCD plus a last round of 32 items on 256 slots (4.6 % of the
+// slot-time idle, tools/attn_harness timeline); pulled work ends within one item.  queue[0..7]: next item of XCD x, queue[8]:
+// workgroups done -- the last one to leave zeroes the nine counters for the next launch (they must be zero at the first).
+template <bool ACCT>
+__global__ __launch_bounds__(512, 2) void attn_pp_persist_k(const AttnArgs a, int nqb, int total, int* __restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_item;
+    const int xcd = blockIdx.x & 7;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int wg = -1;
+            for (int k = 0; k < 8 && wg < 0; ++k) {
+                const int y = (xcd + k) & 7;
+                int first, cnt;
+                attn_xcd_range(total, y, first, cnt);
+                if (__hip_atomic_load(&queue[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cnt) continue;  // drained: do not hammer it
+                const int i = atomicAdd(&queue[y], 1);
+                if (i < cnt) wg = first + i;
+            }
+            s_item = wg;
+        }
+        __syncthreads();  // also fences the previous item's LDS traffic from the next item's prologue
+        const int wg = s_item;
+        __syncthreads();
+        if (wg < 0) break;
+        attn_pp_item<ACCT>(a, nqb, wg, smem);
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&queue[8], 1) == (int)gridDim.x - 1) {
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(&queue[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+        }
+    }
 }
 
 #ifdef S2V_DIAG
 int g_attn_variant = 0;  // 0 = product kernel, 1 = product kernel with stall accounting, 2 = round-1 lock-step kernel (A/B reference)
 extern "C" __attribute__((visibility("default"))) int s2v_set_attn_variant(int v) { g_attn_variant = v; return 0; }
+static int* g_attn_queue = nullptr;  // harness: a queue for op-level launches (variants 4, 5 = persistent product / accounting kernel)
+static int g_attn_ncu = 0;
+extern "C" __attribute__((visibility("default"))) int s2v_set_attn_queue(int* q, int ncu) { g_attn_queue = q; g_attn_ncu = ncu; return 0; }
 #endif
 
-int launch_attn_bf16(const AttnArgs& a, hipStream_t st) {
+int launch_attn_bf16(const AttnArgs& a_in, hipStream_t st) {
+    AttnArgs a = a_in;
     S2V_REQUIRE(a.vt != nullptr, "attn_bf16: V^T buffer missing");
     S2V_REQUIRE(a.ld_qkv % 8 == 0 && a.ntok_pad % 64 == 0, "attn_bf16: bad leading dims");
     S2V_REQUIRE(a.ntok_pad >= ((a.Ntok + 63) / 64) * 64, "attn_bf16: ntok_pad too small");
     const int nqb8 = (a.Ntok + 255) / 256;  // eight waves x 32 query rows per block
-    const dim3 g8(nqb8 * a.B * a.H), b8(512);
+    const int total = nqb8 * a.B * a.H;
+    const dim3 g8(total), b8(512);
     const void* fn = (const void*)attn_pp_k<false>;
     size_t lds = 65536;
 #ifdef S2V_DIAG
-    if (g_attn_variant == 1) fn = (const void*)attn_pp_k<true>;
-    if (g_attn_variant == 2) { fn = (const void*)attn_bf16_k<0, 8>; lds = 4 * ATT_TILE_BYTES; }
+    if ((g_attn_variant == 4 || g_attn_variant == 5) && !a.queue) { a.queue = g_attn_queue; a.num_cus = g_attn_ncu; }
 #endif
+    bool persist = a.queue != nullptr && total > 2 * a.num_cus && a.num_cus >= 8;
+#ifdef S2V_DIAG
+    if (g_attn_variant == 1 || g_attn_variant == 5) fn = (const void*)attn_pp_k<true>;
+    if (g_attn_variant == 2) { fn = (const void*)attn_bf16_k<0, 8>; lds = 4 * ATT_TILE_BYTES; persist = false; }
+    if (g_attn_variant == 3) persist = false;  // the one-workgroup-per-item launch of the product kernel
+#endif
+    if (persist) {
+        fn = (const void*)attn_pp_persist_k<false>;
+#ifdef S2V_DIAG
+        if (g_attn_variant == 1 || g_attn_variant == 5) fn = (const void*)attn_pp_persist_k<true>;
+#endif
+        S2V_TRY(ensure_lds_attr(fn, 65536));
+        int* queue = a.queue;
+        void* args[] = {(void*)&a, (void*)&nqb8, (void*)&total, (void*)&queue};
+        S2V_CHECK_HIP(hipLaunchKernel(fn, dim3((a.num_cus / 8) * 8), b8, args, lds, st));
+        return 0;
+    }
     S2V_TRY(ensure_lds_attr(fn, 65536));
     void* args[] = {(void*)&a, (void*)&nqb8};
     S2V_CHECK_HIP(hipLaunchKernel(fn, g8, b8, args, lds, st));

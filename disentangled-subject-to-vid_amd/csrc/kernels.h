@@ -76,6 +76,9 @@ struct AttnArgs {
     void* out; int ld_out;
     int B, H, Ntok;
     float scale;               // 1/sqrt(64)
+    // bf16 path, optional: nine zero-initialised ints owned by the caller (one set per concurrently running launch) and the CU count
+    // -> the persistent, work-pulling launch (attention.hip: attn_pp_persist_k); null -> one workgroup per q-block
+    int* queue; int num_cus;
 };
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st);
 int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st);

@@ -1,5 +1,6 @@
 // Stand-alone A/B harness for the attention kernels of libs2v_hip_diag.so (no torch: starts in a second on a fresh GPU box).
-//   variants: 0 = product kernel (attn_pp_k), 1 = the same with stall accounting, 2 = round-1 lock-step kernel
+//   variants: 0 = product kernel (attn_pp_k), 1 = the same with stall accounting, 2 = round-1 lock-step kernel,
+//             4 = product kernel in its persistent, work-pulling launch (what the engine runs), 5 = 4 with accounting
 //   checks: every variant against attn_simple_k (fp32 math on the same bf16 inputs) on small / ragged shapes, with rare
 //           outliers and with a block of keys whose scores jump by ~+40 at a late tile (forces the deferred-maximum slow
 //           path after O and l have accumulated), and against the first variant at full size;
@@ -19,6 +20,7 @@ int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, in
 int s2v_set_attn_variant(int v);
 int s2v_attn_debug_read(long long* out);
 int s2v_attn_debug_read_blocks(long long* out);
+int s2v_set_attn_queue(int* q, int ncu);
 const char* s2v_last_error(void);
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -66,6 +68,15 @@ static Bufs make(int B, int H, int N, float scale, float spike) {
 }
 static void release(Bufs& b) { CK(hipFree(b.qkv)); CK(hipFree(b.vt)); CK(hipFree(b.out)); }
 static void run(const Bufs& b, int variant, int impl = 0) {
+    static int* queue = nullptr;  // variants 4 / 5: the persistent, work-pulling launch (product / accounting kernel)
+    if (!queue) {
+        int dev = 0, ncu = 0;
+        CK(hipGetDevice(&dev));
+        CK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+        CK(hipMalloc((void**)&queue, 64));
+        CK(hipMemset(queue, 0, 64));
+        s2v_set_attn_queue(queue, ncu);
+    }
     s2v_set_attn_variant(variant);
     S2(s2v_op_attention(b.qkv, b.vt, b.out, b.B, b.H, b.N, 1, impl, nullptr));
 }
@@ -150,7 +161,7 @@ int main(int argc, char** argv) {
                 ms[vi].push_back(t / 3);
             }
         for (size_t vi = 0; vi < vars.size(); ++vi) {
-            if (vars[vi] == 1) {  // stall accounting
+            if (vars[vi] == 1 || vars[vi] == 5) {  // stall accounting
                 run(b, vars[vi]); CK(hipDeviceSynchronize());
                 long long d[64]; s2v_attn_debug_read(d);
                 const double nt = (N + 63) / 64;
