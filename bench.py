@@ -103,7 +103,7 @@ def cpu_baseline(s2v, cfg, F, H, W, T, dev):
 
 
 # kernel names as rocprofv3 prints them (template arguments included)
-KERNEL_OF_CLASS = {"attention": "attn_pp_k<false>", "gemm_qkv": "gemm_bf16_pp64<4>", "gemm_ff1_gelu": "gemm_bf16_pp64<1>",
+KERNEL_OF_CLASS = {"attention": "attn_pp_persist_k<false>", "gemm_qkv": "gemm_bf16_pp64<4>", "gemm_ff1_gelu": "gemm_bf16_pp64<1>",
                    "gemm_out": "gemm_bf16_pp64<2>", "gemm_ff2": "gemm_bf16_pp64<2>"}  # <4>: QKV with the fused q/k norm + rotary epilogue
 
 
