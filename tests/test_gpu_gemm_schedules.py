@@ -96,3 +96,39 @@ def test_fused_qk_norm_rope_epilogue_is_bit_identical_to_the_separate_kernel(s2v
     finally:
         diag.s2v_set_fused_qk(1)
         L._lib = prev
+
+
+def test_persistent_attention_launch_is_bit_identical_to_one_workgroup_per_q_block(s2v):
+    """the engine launches attention as a persistent, work-pulling grid (one workgroup per CU, per-XCD queues with stealing, counters
+    that reset themselves); the diagnostics build can force the one-workgroup-per-q-block launch.  5B width, the full 19126 tokens
+    (7200 work items on 256 CUs), two layers, two consecutive forwards (the second one finds the counters the first one left)."""
+    L = s2v._lib
+    diag = L.diag_lib()
+    prev = L._lib
+    L.lib()
+    try:
+        L._lib = diag
+        cfg = s2v.cogvideox_5b()
+        cfg.num_layers = 2
+        sd = s2v.weights.synthetic_state_dict(cfg, seed=3, device=DEV, parity=True)
+        eng = s2v.S2VEngine(cfg, torch.bfloat16, DEV)
+        eng.load_state_dict(sd)
+        del sd
+        F, H, W, T = 13, 60, 90, 226
+        g = torch.Generator(device=DEV).manual_seed(4)
+        eng.set_geometry(2, T, F, H, W)
+        eng.prepare_tables(480, 720)
+        eng.set_conditioning(torch.randn(2, T, 4096, generator=g, device=DEV), torch.randn(1, 1, 16, H, W, generator=g, device=DEV) * 0.7)
+        lat = torch.randn(1, F, 16, H, W, generator=g, device=DEV).bfloat16()
+        ts = torch.tensor([500.0, 500.0])
+        outs = []
+        for variant in (0, 0, 3):
+            diag.s2v_set_attn_variant(variant)
+            outs.append(eng.forward(lat, ts, shared_latent=True).clone())
+            torch.cuda.synchronize()
+        assert torch.isfinite(outs[0].float()).all()
+        assert torch.equal(outs[0], outs[1]), "second persistent launch differs: the queue was not reset"
+        assert torch.equal(outs[0], outs[2]), "persistent launch differs from the per-q-block launch"
+    finally:
+        diag.s2v_set_attn_variant(0)
+        L._lib = prev
