@@ -91,7 +91,10 @@ S2V_API int s2v_weight_arena(s2v_ctx* ctx, void** dev_ptr, int64_t* bytes);
 S2V_API int s2v_set_geometry(s2v_ctx* ctx, int32_t B, int32_t T, int32_t F, int32_t H, int32_t W);
 
 /* RoPE tables, fp32 [R + V, 64] (reference rows first): cos/sin as produced by
- * get_3d_rotary_pos_embed (embeddings.py:505-570) and sliced in custom_cogvideox_pipe.py:223-235. */
+ * get_3d_rotary_pos_embed (embeddings.py:505-570) and sliced in custom_cogvideox_pipe.py:223-235.
+ * A setup call: it synchronises `stream` and inspects the tables on the host once per geometry -- tables that repeat every value
+ * twice (repeat_interleave(2), what the reference builds) are also kept in a packed form that lets the QKV projection apply the
+ * rotary embedding in its epilogue; any other table is honoured through the separate q/k pass. */
 S2V_API int s2v_set_rope(s2v_ctx* ctx, const float* cos_dev, const float* sin_dev, s2v_stream stream);
 /* 2B only: additive 3-D sincos table for the video tokens, model dtype [V, D] (embeddings.py:380-401,440-446). */
 S2V_API int s2v_set_pos_embed(s2v_ctx* ctx, const void* table_dev, s2v_stream stream);
