@@ -369,3 +369,32 @@ def test_lora_adaln_scope_intended_vs_oracle(s2v, dt_name):
     torch.cuda.synchronize()
     for a_, b_, nm in zip(got, eb, ("video", "text", "ref")):
         assert_close(a_, b_, dt_name, "intended scope, block seam " + nm)
+
+
+@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+def test_rotary_tables_without_the_pair_structure_take_the_separate_pass(s2v, dt_name):
+    """the fused QKV epilogue needs tables that repeat every value twice (what get_3d_rotary_pos_embed builds); any other table must
+    still be honoured -- through qk_norm_rope_k.  Tables with independent values per dim, against the oracle on the same tables."""
+    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    cfg = s2v.tiny(use_rope=True, heads=2, layers=2, text_dim=64, temb=64)
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=21, parity=True)
+    g = torch.Generator().manual_seed(22)
+    B, F, C, H, W, T = 2, 2, 16, 12, 20, 5
+    lat = torch.randn(B, F, C, H, W, generator=g).to(dt)
+    text = torch.randn(B, T, 64, generator=g).to(dt)
+    ref = (torch.randn(1, 1, C, H, W, generator=g) * 0.7).to(dt)
+    ts = torch.tensor([400, 400])
+    R = (H // 2) * (W // 2)
+    ang = torch.rand(R * (F + 1), 64, generator=g) * 6.28
+    cos, sin = torch.cos(ang), torch.sin(ang)          # no two neighbouring dims share an angle
+    ref_rope, rope = (cos[:R], sin[:R]), (cos[R:], sin[R:])
+    ocfg = dict(num_heads=2, num_layers=2, use_rope=True, norm_eps=1e-5)
+    with torch.no_grad():
+        exp = tr.transformer_forward({k: v.to(dt) for k, v in sd.items()}, ocfg, lat, text, ref, ts, rope, ref_rope)
+    m = s2v.HipCogVideoXTransformer3DModel(cfg, dt, DEV)
+    m.load_state_dict(sd)
+    kw = dict(image_rotary_emb=tuple(x.to(DEV) for x in rope), ref_image_rotary_emb=tuple(x.to(DEV) for x in ref_rope))
+    y = m(hidden_states=lat.to(DEV), encoder_hidden_states=text.to(DEV), ref_img_states=ref.to(DEV), timestep=ts.to(DEV),
+          return_dict=False, eval=True, **kw)[0]
+    torch.cuda.synchronize()
+    assert_close(y, exp, dt_name, "unpaired rotary tables")
