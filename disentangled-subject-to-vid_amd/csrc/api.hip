@@ -519,9 +519,10 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
 }
 
 // weight_format 1: quantise the activation rows (per token, dynamic) and run the fp8 GEMM against the e4m3 weight copy
-static int linear_fp8(s2v_ctx* c, const GemmArgs& g0, int epi, const char* wq, const float* wscale, hipStream_t st) {
+// prequant: the producer (ln_modulate_k) already left the e4m3 image and the row scales of A in c->aq / c->aq_scale
+static int linear_fp8(s2v_ctx* c, const GemmArgs& g0, int epi, const char* wq, const float* wscale, hipStream_t st, bool prequant = false) {
     GemmArgs g = g0;
-    S2V_TRY(launch_quant_rows_fp8(g.A, g.lda, g.M, g.K, c->aq, c->aq_scale, st));
+    if (!prequant) S2V_TRY(launch_quant_rows_fp8(g.A, g.lda, g.M, g.K, c->aq, c->aq_scale, st));
     g.A = c->aq; g.lda = g.K; g.W = wq; g.ldw = g.K;
     g.a_scale = c->aq_scale; g.w_scale = wscale;
     g.a_rows_padded = (int)rup(g.M, 256);
@@ -557,10 +558,12 @@ extern "C" int s2v_set_conditioning(s2v_ctx* c, const void* text_dev, const void
 
 // ---- one transformer block on the packed residual buffer X ------------------------------------------------
 #ifdef S2V_DIAG
+static int g_fused_q8 = 1;
+extern "C" __attribute__((visibility("default"))) int s2v_set_fused_q8(int on) { g_fused_q8 = on; return 0; }
 static int g_fused_qk = 1;
 extern "C" __attribute__((visibility("default"))) int s2v_set_fused_qk(int on) { g_fused_qk = on; return 0; }
 #endif
-static int run_attention(s2v_ctx* c, int l, hipStream_t st) {
+static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = false) {
     // Xn -> QKV -> (qk-norm, rope, V^T) -> attention -> Xn (reused as the attention output buffer)
     const LayerW& w = c->layers[l];
     const int D = c->D;
@@ -583,7 +586,7 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st) {
     {
         ProfScope ps(c, PK_QKV, st);
         const int epi = fused_qk ? EPI_BIAS_QKNORM : EPI_BIAS;
-        if (c->fp8) S2V_TRY(linear_fp8(c, g, epi, w.q_qkv, w.s_qkv, st));
+        if (c->fp8) S2V_TRY(linear_fp8(c, g, epi, w.q_qkv, w.s_qkv, st, prequant));
         else S2V_TRY(linear(c, g, epi, st));
     }
     if (fused_qk) {
@@ -621,13 +624,19 @@ static int run_block(s2v_ctx* c, int l, const char* mod_base /* [B][mod_stride] 
         n.shift_vid = mb; n.scale_vid = mb + D * E; n.shift_txt = mb + 3 * D * E; n.scale_txt = mb + 4 * D * E;
         n.mod_stride = (int)mod_stride; n.B = c->B; n.Ntok = c->Ntok; n.text_len = c->T; n.D = D;
         if (c->mc == 9) { n.shift_ref = mb + 6 * D * E; n.scale_ref = mb + 7 * D * E; n.ref_len = c->R; }
+        // fp8 linears: the LayerNorm output feeds exactly one projection (QKV / FF1), so it is quantised where it is produced
+        bool prequant = c->fp8;
+#ifdef S2V_DIAG
+        prequant = prequant && g_fused_q8;
+#endif
+        if (prequant) { n.q8 = c->aq; n.q8_scale = c->aq_scale; }
         { ProfScope ps(c, PK_LNMOD, st); S2V_TRY(launch_ln_modulate(n, c->dtype, st)); }
         GemmArgs g{};
         g.X = c->X; g.ldx = D; g.gate_vid = mb + 2 * D * E; g.gate_txt = mb + 5 * D * E; g.gate_stride = (int)mod_stride;
         g.tok_per_batch = c->Ntok; g.text_len = c->T; g.M = (int)c->M; g.N = D;
         if (c->mc == 9) { g.gate_ref = mb + 8 * D * E; g.ref_len = c->R; }
         if (half == 0) {
-            S2V_TRY(run_attention(c, l, st));
+            S2V_TRY(run_attention(c, l, st, prequant));
             g.A = c->Xn; g.lda = D; g.W = w.wo; g.ldw = D; g.bias = w.bo; g.K = D;
             ProfScope ps(c, PK_OUT, st);
             if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS_GATE_RES, w.q_o, w.s_o, st));
@@ -638,7 +647,7 @@ static int run_block(s2v_ctx* c, int l, const char* mod_base /* [B][mod_stride] 
             f.M = (int)c->M; f.N = 4 * D; f.K = D;
             {
                 ProfScope ps(c, PK_FF1, st);
-                if (c->fp8) S2V_TRY(linear_fp8(c, f, EPI_BIAS_GELU, w.q_1, w.s_1, st));
+                if (c->fp8) S2V_TRY(linear_fp8(c, f, EPI_BIAS_GELU, w.q_1, w.s_1, st, prequant));
                 else S2V_TRY(linear(c, f, EPI_BIAS_GELU, st));
             }
             g.A = c->Hb; g.lda = 4 * D; g.W = w.w2; g.ldw = 4 * D; g.bias = w.b2; g.K = 4 * D;

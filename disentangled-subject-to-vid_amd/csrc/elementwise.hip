@@ -109,6 +109,45 @@ __device__ __forceinline__ void row_modulate_store(float* v, int D, int lane, co
         if (ok) Vec16<T>::st(y + c * VN, o);
     }
 }
+// the same modulation, then per-row e4m3 quantisation of the bf16-rounded result instead of the bf16 store (bf16 rows only): the
+// arithmetic of quant_rows_fp8_k on values that never leave the registers
+template <int NR>
+__device__ __forceinline__ void row_modulate_quant_store(float* v, int D, int lane, const bf16_t* shift, const bf16_t* scale, unsigned char* q,
+                                                         float* qscale) {
+    const int chunks = D / 8;
+    float amax = 0.f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int c = lane + 64 * i;
+        const bool ok = c < chunks;
+        const int cc = ok ? c : 0;
+        float sc[8], sh[8];
+        Vec16<bf16_t>::ld(scale + cc * 8, sc);
+        Vec16<bf16_t>::ld(shift + cc * 8, sh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float s1 = ET<bf16_t>::rnd(1.0f + sc[e]);
+            const float p = ET<bf16_t>::rnd(v[i * 8 + e] * s1);
+            const float o = ok ? ET<bf16_t>::rnd(p + sh[e]) : 0.f;  // the value the bf16 store would have held
+            v[i * 8 + e] = o;
+            amax = fmaxf(amax, fabsf(o));
+        }
+    }
+    amax = wave_max(amax);
+    const float sc = amax > 0.f ? amax * (1.0f / 448.0f) : 1.0f;
+    const float inv = 1.0f / sc;
+    if (lane == 0) *qscale = sc;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        const int c = lane + 64 * i;
+        int w0 = 0, w1 = 0;
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i * 8 + 0] * inv, v[i * 8 + 1] * inv, w0, false);
+        w0 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i * 8 + 2] * inv, v[i * 8 + 3] * inv, w0, true);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i * 8 + 4] * inv, v[i * 8 + 5] * inv, w1, false);
+        w1 = __builtin_amdgcn_cvt_pk_fp8_f32(v[i * 8 + 6] * inv, v[i * 8 + 7] * inv, w1, true);
+        if (c < chunks) *(u32x2*)(q + c * 8) = u32x2{(unsigned)w0, (unsigned)w1};
+    }
+}
 // rounds needed for D elements of T, rounded up to an instantiated count
 template <typename T> static int ln_rounds(int D) {
     const int need = (D / Vec16<T>::N + 63) / 64;
@@ -143,10 +182,17 @@ __global__ __launch_bounds__(256) void ln_modulate_k(const LnModArgs a) {
     const bool ref = a.shift_ref != nullptr && !txt && r < a.text_len + a.ref_len;
     const T* shift = (const T*)(txt ? a.shift_txt : ref ? a.shift_ref : a.shift_vid) + (size_t)b * a.mod_stride;
     const T* scale = (const T*)(txt ? a.scale_txt : ref ? a.scale_ref : a.scale_vid) + (size_t)b * a.mod_stride;
+    if constexpr (sizeof(T) == 2) {
+        if (a.q8 != nullptr) {
+            row_modulate_quant_store<NR>(v, a.D, lane, shift, scale, (unsigned char*)a.q8 + (size_t)row * a.D, a.q8_scale + row);
+            return;
+        }
+    }
     row_modulate_store<T, NR>(v, a.D, lane, shift, scale, (T*)a.y + (size_t)row * a.ldy);
 }
 int launch_ln_modulate(const LnModArgs& a, int dtype, hipStream_t st) {
     S2V_REQUIRE(a.D <= 4096 && a.D % 8 == 0, "ln_modulate: D must be <= 4096 and a multiple of 8");
+    S2V_REQUIRE(a.q8 == nullptr || (dtype == S2V_BF16 && a.q8_scale != nullptr), "ln_modulate: the fp8 output needs bf16 rows and a scale vector");
     const int rows = a.B * a.Ntok;
     dim3 grid((rows + 3) / 4);
     if (dtype == S2V_BF16) {

@@ -92,6 +92,10 @@ struct LnModArgs {
     const void* shift_vid; const void* scale_vid; const void* shift_txt; const void* scale_txt; int mod_stride;
     int B, Ntok, text_len, D;
     const void* shift_ref; const void* scale_ref; int ref_len;  // optional set for rows [text_len, text_len + ref_len); null: vid
+    // fp8 linears (bf16 storage only): when q8 is set the modulated row is NOT stored as bf16 but quantised on the spot exactly as
+    // quant_rows_fp8_k would quantise its bf16 image -- e4m3 bytes [row][D] and scale[row] = amax / 448 -- for the projection that
+    // consumes it (one read + one write pass over the activations less per LayerNorm)
+    void* q8; float* q8_scale;
 };
 int launch_ln_modulate(const LnModArgs& a, int dtype, hipStream_t st);
 

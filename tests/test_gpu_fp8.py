@@ -137,3 +137,34 @@ def test_fp8_engine_full_tokens_properties_and_closeness(s2v):
             eng.denoise_step(x, float(t), sch.coef(t, torch.bfloat16, 6.0), use_graph=graph)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+def test_fp8_quantisation_fused_into_layernorm_is_bit_identical_to_the_separate_pass(s2v):
+    """under weight_format = "fp8" ln_modulate_k writes the e4m3 image + row scales of its output itself (the operand of the QKV /
+    FF1 projection) instead of bf16 rows that quant_rows_fp8_k would re-read; the diagnostics build can switch that off: same bytes,
+    so the same forward, bit for bit (ragged token count: the masked lanes of a row must not reach the amax)"""
+    import copy
+
+    L = s2v._lib
+    diag = L.diag_lib()
+    prev = L._lib
+    L.lib()
+    try:
+        L._lib = diag
+        cfg = s2v.tiny(use_rope=True, heads=4, layers=2, text_dim=128, temb=64)
+        cfg.max_text_seq_length = 7
+        cfg.weight_format = "fp8"
+        sd = s2v.weights.synthetic_state_dict(cfg, seed=5, parity=True)
+        g = torch.Generator().manual_seed(18)
+        lat = torch.randn(1, 3, 16, 18, 22, generator=g).bfloat16()
+        text = torch.randn(2, 7, 128, generator=g).bfloat16()
+        ref = (torch.randn(1, 1, 16, 18, 22, generator=g) * 0.7).bfloat16()
+        outs = []
+        for fused in (1, 0):
+            diag.s2v_set_fused_q8(fused)
+            outs.append(_run_engine(s2v, copy.copy(cfg), sd, lat, text, ref, 300.0)[1].clone())
+        assert torch.isfinite(outs[0].float()).all()
+        assert torch.equal(outs[0], outs[1]), (outs[0].float() - outs[1].float()).abs().max().item()
+    finally:
+        diag.s2v_set_fused_q8(1)
+        L._lib = prev
