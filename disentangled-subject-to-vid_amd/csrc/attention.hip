@@ -1,7 +1,9 @@
 // Joint [text | ref-image | video] self-attention, head_dim 64, no mask
 // (replaces F.scaled_dot_product_attention at attention_processor.py:2083-2087).
 //
-//  attn_pp_k : flash-attention forward on v_mfma_f32_32x32x16_bf16, eight waves in a two-group ping-pong (below).
+//  attn_pp_k / attn_pp_persist_k : flash-attention forward on v_mfma_f32_32x32x16_bf16, eight waves in a two-group ping-pong (below);
+//     one workgroup per 256-row q-block (op-level launches) or one persistent workgroup per CU pulling q-blocks from per-XCD
+//     queues (the engine's launches).
 //     block = 8 waves x 32 query rows; KV tile = 64 keys; K tile [64 kv][64 d] and V^T tile [64 d][64 kv] are staged with
 //     LDS-DMA (global_load_lds) into a ring of XOR-swizzled LDS slots (same image as gemm.hip).
 //     QK^T is issued swapped (S^T = K . Q^T) so every lane owns ONE query row: row max / row sum / rescale are
