@@ -149,7 +149,13 @@ def main():
     args = ap.parse_args()
 
     s2v = importlib.import_module("disentangled-subject-to-vid_amd")
-    rank, world, local = s2v.dist.init_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    # S2V_BENCH_BACKEND=gloo + S2V_BENCH_ONE_DEVICE=1: a functional check of the multi-rank path on a one-GPU box (all ranks on cuda:0);
+    # the driver's multi-GPU runs use neither
+    backend = os.environ.get("S2V_BENCH_BACKEND", "nccl")
+    one_dev = os.environ.get("S2V_BENCH_ONE_DEVICE", "0") == "1"
+    if one_dev:
+        os.environ["LOCAL_RANK"] = "0"
+    rank, world, local = s2v.dist.init_from_env(backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dev = f"cuda:{local}"
