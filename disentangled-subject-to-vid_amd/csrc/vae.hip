@@ -13,6 +13,7 @@
 #define S2V_HOST
 #include "common.h"
 #include "kernels.h"
+#include <algorithm>
 #include "vae_kernels.h"
 
 template <typename T> struct V16;
@@ -280,6 +281,64 @@ __global__ __launch_bounds__(256) void snorm_apply_k(const SNormArgs a) {
         V16<T>::st(out + ((((int64_t)(f + a.f_off)) * Hp + yy + 1) * Wp + xx + 1) * C + c0, o);
     }
 }
+// The same operator for channel counts whose 16-byte vectors per pixel divide 256 (every width of the CogVideoX VAE): a block walks
+// image ROWS, so the frame / row arithmetic (and the latent row of the tables) is wave-uniform, and a thread keeps ONE channel vector
+// for all its pixels: GroupNorm weight / bias, group mean / rstd are loaded once per thread instead of once per element, and no
+// 64-bit division is left in the loop (snorm_apply_k spends most of its instructions on index arithmetic: 5 int64 divisions per
+// vector and one int division per channel).  Same arithmetic and rounding points.
+template <typename T>
+__global__ __launch_bounds__(256) void snorm_apply_rows_k(const SNormArgs a) {
+    constexpr int VN = V16<T>::N;
+    const int C = a.C, G = a.G, cpg = C / G;
+    const int vpp = C / VN;  // 256 % vpp == 0
+    const int tid = threadIdx.x;
+    const int vi = tid % vpp, pl = tid / vpp, ppi = 256 / vpp;  // this thread's channel vector, its pixel lane, pixels per pass
+    const int c0 = vi * VN;
+    const double cnt = (double)a.F * a.H * a.W * cpg;
+    float g_w[VN], g_b[VN], mu[VN], rs[VN];
+    V16<T>::ld((const T*)a.gn_w + c0, g_w);
+    V16<T>::ld((const T*)a.gn_b + c0, g_b);
+#pragma unroll
+    for (int e = 0; e < VN; ++e) {
+        const int g = (c0 + e) / cpg;
+        const double m = a.sums[2 * g] / cnt;
+        const double var = a.sums[2 * g + 1] / cnt - m * m;
+        mu[e] = (float)m;
+        rs[e] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)a.eps));
+    }
+    const int Hp = a.H + 2, Wp = a.W + 2;
+    const T* x = (const T*)a.x;
+    T* out = (T*)a.out;
+    const int rows = a.F * a.H;
+    for (int r = blockIdx.x; r < rows; r += gridDim.x) {
+        const int f = r / a.H, yy = r - f * a.H;
+        const int fz = zq_frame(f, a.F, a.Fz);
+        const int yz = (int)(((int64_t)yy * a.hz) / a.H);
+        const T* xr = x + (int64_t)r * a.W * C + c0;
+        T* orow = out + ((((int64_t)(f + a.f_off)) * Hp + yy + 1) * Wp + 1) * C + c0;
+        const int64_t zrow = ((int64_t)fz * a.hz + yz) * a.wz;
+        for (int xx = pl; xx < a.W; xx += ppi) {
+            float v[VN], cy[VN], cb[VN];
+            V16<T>::ld(xr + (int64_t)xx * C, v);
+            if (a.yt != nullptr) {
+                const int xz = (int)(((unsigned)xx * (unsigned)a.wz) / (unsigned)a.W);
+                const int64_t pz = (zrow + xz) * C + c0;
+                V16<T>::ld((const T*)a.yt + pz, cy);
+                V16<T>::ld((const T*)a.bt + pz, cb);
+            }
+            float o[VN];
+#pragma unroll
+            for (int e = 0; e < VN; ++e) {
+                const float n = ET<T>::rnd((v[e] - mu[e]) * rs[e] * g_w[e] + g_b[e]);
+                float rr = n;
+                if (a.yt != nullptr) rr = ET<T>::rnd(ET<T>::rnd(n * cy[e]) + cb[e]);
+                if (a.silu) rr = ET<T>::rnd(silu_f(rr));
+                o[e] = rr;
+            }
+            V16<T>::st(orow + (int64_t)xx * C, o);
+        }
+    }
+}
 // latent-resolution tables: yt[p][c] = rnd(sum_j zq[p][j] wy[j][c] + by[c]), bt likewise (p over Fz*hz*wz)
 template <typename T>
 __global__ void snorm_tables_k(const SNormArgs a) {
@@ -316,12 +375,17 @@ int launch_snorm_apply(const SNormArgs& a, int dtype, hipStream_t st) {
     const size_t shmem = sizeof(float) * (size_t)2 * a.G;
     const int64_t tl = (int64_t)a.Fz * a.hz * a.wz * (a.C / VN);
     const int64_t total = (int64_t)a.F * a.H * a.W * (a.C / VN);
+    const int vpp = a.C / VN;
+    const bool rows_form = vpp <= 256 && 256 % vpp == 0 && (int64_t)a.W * a.wz < (1ll << 31);
+    const unsigned row_grid = (unsigned)std::min<int64_t>((int64_t)a.F * a.H, 16384);
     if (dtype == S2V_BF16) {
         if (!plain) hipLaunchKernelGGL(snorm_tables_k<bf16_t>, dim3(grid_for(tl)), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(snorm_apply_k<bf16_t>, dim3(grid_for(total, 16384)), dim3(256), shmem, st, a);
+        if (rows_form) hipLaunchKernelGGL(snorm_apply_rows_k<bf16_t>, dim3(row_grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(snorm_apply_k<bf16_t>, dim3(grid_for(total, 16384)), dim3(256), shmem, st, a);
     } else {
         if (!plain) hipLaunchKernelGGL(snorm_tables_k<float>, dim3(grid_for(tl)), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(snorm_apply_k<float>, dim3(grid_for(total, 16384)), dim3(256), shmem, st, a);
+        if (rows_form) hipLaunchKernelGGL(snorm_apply_rows_k<float>, dim3(row_grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(snorm_apply_k<float>, dim3(grid_for(total, 16384)), dim3(256), shmem, st, a);
     }
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
