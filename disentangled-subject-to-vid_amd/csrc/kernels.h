@@ -33,6 +33,7 @@ struct GemmArgs {
     // buffer hold the conv cache); kt = 1: per-frame 3x3 conv.  (CogVideoXCausalConv3d, autoencoder_kl_cogvideox.py:120-137)
     int conv, cin, Hp, Wp, oH, oW, kt;
     int cstride;        // conv mode: spatial stride of the output grid (0 or 1 = dense; 2 = CogVideoXDownsample3D, downsampling.py:322-353)
+    int gm;             // 256-row kernel: row tiles per group of the tile order (0: chosen by the launcher)
     int ablate;         // diagnostics only
     int a_rows_padded;  // plain mode: rows physically present behind A (>= M); the 256-row kernel needs ceil256(M)
     int m_begin;        // first output row of this launch (row-tail launches of a split GEMM; 128-row kernel only)
