@@ -34,11 +34,18 @@ class _SchedulerBase:
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
                  clip_sample=False, set_alpha_to_one=True, prediction_type="v_prediction",
-                 timestep_spacing="trailing", rescale_betas_zero_snr=True, snr_shift_scale=3.0, **unused):
+                 timestep_spacing="trailing", rescale_betas_zero_snr=True, snr_shift_scale=3.0, scalar_semantics="cpu",
+                 **unused):
         if beta_schedule != "scaled_linear" or prediction_type != "v_prediction" or timestep_spacing != "trailing" \
                 or not rescale_betas_zero_snr or not set_alpha_to_one or clip_sample:
             raise NotImplementedError("only the CogVideoX scheduler configuration is implemented "
                                       "(scaled_linear, v_prediction, trailing, zero-SNR, set_alpha_to_one)")
+        # The per-step scalars that multiply model-dtype tensors (sqrt(alpha_t), a_t, m1, mn): torch on the CPU materialises such a
+        # 0-dim fp64 scalar in the tensor's dtype (rounded to bf16 for a bf16 sample) -- "cpu", the default, what the committed
+        # goldens were generated with; on a CUDA device torch fetches it as the op's fp32 math type and never rounds it -- "cuda".
+        if scalar_semantics not in ("cpu", "cuda"):
+            raise ValueError("scalar_semantics must be 'cpu' or 'cuda'")
+        self.scalar_semantics = scalar_semantics
         self.config = dict(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                            snr_shift_scale=snr_shift_scale)
         self.alphas_cumprod = torch.from_numpy(
@@ -46,6 +53,9 @@ class _SchedulerBase:
         self.final_alpha_cumprod = torch.tensor(1.0)
         self.num_inference_steps = None
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    def _sc(self, x, dtype):
+        return _as_model(x, dtype) if self.scalar_semantics == "cpu" else _f32(x)
 
     def set_timesteps(self, num_inference_steps, device=None):
         n_train = self.config["num_train_timesteps"]
@@ -90,8 +100,8 @@ class CogVideoXDDIMScheduler(_SchedulerBase):
         bt = a_prev**0.5 - a_t**0.5 * at
         c = _lib.SchedCoefC()
         c.kind, c.guidance = 0, float(np.float32(guidance))
-        c.c_x0_x, c.c_x0_v = _as_model(a_t**0.5, dtype), _f32(b_t**0.5)
-        c.a_t, c.b_t = _as_model(at, dtype), _f32(bt)
+        c.c_x0_x, c.c_x0_v = self._sc(a_t**0.5, dtype), _f32(b_t**0.5)
+        c.a_t, c.b_t = self._sc(at, dtype), _f32(bt)
         return c
 
     def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None,
@@ -115,8 +125,8 @@ class CogVideoXDPMScheduler(_SchedulerBase):
         mn = (1 - a_prev) ** 0.5 * (1 - (-2 * h).exp()) ** 0.5
         c = _lib.SchedCoefC()
         c.guidance = float(np.float32(guidance))
-        c.c_x0_x, c.c_x0_v = _as_model(a_t**0.5, dtype), _f32(b_t**0.5)
-        c.m1, c.m2, c.mn = _as_model(m1, dtype), _f32(m2), _as_model(mn, dtype)
+        c.c_x0_x, c.c_x0_v = self._sc(a_t**0.5, dtype), _f32(b_t**0.5)
+        c.m1, c.m2, c.mn = self._sc(m1, dtype), _f32(m2), self._sc(mn, dtype)
         if first or prev_t < 0:
             c.kind = 1
         else:

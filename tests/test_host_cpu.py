@@ -88,6 +88,30 @@ def test_scheduler_coefficients_reproduce_reference_bits(s2v, kind, dt_name, n_s
             np.testing.assert_array_equal(prev, g[f"lat_out_{i}"], err_msg=f"latents step {i}")
 
 
+def test_scheduler_scalar_semantics_switch(s2v):
+    """"cpu" (default): the scalars that multiply bf16 tensors are rounded to bf16 first, as CPU torch materialises a 0-dim scalar
+    in the tensor dtype (what the goldens above pin); "cuda": they stay fp32, as torch's CUDA kernels fetch them (opmath)."""
+    cpu = s2v.CogVideoXDDIMScheduler(snr_shift_scale=1.0)
+    gpu = s2v.CogVideoXDDIMScheduler(snr_shift_scale=1.0, scalar_semantics="cuda")
+    for s in (cpu, gpu):
+        s.set_timesteps(50)
+    differs = 0
+    for i in (0, 7, 23, 49):
+        t = cpu.timesteps[i]
+        a, b = cpu.coef(t, torch.bfloat16, 6.0), gpu.coef(t, torch.bfloat16, 6.0)
+        for f in ("c_x0_x", "a_t"):
+            va, vb = getattr(a, f), getattr(b, f)
+            assert va == float(torch.tensor(vb).bfloat16().float())      # cpu = cuda rounded to bf16
+            assert vb == float(np.float32(vb))                            # cuda = an fp32 value
+            differs += va != vb
+        assert (a.c_x0_v, a.b_t) == (b.c_x0_v, b.b_t)                   # the other two were fp32 in both
+        f32a, f32b = cpu.coef(t, torch.float32, 6.0), gpu.coef(t, torch.float32, 6.0)
+        assert (f32a.c_x0_x, f32a.a_t) == (f32b.c_x0_x, f32b.a_t)       # no difference for an fp32 model
+    assert differs > 0
+    with pytest.raises(ValueError):
+        s2v.CogVideoXDPMScheduler(scalar_semantics="tpu")
+
+
 def test_scheduler_protocol_surface(s2v):
     s = s2v.CogVideoXDDIMScheduler(snr_shift_scale=1.0)
     assert s.order == 1 and s.init_noise_sigma == 1.0
