@@ -1,0 +1,39 @@
+"""fp8 (e4m3 W8A8) linears vs bf16 linears at the real depth / width of CogVideoX-5B (42 layers), small geometry (322 tokens) and the
+C3 token count (2 layers are not enough to see depth effects; 42 layers at 19126 tokens take ~1.5 s per forward): relative L2 of
+the noise prediction of ONE forward and of the latents after 3 DDIM steps.  There is no reference for this path (parity unpinned)."""
+import copy, importlib, os, sys, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+s2v = importlib.import_module("disentangled-subject-to-vid_amd")
+DEV = "cuda:0"
+cfg = s2v.cogvideox_5b()
+sd = s2v.weights.synthetic_state_dict(cfg, seed=51, device=DEV, parity=True)
+
+
+def rel(a, b):
+    return ((a.double() - b.double()).norm() / b.double().norm()).item()
+
+
+for (F, H, W, T, tag) in ((3, 8, 12, 226, "322 tokens"), (13, 60, 90, 226, "19126 tokens")):
+    g = torch.Generator(device=DEV).manual_seed(52)
+    lat0 = torch.randn(1, F, 16, H, W, generator=g, device=DEV).bfloat16()
+    pe, ne = (torch.randn(1, T, 4096, generator=g, device=DEV).bfloat16() for _ in range(2))
+    ref = (torch.randn(1, 1, 16, H, W, generator=g, device=DEV) * 0.7).bfloat16()
+    res = {}
+    for fmt in ("bf16", "fp8"):
+        c = copy.copy(cfg)
+        c.weight_format = None if fmt == "bf16" else "fp8"
+        m = s2v.HipCogVideoXTransformer3DModel(c, torch.bfloat16, DEV)
+        m.load_state_dict(sd)
+        eng = m.engine
+        eng.set_geometry(2, T, F, H, W)
+        eng.prepare_tables(H * 8, W * 8)
+        eng.set_conditioning(torch.cat([ne, pe]), ref)
+        npred = eng.forward(lat0, torch.tensor([999.0, 999.0]), shared_latent=True).float().clone()
+        pipe = s2v.S2VPipeline(m, s2v.CogVideoXDDIMScheduler(snr_shift_scale=cfg.snr_shift_scale), None)
+        lat = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, ref_img_states=ref, height=H * 8, width=W * 8, num_frames=(F - 1) * 4 + 1,
+                   num_inference_steps=3, guidance_scale=6.0, latents=lat0.clone(), output_type="latent", return_dict=False, use_graph=True)[0]
+        torch.cuda.synchronize()
+        res[fmt] = (npred, lat.float().clone())
+        del m, pipe, eng
+    print(f"{tag}: fp8 vs bf16 rel-L2  one forward (42 layers) {rel(res['fp8'][0], res['bf16'][0]):.3e}   latents after 3 DDIM steps {rel(res['fp8'][1], res['bf16'][1]):.3e}", flush=True)
