@@ -67,3 +67,44 @@ def test_t5_errors(s2v):
         m.load_state_dict({"decoder.block.0.layer.0.SelfAttention.q.weight": torch.zeros(128, 128)})
     with pytest.raises(s2v.S2VError):
         s2v.HipT5EncoderModel(s2v.T5Config(**dict(TINY, d_kv=32)), torch.float32, DEV)
+
+
+def test_t5_xxl_real_width_and_depth_vs_oracle(s2v):
+    """T5-v1.1-XXL as CogVideoX ships it (d_model 4096, 64 heads, d_ff 10240, 24 blocks; 4.7 G parameters), the pipeline's 2 x 226
+    tokens, synthetic weights scaled so that activations stay O(1) through 24 residual blocks.  fp32 path against the fp32 oracle:
+    max-abs <= 1e-3 (measured 5e-5).  bf16 (MFMA) path: its distance from the fp32 oracle must not exceed what the oracle's OWN bf16
+    run shows on the same inputs by more than half (measured 3.95e-2 vs 3.94e-2: 24 blocks of bf16 rounding, not the kernels)."""
+    import dataclasses
+    import os
+
+    cfg = s2v.T5Config()
+    cfgd = dataclasses.asdict(cfg)
+    sd = {k: v.bfloat16() for k, v in s2v.weights.synthetic_t5_state_dict(cfg, seed=71, gain=0.6).items()}
+    ids = torch.randint(0, cfg.vocab_size, (2, 226), generator=torch.Generator().manual_seed(72))
+    ids[1, 200:] = 0  # padding ids are ordinary tokens for the encoder (the pipeline passes no mask)
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm()).item()
+
+    m = s2v.HipT5EncoderModel(cfg, torch.bfloat16, DEV)
+    m.load_state_dict(sd)
+    y16 = m(ids.to(DEV))[0].float().cpu()
+    torch.cuda.synchronize()
+    del m
+    sd32 = {k: v.float() for k, v in sd.items()}
+    m = s2v.HipT5EncoderModel(cfg, torch.float32, DEV)
+    m.load_state_dict(sd32)
+    y32 = m(ids.to(DEV))[0].float().cpu()
+    torch.cuda.synchronize()
+    del m
+    threads0 = torch.get_num_threads()
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    with torch.no_grad():
+        e16 = t5_ref.encoder_forward(sd, cfgd, ids).float()
+        e32 = t5_ref.encoder_forward(sd32, cfgd, ids).float()
+    torch.set_num_threads(threads0)
+    err32 = (y32 - e32).abs().max().item()
+    print(f"T5-XXL fp32: max-abs {err32:.2e} (max|ref| {e32.abs().max().item():.2f}); bf16 vs fp32 oracle: HIP {rel(y16, e32):.3e}, "
+          f"oracle's own bf16 run {rel(e16, e32):.3e}; HIP bf16 vs bf16 oracle {rel(y16, e16):.3e}")
+    assert err32 <= 1e-3, err32
+    assert torch.isfinite(y16).all() and rel(y16, e32) <= 1.5 * rel(e16, e32) + 5e-3
