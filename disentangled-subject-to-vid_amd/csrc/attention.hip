@@ -526,6 +526,7 @@ __global__ __launch_bounds__(512, 2) void attn_pp_persist_k(const AttnArgs a, in
     }
 }
 
+
 #ifdef S2V_DIAG
 int g_attn_variant = 0;  // 0 = product kernel, 1 = product kernel with stall accounting, 2 = round-1 lock-step kernel (A/B reference)
 extern "C" __attribute__((visibility("default"))) int s2v_set_attn_variant(int v) { g_attn_variant = v; return 0; }
@@ -552,6 +553,10 @@ int launch_attn_bf16(const AttnArgs& a_in, hipStream_t st) {
     if (g_attn_variant == 1 || g_attn_variant == 5) fn = (const void*)attn_pp_k<true>;
     if (g_attn_variant == 2) { fn = (const void*)attn_bf16_k<0, 8>; lds = 4 * ATT_TILE_BYTES; persist = false; }
     if (g_attn_variant == 3) persist = false;  // the one-workgroup-per-item launch of the product kernel
+    if (g_attn_variant == 6 || g_attn_variant == 7) {  // four-wave kernel: per item / persistent
+        if (!a.queue) { a.queue = g_attn_queue; a.num_cus = g_attn_ncu; }
+        return launch_attn_q4(a, g_attn_variant == 7, st);
+    }
 #endif
     if (persist) {
         fn = (const void*)attn_pp_persist_k<false>;

@@ -1,0 +1,211 @@
+// Joint [text | ref-image | video] self-attention, head_dim 64, no mask (replaces F.scaled_dot_product_attention at
+// attention_processor.py:2083-2087): the four-wave, one-wave-per-SIMD form.  Compiled with -fno-slp-vectorize (build.py): the SLP
+// vectoriser merges element accesses of neighbouring accumulators into 32-wide vectors, which keeps SROA from promoting them.
+#define S2V_HOST
+#include "common.h"
+#include "kernels.h"
+#include <type_traits>
+
+#define KV_TILE 64
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// XCD-aware order of the work items (as attention.hip): XCD x owns a contiguous range of q-blocks
+__device__ __forceinline__ void attn_xcd_range(int total, int x, int& first, int& cnt) {
+    const int q = total >> 3, r = total & 7;
+    first = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+    cnt = q + (x < r ? 1 : 0);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// attn_q4: FOUR waves, one per SIMD, 64 query rows per wave (two 32-row blocks j = 0, 1), the whole 512-entry register file.
+// A workgroup is the same 256-row work item as attn_pp_item (attention.hip).  What changes against the eight-wave ping-pong:
+//   * no SIMD partner: the wave fills the shadow of its OWN MFMAs.  A 32x32x16 MFMA occupies the matrix pipe for 32 cycles and
+//     leaves room for about five single-issue instructions behind it (MI355X_MICROARCH, per-instruction constants); the
+//     eight-wave form gave the softmax wave one VALU per 16 cycles beside its partner's MFMA stream;
+//   * a K / V^T fragment read from LDS feeds TWO MFMAs (both 32-row blocks): 16 ds_read_b128 per 32 MFMA instead of 32;
+//   * one barrier per KV tile instead of two.
+// Per KV tile and wave: 32 MFMA (1024 matrix-pipe cycles) and 64 exp2 + 64 row-sum adds + 32 v_cvt_pk + 16 fragment reads +
+// 4 LDS-DMA pieces + the check = about six fillers per MFMA, each placed by hand.
+// Software pipeline (iteration t, S = scores, P = exp2(S - m)):
+//   segment 1: 16 MFMA  S(t+1) = K(t+1).Q^T  -> st[(t+1)&1]   | fillers: second half of P(t) (keys 32-63) -> pk[.][2,3],
+//                                                               V^T(t) fragments, K(t+4) DMA
+//   check    : row sums of tile t against 2^13 (deferred maximum, as attn_pp_item)
+//   segment 2: 16 MFMA  O += V^T(t).P(t)                       | fillers: first half of P(t+1) (keys 0-31) -> pk[.][0,1] (written
+//                                                               behind the MFMAs that read the old values), K(t+2) fragments,
+//                                                               V^T(t+2) DMA, l += row sums of t; vmcnt(4) + barrier
+// The raw scores of a tile stay in their st buffer until S(t+2) overwrites them, so the slow path (true row maximum, rescale,
+// exp2 redone) has them at the check; it also shifts S(t+1), which segment 1 computed against the old maximum.
+// Everything from "tiles staged, Q loaded" to "O and l complete" is ONE generated asm statement (csrc/gen_attn_q4.py ->
+// attn_q4_body.inc; register map, phases and the reasons in its header): this function stages the first tiles, loads Q and, after
+// the asm, normalises and stores O.  Hazards the assembler does not see: a VALU reads an MFMA result at least four MFMAs after its
+// issue, the rare paths and the end of the body start with s_nop 15 x 2, fragment reads are awaited with one s_waitcnt lgkmcnt(0)
+// per segment.
+// LDS: ring of 4 slots x [K tile 8 KiB | V^T tile 8 KiB]; a wave stages pieces w and w + 4 (8 rows each) of every tile.
+//   RAW  K(t+4), V(t+2) are issued in iteration t and awaited (vmcnt(4): everything but this iteration's four) at the end of
+//        iteration t+1, one barrier before their first readers (K(t+4): segment 2 of t+2; V(t+2): segment 1 of t+2).
+//   WAR  K(t+4) replaces K(t) (last read in segment 2 of t-2), V(t+2) replaces V(t-2) (last read in segment 1 of t-2).
+#include "attn_q4_regs.h"
+typedef __attribute__((ext_vector_type(32))) float f32x32;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(32))) unsigned int u32x32;
+typedef __attribute__((ext_vector_type(8))) unsigned int u32x8;
+template <bool ACCT>
+__device__ __forceinline__ void attn_q4_item(const AttnArgs& a, int nqb, int wg, char* smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, hi = lane >> 5;
+    const int bh = wg / nqb, qb = wg - bh * nqb;
+    const int b = bh / a.H, h = bh - b * a.H;
+    const int D = a.H * 64;
+
+    const bf16_t* qkv = (const bf16_t*)a.qkv + (size_t)b * a.Ntok * a.ld_qkv;
+    const char* Kg = (const char*)(qkv + D + h * 64);
+    const char* VTg = (const char*)((const bf16_t*)a.vt + (size_t)(b * a.H + h) * 64 * a.ntok_pad);
+    const int nt = (a.Ntok + KV_TILE - 1) / KV_TILE;
+    const unsigned lds0 = lds_base_u32(smem);
+
+    // staging: pieces `wave` and `wave + 4` of a tile (8 rows x 128 B each), lane = (row, 16-B chunk), chunk XOR on the SOURCE
+    // address ((row + 32) has the same XOR term: the second piece is the first one's lane offset + 32 rows)
+    const int srow = wave * 8 + (lane >> 3);
+    const int sc = (lane & 7) ^ ((srow >> 1) & 7);
+    u32x8 vin;  // [0..3] fragment address of k-step kk in slot 0 (the 32-row half and the slot are immediates), [4..7] staging offsets
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) vin[kk] = lds0 + fr * 128 + (((kk * 2 + hi) ^ ((fr >> 1) & 7)) << 4);
+    vin[4] = (unsigned)(2 * (srow * a.ld_qkv + sc * 8));
+    vin[5] = vin[4] + 64u * a.ld_qkv;
+    vin[6] = (unsigned)(2 * (srow * a.ntok_pad + sc * 8));
+    vin[7] = vin[6] + 64u * a.ntok_pad;
+    const unsigned k_tile_stride = (unsigned)KV_TILE * a.ld_qkv * 2;
+    const unsigned m0w = lds0 + wave * 1024;  // LDS address of this wave's first piece in slot 0
+    // tiles past the end are clamped (re-staged into a dead slot): every wave issues the same number of DMAs in every iteration
+    auto k_src = [&](int t) __attribute__((always_inline)) { return Kg + (size_t)min(t, nt - 1) * k_tile_stride; };
+    auto v_src = [&](int t) __attribute__((always_inline)) { return VTg + (size_t)min(t, nt - 1) * (KV_TILE * 2); };
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        glds16_saddr_m0(k_src(i), vin[4], m0w + i * 16384);
+        glds16_saddr_m0(k_src(i), vin[5], m0w + i * 16384 + 4096);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        glds16_saddr_m0(v_src(i), vin[6], m0w + i * 16384 + 8192);
+        glds16_saddr_m0(v_src(i), vin[7], m0w + i * 16384 + 8192 + 4096);
+    }
+
+    // Q fragments of both row blocks, pre-multiplied by scale * log2(e) and rounded to bf16 once (as attn_pp_item); word 16 j + 4 kk
+    const float c0 = a.scale * 1.4426950408889634f;
+    u32x32 qf;
+    int q_row[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        q_row[j] = qb * 256 + wave * 64 + j * 32 + fr;
+        const int q_ld = min(q_row[j], a.Ntok - 1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const bf16x8 q = *(const bf16x8*)(qkv + (size_t)q_ld * a.ld_qkv + h * 64 + kk * 16 + hi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) qf[16 * j + 4 * kk + (e >> 1)] = pack2bf((float)q[e] * c0, (float)q[e + 1] * c0);
+        }
+    }
+    u32x4 ptr, sin;  // sources of the next K / V^T tile to stage (64-bit each); nt, K tile stride, Ntok, LDS address of the wave's first piece
+    {
+        const unsigned long long kp = (unsigned long long)k_src(4), vp = (unsigned long long)v_src(2);
+        ptr[0] = (unsigned)kp; ptr[1] = (unsigned)(kp >> 32); ptr[2] = (unsigned)vp; ptr[3] = (unsigned)(vp >> 32);
+        ptr[0] = __builtin_amdgcn_readfirstlane(ptr[0]); ptr[1] = __builtin_amdgcn_readfirstlane(ptr[1]);
+        ptr[2] = __builtin_amdgcn_readfirstlane(ptr[2]); ptr[3] = __builtin_amdgcn_readfirstlane(ptr[3]);
+        sin[0] = (unsigned)nt; sin[1] = k_tile_stride; sin[2] = (unsigned)a.Ntok; sin[3] = m0w;
+    }
+    f32x32 OT[2];  // ot(j, db)[e] = OT[j][16 db + e]
+    f32x2 LR;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile(
+#include "attn_q4_body.inc"
+        : "=" Q4_OT0(OT[0]), "=" Q4_OT1(OT[1]), "=" Q4_LRUN(LR), "+" Q4_PTR(ptr)
+        : Q4_QF(qf), Q4_VIN(vin), Q4_SIN(sin)
+        : Q4_CLOBBERS);
+
+    // epilogue: as attn_pp_item, once per row block
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float l_tot = LR[j] + __shfl_xor(LR[j], 32, 64);
+        const float inv = 1.0f / l_tot;
+        u32x2 og[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int db = g >> 2, rq = g & 3;
+            og[g].x = pack2bf(OT[j][16 * db + rq * 4 + 0] * inv, OT[j][16 * db + rq * 4 + 1] * inv);
+            og[g].y = pack2bf(OT[j][16 * db + rq * 4 + 2] * inv, OT[j][16 * db + rq * 4 + 3] * inv);
+        }
+        bf16_t* o = (bf16_t*)a.out + (size_t)(b * a.Ntok + min(q_row[j], a.Ntok - 1)) * a.ld_out + h * 64 + hi * 8;
+#pragma unroll
+        for (int g = 0; g < 8; g += 2) {
+            const auto rx = __builtin_amdgcn_permlane32_swap(og[g].x, og[g + 1].x, false, false);
+            const auto ry = __builtin_amdgcn_permlane32_swap(og[g].y, og[g + 1].y, false, false);
+            u32x4 v = {rx[0], ry[0], rx[1], ry[1]};
+            if (q_row[j] < a.Ntok) *(u32x4*)(o + 8 * g) = v;
+        }
+    }
+}
+template <bool ACCT>
+__global__ __launch_bounds__(256, 1) void attn_q4_k(const AttnArgs a, int nqb) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 slots][K tile | VT tile]
+    int first, cnt;
+    attn_xcd_range((int)gridDim.x, blockIdx.x & 7, first, cnt);
+    attn_q4_item<ACCT>(a, nqb, first + (int)(blockIdx.x >> 3), smem);
+}
+template <bool ACCT>
+__global__ __launch_bounds__(256, 1) void attn_q4_persist_k(const AttnArgs a, int nqb, int total, int* __restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int s_item;
+    const int xcd = blockIdx.x & 7;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            int wg = -1;
+            for (int k = 0; k < 8 && wg < 0; ++k) {
+                const int y = (xcd + k) & 7;
+                int first, cnt;
+                attn_xcd_range(total, y, first, cnt);
+                if (__hip_atomic_load(&queue[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cnt) continue;
+                const int i = atomicAdd(&queue[y], 1);
+                if (i < cnt) wg = first + i;
+            }
+            s_item = wg;
+        }
+        __syncthreads();
+        const int wg = s_item;
+        __syncthreads();
+        if (wg < 0) break;
+        attn_q4_item<ACCT>(a, nqb, wg, smem);
+    }
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(&queue[8], 1) == (int)gridDim.x - 1) {
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(&queue[i], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence();
+        }
+    }
+}
+
+
+int launch_attn_q4(const AttnArgs& a, bool persistent, hipStream_t st) {
+    const int nqb = (a.Ntok + 255) / 256;  // four waves x 64 query rows per item
+    const int total = nqb * a.B * a.H;
+    const size_t lds = 65536;
+    if (persistent && a.queue != nullptr && a.num_cus >= 8) {
+        const void* fn = (const void*)attn_q4_persist_k<false>;
+        S2V_TRY(ensure_lds_attr(fn, 65536));
+        int* queue = a.queue;
+        void* args[] = {(void*)&a, (void*)&nqb, (void*)&total, (void*)&queue};
+        S2V_CHECK_HIP(hipLaunchKernel(fn, dim3((a.num_cus / 8) * 8), dim3(256), args, lds, st));
+        return 0;
+    }
+    const void* fn = (const void*)attn_q4_k<false>;
+    S2V_TRY(ensure_lds_attr(fn, 65536));
+    void* args[] = {(void*)&a, (void*)&nqb};
+    S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(total), dim3(256), args, lds, st));
+    return 0;
+}

@@ -1,0 +1,361 @@
+#!/usr/bin/env python3
+"""Generator of the hand-scheduled body of attn_q4 (csrc/attention_q4.hip): writes attn_q4_body.inc -- ONE asm statement that
+takes a work item from "K / V^T tiles 0-3 / 0-1 staged, Q fragments loaded" to "O^T accumulators and row sums complete" -- and
+attn_q4_regs.h (the physical-register constraints and the clobber list of that statement).  Run by build.py when the
+generated files are older than this script; the outputs are committed.
+
+Why generated asm: with more than 256 registers per lane hipcc selects the AGPR form for every MFMA builtin and copies the
+scores to VGPRs for the softmax, and its allocator does not fit S (128) + -m (32) + P (32) into the 256 VGPRs without
+shuttling tuples through AGPRs; the loop is issue-bound (about six fillers per MFMA), so every extra instruction is time.
+A first version kept the rare paths in C++ and left the asm at the checks: the register shuffling and scratch spills hipcc put
+around each exit cost 3.8 ms of a 10.9 ms launch, so everything between the prologue's DMA and the epilogue is in here.
+
+Register file (per lane):
+  v[0:127]    S^T accumulators st[buf][j][kb] (16 each): buf = tile parity, j = 32-row block, kb = 32-key half
+  v[128:159]  -m of the rows of block j (16 copies: the C operand of the first MFMA of a chain)
+  v[160:191]  P as bf16 pairs pk[j][s] (4 each): B operand of the P.V step s (16 keys)
+  v[192:199]  exp2 results in flight, two groups of four
+  v[200:207]  row sums ps[set][j][x] of the tile whose P is being built (set = tile parity)
+  v[208:215]  IN: fragment address of k-step kk in slot 0 (4), staging lane offsets K piece 0 / 1, V^T piece 0 / 1
+  v[216:217]  OUT: running row sums l[j];  v[218:229] scratch of the rare paths
+  a[0:63]     OUT: O^T accumulators ot[j][db];  a[64:95] IN: Q fragments qf[j][kk];  a[96:127] K fragments;  a[128:159] V^T fragments
+  s[36:37] IN: K source, s[38:39] IN: V^T source (next tile to stage: K(4), V^T(2), clamped)
+  s44 IN: nt, s45 IN: K tile stride (bytes), s46 IN: Ntok, s47 IN: LDS address of the wave's first piece in slot 0
+  s40 t, s41 end of the current phase, s42 / s43 K / V^T source advance per iteration, s48 threshold (f32 bits), s49 return position,
+  s[50:51] scratch
+Phases: A = iterations t < nt - 5 (threshold 2^13: a check fires only for a genuine slow path); B = the last five (threshold -1:
+every check enters the rare-path handler, which applies the staging clamp, the tail mask and the real threshold).
+"""
+import os
+
+ST, NEGM, PK, TMP, PS, VIN, LRUN = 0, 128, 160, 192, 200, 208, 216
+VS = 218  # scratch v218..v229
+OT, QF, KF, VF = 0, 64, 96, 128
+S_KPTR, S_VPTR, S_T, S_END, S_KADV, S_VADV, S_NT, S_KSTR, S_NTOK, S_M0W, S_THR, S_RET, S_X0, S_X1 = 36, 38, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51
+ABLATE = set(filter(None, os.environ.get("Q4_ABLATE", "").split(",")))  # timing experiments only (results are wrong)
+
+
+def vr(base, n=1):
+    return f"v{base}" if n == 1 else f"v[{base}:{base + n - 1}]"
+
+
+def ar(base, n=1):
+    return f"a{base}" if n == 1 else f"a[{base}:{base + n - 1}]"
+
+
+def st(buf, j, kb):
+    return ST + 64 * buf + 32 * j + 16 * kb
+
+
+def ps(sset, j, x):
+    return PS + 4 * sset + 2 * j + x
+
+
+def pk(j, s):
+    return PK + 16 * j + 4 * s
+
+
+def tmp(g, x):
+    return TMP + 4 * (g & 1) + x
+
+
+def soft_stream(sb, kb, sset):
+    """80 ops turning half kb of the scores in st[sb] into P: groups g of four values (row block g >> 2, accumulator elements
+    4 (g & 3) ..); exp2 of group g interleaved with the row-sum adds and the two v_cvt_pk of group g - 1."""
+    def exp(g, x):
+        return f"v_exp_f32 {vr(tmp(g, x))}, {vr(st(sb, g >> 2, kb) + (g & 3) * 4 + x)}"
+
+    def add(g, x):
+        acc = vr(ps(sset, g >> 2, x & 1))
+        if kb == 0 and (g & 3) == 0 and x < 2:  # first touch of this accumulator in the tile: no reset needed
+            return f"v_mov_b32 {acc}, {vr(tmp(g, x))}"
+        return f"v_add_f32 {acc}, {acc}, {vr(tmp(g, x))}"
+
+    def cvt(g, c):
+        e0 = (g & 3) * 4
+        dst = pk(g >> 2, kb * 2 + (e0 >> 3)) + ((e0 & 7) >> 1) + c
+        return f"v_cvt_pk_bf16_f32 {vr(dst)}, {vr(tmp(g, 2 * c))}, {vr(tmp(g, 2 * c + 1))}"
+
+    ops = [exp(0, x) for x in range(4)]
+    for g in range(1, 8):
+        ops += [exp(g, 0), exp(g, 1), add(g - 1, 0), add(g - 1, 1), exp(g, 2), exp(g, 3), add(g - 1, 2), add(g - 1, 3),
+                cvt(g - 1, 0), cvt(g - 1, 1)]
+    ops += [add(7, x) for x in range(4)] + [cvt(7, 0), cvt(7, 1)]
+    assert len(ops) == 80
+    return ops
+
+
+def frag_read(dst_base, i, slot, is_v):
+    # fragment i = (k-step i >> 1, 32-row half i & 1) of the K (V^T) tile in ring slot `slot`
+    off = slot * 16384 + (8192 if is_v else 0) + (i & 1) * 4096
+    return f"ds_read_b128 {ar(dst_base + 4 * i, 4)}, {vr(VIN + (i >> 1))} offset:{off}"
+
+
+def qk_mfma(buf, i):
+    kk, kb, j = i >> 2, (i >> 1) & 1, i & 1
+    d = vr(st(buf, j, kb), 16)
+    c = vr(NEGM + 16 * j, 16) if kk == 0 else d
+    return f"v_mfma_f32_32x32x16_bf16 {d}, {ar(KF + 4 * (kk * 2 + kb), 4)}, {ar(QF + 16 * j + 4 * kk, 4)}, {c}"
+
+
+def slow_path(emit, cur, first):
+    """raise the running maximum of both row blocks to the true maximum of the tile in st[cur], rescale everything at the old
+    scale, redo P and the row sums of the whole tile; S of the next tile (other buffer) was computed against the old maximum and
+    is shifted as well.  first: tile 0 adopts its maximum (O and l are zero, exp2(-d) could overflow) and only the first half of
+    P(0) is built: segment 1 of iteration 0 builds the second half, as for every tile"""
+    nxt = cur ^ 1
+    vA, vB, vD, vAl, T = VS, VS + 1, VS + 2, VS + 3, VS + 4  # T: 8 temporaries v222..v229
+    for j in range(2):
+        s = [st(cur, j, 0) + e for e in range(16)] + [st(cur, j, 1) + e for e in range(16)]
+        emit(f"v_max3_f32 {vr(vA)}, {vr(s[0])}, {vr(s[1])}, {vr(s[2])}")
+        for x in range(3, 31, 2):
+            emit(f"v_max3_f32 {vr(vA)}, {vr(vA)}, {vr(s[x])}, {vr(s[x + 1])}")
+        emit(f"v_max_f32 {vr(vA)}, {vr(vA)}, {vr(s[31])}")
+        emit(f"v_mov_b32 {vr(vB)}, {vr(vA)}")
+        emit("s_nop 1")
+        emit(f"v_permlane32_swap_b32 {vr(vA)}, {vr(vB)}")  # vA = lower half's value in both halves, vB = upper half's
+        emit("s_nop 1")
+        emit(f"v_max_f32 {vr(vD)}, {vr(vA)}, {vr(vB)}")
+        if not first:
+            emit(f"v_max_f32 {vr(vD)}, 0, {vr(vD)}")
+            emit(f"v_exp_f32_e64 {vr(vAl)}, -{vr(vD)}")
+            emit("s_nop 0")
+            emit(f"v_mul_f32 {vr(LRUN + j)}, {vr(LRUN + j)}, {vr(vAl)}")
+            for e0 in range(0, 32, 4):
+                for k in range(4):
+                    emit(f"v_accvgpr_read_b32 {vr(T + k)}, {ar(OT + 32 * j + e0 + k)}")
+                for k in range(4):
+                    emit(f"v_mul_f32 {vr(T + k)}, {vr(T + k)}, {vr(vAl)}")
+                for k in range(4):
+                    emit(f"v_accvgpr_write_b32 {ar(OT + 32 * j + e0 + k)}, {vr(T + k)}")
+        for e in range(16):
+            emit(f"v_sub_f32 {vr(NEGM + 16 * j + e)}, {vr(NEGM + 16 * j + e)}, {vr(vD)}")
+        for x in range(32):
+            emit(f"v_sub_f32 {vr(s[x])}, {vr(s[x])}, {vr(vD)}")
+        nexp = 16 if first else 32
+        for x0 in range(0, nexp, 4):  # four exp2, then their sums and packs (a transcendental's result is not read by the next instruction)
+            for k in range(4):
+                emit(f"v_exp_f32 {vr(T + k)}, {vr(s[x0 + k])}")
+            emit("s_nop 0")
+            for k in range(4):
+                acc = vr(ps(cur, j, k & 1))
+                emit(f"v_mov_b32 {acc}, {vr(T + k)}" if x0 == 0 and k < 2 else f"v_add_f32 {acc}, {acc}, {vr(T + k)}")
+            kb, e = x0 >> 4, x0 & 15
+            dst = pk(j, kb * 2 + (e >> 3)) + ((e & 7) >> 1)
+            emit(f"v_cvt_pk_bf16_f32 {vr(dst)}, {vr(T)}, {vr(T + 1)}")
+            emit(f"v_cvt_pk_bf16_f32 {vr(dst + 1)}, {vr(T + 2)}, {vr(T + 3)}")
+        if not first:
+            for kb in range(2):
+                for e in range(16):
+                    r = st(nxt, j, kb) + e
+                    emit(f"v_sub_f32 {vr(r)}, {vr(r)}, {vr(vD)}")
+
+
+def mask_tile(emit, buf, s_kv0):
+    """keys >= Ntok of the tile in st[buf] (first key in SGPR s_kv0) get score -inf; a clamped duplicate past the end is masked
+    completely.  Element e of half kb is key kv0 + 32 kb + (e & 3) + 8 (e >> 2) + 4 (lane >> 5)."""
+    vL, vBase, vInf = VS + 4, VS + 5, VS + 6
+    emit(f"v_mbcnt_lo_u32_b32 {vr(vL)}, -1, 0")
+    emit(f"v_mbcnt_hi_u32_b32 {vr(vL)}, -1, {vr(vL)}")
+    emit(f"v_lshrrev_b32 {vr(vL)}, 5, {vr(vL)}")
+    emit(f"v_lshlrev_b32 {vr(vL)}, 2, {vr(vL)}")
+    emit(f"s_sub_u32 s{S_X1}, s{S_NTOK}, s{s_kv0}")  # keys of this tile below Ntok (<= 0: none)
+    emit(f"v_sub_u32 {vr(vBase)}, s{S_X1}, {vr(vL)}")
+    emit(f"v_mov_b32 {vr(vInf)}, 0xff800000")
+    for kb in range(2):
+        for e in range(16):
+            c = kb * 32 + (e & 3) + 8 * (e >> 2)
+            emit(f"v_cmp_ge_i32 vcc, {c}, {vr(vBase)}")
+            for j in range(2):
+                r = st(buf, j, kb) + e
+                emit(f"v_cndmask_b32 {vr(r)}, {vr(r)}, {vr(vInf)}, vcc")
+
+
+def gen():
+    L = []
+
+    def emit(ln):
+        op = ln.split()[0]
+        if "nodma" in ABLATE and op == "global_load_lds_dwordx4":
+            return
+        if "noread" in ABLATE and op == "ds_read_b128":
+            return
+        if "nosoft" in ABLATE and op in ("v_exp_f32", "v_add_f32", "v_mov_b32", "v_cvt_pk_bf16_f32"):
+            return
+        if "movexp" in ABLATE and op == "v_exp_f32":
+            ln = ln.replace("v_exp_f32", "v_mov_b32")
+        if "nobar" in ABLATE and op == "s_barrier":
+            return
+        if "nowait" in ABLATE and ln.startswith("s_waitcnt lgkmcnt"):
+            return
+        if "nomfma" in ABLATE and op.startswith("v_mfma"):
+            return
+        L.append(ln)
+
+    emit("; ---- attn_q4 body (generated by gen_attn_q4.py; do not edit)")
+    # ---------------- state
+    for r in range(64):
+        emit(f"v_accvgpr_write_b32 {ar(OT + r)}, 0")
+    for r in range(32):
+        emit(f"v_mov_b32 {vr(NEGM + r)}, 0")
+    emit(f"v_mov_b32 {vr(LRUN)}, 0")
+    emit(f"v_mov_b32 {vr(LRUN + 1)}, 0")
+    emit(f"s_mov_b32 s{S_T}, 0")
+    emit(f"s_mov_b32 s{S_THR}, 0x46000000")      # 8192.0
+    emit(f"s_mov_b32 s{S_KADV}, s{S_KSTR}")
+    emit(f"s_mov_b32 s{S_VADV}, 128")
+    emit(f"s_sub_u32 s{S_END}, s{S_NT}, 5")      # phase A ends at nt - 5 ...
+    emit(f"s_cmp_gt_i32 s{S_END}, 0")
+    emit("s_cbranch_scc1 L_q4_pa_%=")
+    emit(f"s_mov_b32 s{S_END}, s{S_NT}")         # ... or there is none: phase B from the start
+    emit(f"s_mov_b32 s{S_THR}, 0xbf800000")
+    emit(f"s_mov_b32 s{S_KADV}, 0")
+    emit("L_q4_pa_%=:")
+    # ---------------- prologue: K(0) fragments, S(0) -> st[0], K(1) fragments, tail mask, adoption of tile 0's maxima
+    for i in range(8):
+        emit(frag_read(KF, i, 0, False))
+    emit("s_waitcnt lgkmcnt(0)")
+    for i in range(16):
+        emit(qk_mfma(0, i))
+    for i in range(8):
+        emit(frag_read(KF, i, 1, False))
+    emit("s_nop 15")
+    emit("s_nop 15")
+    emit(f"s_cmp_ge_u32 s{S_NTOK}, 64")
+    emit("s_cbranch_scc1 L_q4_nomask0_%=")
+    emit(f"s_mov_b32 s{S_X0}, 0")
+    mask_tile(emit, 0, S_X0)
+    emit("L_q4_nomask0_%=:")
+    slow_path(emit, 0, True)
+    emit("s_branch L_q4_e0_%=")
+    # ---------------- main loop, unrolled over four tiles (U = t mod 4: st buffers and LDS slots are immediates)
+    for U in range(4):
+        cur, nxt = U & 1, (U & 1) ^ 1
+        # segment 1: S(t+1) = K(t+1).Q^T -> st[nxt]; second half of P(t); V^T(t) fragments; K(t+4) pieces
+        emit(f"L_q4_e{U}_%=:")
+        emit("s_waitcnt lgkmcnt(0)")
+        soft = soft_stream(cur, 1, cur)
+        for i in range(16):
+            emit(qk_mfma(nxt, i))
+            for op in soft[5 * i:5 * i + 5]:
+                emit(op)
+            if i % 2 == 0:
+                emit(frag_read(VF, i >> 1, U, True))
+            if i == 3:
+                emit(f"s_add_u32 m0, s{S_M0W}, {U * 16384}")
+            if i == 5:
+                emit(f"global_load_lds_dwordx4 {vr(VIN + 4)}, s[{S_KPTR}:{S_KPTR + 1}]")
+            if i == 9:
+                emit(f"s_add_u32 m0, s{S_M0W}, {U * 16384 + 4096}")
+            if i == 11:
+                emit(f"global_load_lds_dwordx4 {vr(VIN + 5)}, s[{S_KPTR}:{S_KPTR + 1}]")
+            if i == 14:
+                emit(f"s_add_u32 s{S_KPTR}, s{S_KPTR}, s{S_KADV}")
+                emit(f"s_addc_u32 s{S_KPTR + 1}, s{S_KPTR + 1}, 0")
+        # check of tile t: the four partial row sums against the threshold (any lane)
+        emit(f"v_max3_f32 {vr(VS)}, {vr(ps(cur, 0, 0))}, {vr(ps(cur, 0, 1))}, {vr(ps(cur, 1, 0))}")
+        emit(f"v_max_f32 {vr(VS)}, {vr(VS)}, {vr(ps(cur, 1, 1))}")
+        emit(f"v_cmp_nge_f32 vcc, s{S_THR}, {vr(VS)}")  # row sum > threshold, or NaN
+        emit(f"s_cbranch_vccnz L_q4_x{U}_%=")
+        # segment 2: O += V^T(t).P(t); first half of P(t+1); K(t+2) fragments; V^T(t+2) pieces; l += row sums of t
+        emit(f"L_q4_e{4 + U}_%=:")
+        emit("s_waitcnt lgkmcnt(0)")
+        soft = soft_stream(nxt, 0, nxt)
+        slot2 = (U + 2) & 3
+        ladd = {1: (0, 0), 7: (0, 1), 13: (1, 0), 15: (1, 1)}
+        for i in range(16):
+            s, j, db = i >> 2, (i >> 1) & 1, i & 1
+            d = ar(OT + 32 * j + 16 * db, 16)
+            emit(f"v_mfma_f32_32x32x16_bf16 {d}, {ar(VF + 4 * (s * 2 + db), 4)}, {vr(pk(j, s), 4)}, {d}")
+            for op in soft[5 * i:5 * i + 5]:
+                emit(op)
+            if i % 2 == 0:
+                emit(frag_read(KF, i >> 1, slot2, False))
+            if i in ladd:
+                jj, x = ladd[i]
+                emit(f"v_add_f32 {vr(LRUN + jj)}, {vr(LRUN + jj)}, {vr(ps(cur, jj, x))}")
+            if i == 3:
+                emit(f"s_add_u32 m0, s{S_M0W}, {slot2 * 16384 + 8192}")
+            if i == 5:
+                emit(f"global_load_lds_dwordx4 {vr(VIN + 6)}, s[{S_VPTR}:{S_VPTR + 1}]")
+            if i == 9:
+                emit(f"s_add_u32 m0, s{S_M0W}, {slot2 * 16384 + 8192 + 4096}")
+            if i == 11:
+                emit(f"global_load_lds_dwordx4 {vr(VIN + 7)}, s[{S_VPTR}:{S_VPTR + 1}]")
+        emit(f"s_add_u32 s{S_VPTR}, s{S_VPTR}, s{S_VADV}")
+        emit(f"s_addc_u32 s{S_VPTR + 1}, s{S_VPTR + 1}, 0")
+        emit("s_waitcnt vmcnt(4)")
+        emit("s_barrier")
+        emit(f"s_add_u32 s{S_T}, s{S_T}, 1")
+        emit(f"s_cmp_lt_u32 s{S_T}, s{S_END}")
+        emit("s_cbranch_scc0 L_q4_phase_%=")
+        if U == 3:
+            emit("s_branch L_q4_e0_%=")
+    # ---------------- end of a phase: A -> B (threshold -1, no more K advance), or finished
+    emit("L_q4_phase_%=:")
+    emit(f"s_cmp_ge_u32 s{S_T}, s{S_NT}")
+    emit("s_cbranch_scc1 L_q4_done_%=")
+    emit(f"s_mov_b32 s{S_END}, s{S_NT}")
+    emit(f"s_mov_b32 s{S_THR}, 0xbf800000")
+    emit(f"s_mov_b32 s{S_KADV}, 0")
+    emit(f"s_and_b32 s{S_X0}, s{S_T}, 3")
+    for U in range(1, 4):
+        emit(f"s_cmp_eq_u32 s{S_X0}, {U}")
+        emit(f"s_cbranch_scc1 L_q4_e{U}_%=")
+    emit("s_branch L_q4_e0_%=")
+    # ---------------- rare-path handlers: the check of position U fired (st[U & 1] = S(t), st[~U & 1] = S(t+1))
+    for U in range(4):
+        emit(f"L_q4_x{U}_%=:")
+        emit(f"s_mov_b32 s{S_RET}, {U}")
+        emit(f"s_branch L_q4_rare{U & 1}_%=")
+    for cur in range(2):
+        nxt = cur ^ 1
+        emit(f"L_q4_rare{cur}_%=:")
+        emit("s_nop 15")  # MFMA results of segment 1 are read below
+        emit("s_nop 15")
+        emit(f"s_add_u32 s{S_X0}, s{S_T}, 3")      # V^T(t+2) is staged by this iteration: the source advances while t + 3 < nt
+        emit(f"s_cmp_lt_u32 s{S_X0}, s{S_NT}")
+        emit(f"s_cselect_b32 s{S_VADV}, 128, 0")
+        emit(f"s_add_u32 s{S_X0}, s{S_T}, 1")      # tail mask of S(t+1): first key 64 (t+1); needed when it ends past Ntok
+        emit(f"s_lshl_b32 s{S_X0}, s{S_X0}, 6")
+        emit(f"s_add_u32 s{S_X1}, s{S_X0}, 64")
+        emit(f"s_cmp_gt_u32 s{S_X1}, s{S_NTOK}")
+        emit(f"s_cbranch_scc0 L_q4_nomask{1 + cur}_%=")
+        mask_tile(emit, nxt, S_X0)
+        emit(f"L_q4_nomask{1 + cur}_%=:")
+        emit(f"v_max3_f32 {vr(VS)}, {vr(ps(cur, 0, 0))}, {vr(ps(cur, 0, 1))}, {vr(ps(cur, 1, 0))}")
+        emit(f"v_max_f32 {vr(VS)}, {vr(VS)}, {vr(ps(cur, 1, 1))}")
+        emit(f"s_mov_b32 s{S_X0}, 0x46000000")
+        emit(f"v_cmp_nge_f32 vcc, s{S_X0}, {vr(VS)}")
+        emit(f"s_cbranch_vccz L_q4_ret{cur}_%=")
+        slow_path(emit, cur, False)
+        emit(f"L_q4_ret{cur}_%=:")
+        emit("s_nop 7")
+        for U in (cur, cur + 2):
+            emit(f"s_cmp_eq_u32 s{S_RET}, {U}")
+            emit(f"s_cbranch_scc1 L_q4_e{4 + U}_%=")
+        emit("s_trap 2")
+    emit("L_q4_done_%=:")
+    emit("s_waitcnt vmcnt(0)")
+    emit("s_nop 15")  # the epilogue reads the O^T accumulators next
+    emit("s_nop 15")
+    return L
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "attn_q4_body.inc"), "w") as f:
+        for ln in gen():
+            f.write('"' + ln + '\\n\\t"\n')
+    clob = [f"v{r}" for r in list(range(0, VIN)) + list(range(VS, VS + 12))] + [f"a{r}" for r in range(KF, VF + 32)]
+    clob += [f"s{r}" for r in (S_T, S_END, S_KADV, S_VADV, S_THR, S_RET, S_X0, S_X1)]
+    with open(os.path.join(here, "attn_q4_regs.h"), "w") as f:
+        f.write("// generated by gen_attn_q4.py: the physical registers the body of attn_q4 owns\n#pragma once\n")
+        for name, cls, base, n in (("VIN", "v", VIN, 8), ("LRUN", "v", LRUN, 2), ("OT0", "a", OT, 32), ("OT1", "a", OT + 32, 32),
+                                   ("QF", "a", QF, 32), ("PTR", "s", S_KPTR, 4), ("SIN", "s", S_NT, 4)):
+            f.write(f'#define Q4_{name} "{{{cls}[{base}:{base + n - 1}]}}"\n')
+        f.write("#define Q4_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + ', "vcc", "scc", "m0", "memory"\n')
+
+
+if __name__ == "__main__":
+    main()

@@ -64,7 +64,10 @@ class HipDiagonalGaussianDistribution:
 
 
 class HipAutoencoderKLCogVideoX:
-    def __init__(self, cfg: VAEConfig = None, dtype=torch.bfloat16, device="cuda:0", force_simple=False):
+    def __init__(self, cfg: VAEConfig = None, dtype=torch.bfloat16, device="cuda:0", force_simple=False, with_encoder=True):
+        """with_encoder: also build the encoder half (AutoencoderKLCogVideoX always has one; src/video_generate.py:26-38 encodes the
+        reference image with it).  Every replica must be built the same way: the arenas of BOTH halves are what
+        dist.broadcast_components replicates, so a receiving rank can run `encode` without ever seeing a checkpoint."""
         cfg = cfg or VAEConfig()
         if dtype not in _lib.DTYPE_OF:
             raise _lib.S2VError(f"unsupported VAE dtype {dtype}")
@@ -89,7 +92,10 @@ class HipAutoencoderKLCogVideoX:
         self._h = ctypes.c_void_p()
         _lib.check(_lib.lib().s2v_vae_create(ctypes.byref(c), ctypes.byref(self._h)))
         self._cfg_c = c
-        self._enc = ctypes.c_void_p()  # encoder handle, created when `encoder.*` weights arrive
+        self._enc = ctypes.c_void_p()  # encoder handle (also created lazily when `encoder.*` weights arrive)
+        self._enc_loaded = False       # weights present: load_state_dict saw `encoder.*` keys, or a replica was marked loaded
+        if with_encoder:
+            _lib.check(_lib.lib().s2v_vae_enc_create(ctypes.byref(c), ctypes.byref(self._enc)))
 
     def close(self):
         lib = _lib.lib()
@@ -123,7 +129,10 @@ class HipAutoencoderKLCogVideoX:
         self.use_tiling = False
 
     def enable_slicing(self):
-        self.use_slicing = True  # batch slicing is a no-op for the single-video path (decode takes B = 1)
+        """AutoencoderKLCogVideoX.enable_slicing (:1070-1075) splits a BATCH of videos into single-video decodes; this object's
+        decode / encode take B = 1 (the pipeline's only use, pipeline_cogvideox.py:346-351), so the flag is recorded and has no
+        effect"""
+        self.use_slicing = True
 
     def disable_slicing(self):
         self.use_slicing = False
@@ -154,14 +163,19 @@ class HipAutoencoderKLCogVideoX:
         torch.cuda.synchronize(self.device)
         for pre in loaded:
             _lib.check(_lib.lib().s2v_vae_finalize(halves[pre]))
+        if "encoder." in loaded:
+            self._enc_loaded = True
 
     # ---- replicas: the weights of each half are one device range (dist.broadcast_components) ------------------------
-    def weight_arenas(self, with_encoder=False):
-        """list of uint8 CUDA tensors aliasing the packed weights: [decoder] or [decoder, encoder]"""
+    def weight_arenas(self, with_encoder=None):
+        """list of uint8 CUDA tensors aliasing the packed weights: [decoder, encoder], or [decoder] for an object built or asked
+        without the encoder half (with_encoder: None = whatever this object has, True = create the half if missing)"""
         from .engine import _ArenaView
 
         if with_encoder and not self._enc:
             _lib.check(_lib.lib().s2v_vae_enc_create(ctypes.byref(self._cfg_c), ctypes.byref(self._enc)))
+        if with_encoder is None:
+            with_encoder = bool(self._enc)
         out = []
         for h in [self._h] + ([self._enc] if with_encoder else []):
             p, n = ctypes.c_void_p(), ctypes.c_int64()
@@ -169,14 +183,19 @@ class HipAutoencoderKLCogVideoX:
             out.append(torch.as_tensor(_ArenaView(p.value, n.value), device=self.device))
         return out
 
-    def mark_weights_loaded(self, with_encoder=False):
+    def mark_weights_loaded(self, with_encoder=None):
+        """the receiving side of a replica hand-off: the same halves weight_arenas() listed now hold a sender's weights"""
+        if with_encoder is None:
+            with_encoder = bool(self._enc)
         for h in [self._h] + ([self._enc] if with_encoder else []):
             _lib.check(_lib.lib().s2v_vae_mark_weights_loaded(h))
+        if with_encoder:
+            self._enc_loaded = True
 
     def encode(self, x, return_dict=True):
         """AutoencoderKLCogVideoX.encode (:1205-1229) for the reference image: x [1,3,1,H,W] in [-1,1] ->
         `.latent_dist` whose `.sample(generator)` is the [1,C,1,h,w] draw (src/video_generate.py:35-37)."""
-        if not self._enc:
+        if not self._enc or not self._enc_loaded:
             raise _lib.S2VError("encode: no `encoder.*` weights were loaded into this VAE")
         if x.ndim != 5 or x.shape[0] != 1 or x.shape[2] != 1:
             raise NotImplementedError("encode takes ONE frame [1,3,1,H,W]: video encode is outside the path")

@@ -90,17 +90,24 @@ def test_two_rank_replicas_match_single_process():
 
 
 class FakeVAE:
-    """two arenas (decoder, encoder), like HipAutoencoderKLCogVideoX.weight_arenas(with_encoder=True)"""
+    """same replica protocol as HipAutoencoderKLCogVideoX: built with the encoder half by default, weight_arenas() /
+    mark_weights_loaded() called WITHOUT arguments (as dist.broadcast_components calls them) cover the halves the object has"""
 
-    def __init__(self):
-        self.dec, self.enc = torch.zeros(70001, dtype=torch.uint8), torch.zeros(513, dtype=torch.uint8)
-        self.loaded = False
+    def __init__(self, with_encoder=True):
+        self.dec = torch.zeros(70001, dtype=torch.uint8)
+        self.enc = torch.zeros(513, dtype=torch.uint8) if with_encoder else None
+        self.loaded, self.enc_loaded = False, False
 
-    def weight_arenas(self):
-        return [self.dec, self.enc]
+    def weight_arenas(self, with_encoder=None):
+        if with_encoder is None:
+            with_encoder = self.enc is not None
+        return [self.dec] + ([self.enc] if with_encoder else [])
 
-    def mark_weights_loaded(self):
+    def mark_weights_loaded(self, with_encoder=None):
+        if with_encoder is None:
+            with_encoder = self.enc is not None
         self.loaded = True
+        self.enc_loaded = self.enc_loaded or with_encoder
 
 
 def _worker_multi(rank, world, port, q):

@@ -1,6 +1,7 @@
 // Stand-alone A/B harness for the attention kernels of libs2v_hip_diag.so (no torch: starts in a second on a fresh GPU box).
 //   variants: 0 = product kernel (attn_pp_k), 1 = the same with stall accounting, 2 = round-1 lock-step kernel,
-//             4 = product kernel in its persistent, work-pulling launch (what the engine runs), 5 = 4 with accounting
+//             4 = product kernel in its persistent, work-pulling launch (what the engine runs), 5 = 4 with accounting,
+//             6 = four-wave kernel (attention_q4.hip) one workgroup per item, 7 = the same, persistent
 //   checks: every variant against attn_simple_k (fp32 math on the same bf16 inputs) on small / ragged shapes, with rare
 //           outliers and with a block of keys whose scores jump by ~+40 at a late tile (forces the deferred-maximum slow
 //           path after O and l have accumulated), and against the first variant at full size;
@@ -97,7 +98,9 @@ int main(int argc, char** argv) {
     int bad = 0;
     // ---- correctness on small / ragged shapes against the fp32-math kernel
     const int shapes[][3] = {{1, 2, 1250}, {2, 3, 64}, {1, 1, 65}, {1, 2, 700}, {2, 2, 19126 / 8}, {1, 1, 257}};
+    const bool time_only = getenv("HARNESS_TIME_ONLY") != nullptr;  // ablation builds: wrong results by construction
     for (auto& sh : shapes) {
+        if (time_only) break;
         for (float spike : {0.f, 6.f, -1.f}) {
             if (spike < 0.f && sh[2] < 600) continue;
             Bufs b = make(sh[0], sh[1], sh[2], 1.0f, spike < 0.f ? 0.f : spike);
