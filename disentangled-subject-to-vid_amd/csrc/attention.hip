@@ -1,9 +1,11 @@
 // Joint [text | ref-image | video] self-attention, head_dim 64, no mask
 // (replaces F.scaled_dot_product_attention at attention_processor.py:2083-2087).
 //
-//  attn_pp_k / attn_pp_persist_k : flash-attention forward on v_mfma_f32_32x32x16_bf16, eight waves in a two-group ping-pong (below);
-//     one workgroup per 256-row q-block (op-level launches) or one persistent workgroup per CU pulling q-blocks from per-XCD
-//     queues (the engine's launches).
+//  The bf16 product kernel is attn_q4 (attention_q4.hip: four waves, one per SIMD, generated asm): launch_attn_bf16 below dispatches to
+//     it -- one workgroup per 256-row q-block (op-level launches) or one persistent workgroup per CU pulling q-blocks from per-XCD
+//     queues (the engine's launches).  What follows in this file is compiled into the DIAGNOSTICS library only, as A/B references:
+//  attn_pp_k / attn_pp_persist_k : the round-2 product kernel, flash-attention forward on v_mfma_f32_32x32x16_bf16, eight waves in a
+//     two-group ping-pong (below); same launch forms; 5-6 % slower than attn_q4 on the same box (profiles/r03_attn_harness.txt).
 //     block = 8 waves x 32 query rows; KV tile = 64 keys; K tile [64 kv][64 d] and V^T tile [64 d][64 kv] are staged with
 //     LDS-DMA (global_load_lds) into a ring of XOR-swizzled LDS slots (same image as gemm.hip).
 //     QK^T is issued swapped (S^T = K . Q^T) so every lane owns ONE query row: row max / row sum / rescale are
@@ -23,6 +25,7 @@
 #define Q_BLOCK 128
 #define ATT_TILE_BYTES (64 * 64 * 2)  // 8 KiB
 
+#ifdef S2V_DIAG  // ---- A/B reference kernels (diagnostics library only) ----
 template <int NT>
 __device__ __forceinline__ void stage64(const bf16_t* __restrict__ g, size_t ld, char* lds, int tid) {
     // 64 rows x 128 B; 512 chunks of 16 B; 512 / NT rounds of NT threads.  The address is written as
@@ -57,7 +60,6 @@ __device__ __forceinline__ bf16x8 frag64(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + row * 128 + ((cl ^ ((row >> 1) & 7)) << 4));
 }
 
-#ifdef S2V_DIAG
 // round-1 lock-step kernel (A/B reference of tools/attn_harness); ABL is unused
 template <int ABL, int NW = 8>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int nqb) {
@@ -204,7 +206,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
             }
     }
 }
-#endif  // S2V_DIAG
 
 // ---------------------------------------------------------------------------------------------------
 // attn_pp_k: 8-wave PING-PONG flash attention.  Waves w and w + 4 share a SIMD; group A = waves 0-3, group B = waves 4-7, one
@@ -235,12 +236,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
 // MFMAs (+3 %) or in S (+4 %), dedicated loader waves (three waves per SIMD force 168 registers and drop the fragment
 // prefetch: +2 %), bounded scores with no maximum at all and the row sums on the matrix pipe (20 MFMA per tile: -1.5 %, not
 // worth its precondition).
-#ifdef S2V_DIAG
 __device__ long long g_attn_dbg[64];  // ACCT: per-wave s_memtime totals of block 100
 __device__ long long g_attn_blk[2 * 8192];  // ACCT: s_memrealtime at entry / exit of every workgroup (timeline of a launch)
 extern "C" __attribute__((visibility("default"))) int s2v_attn_debug_read_blocks(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_blk), sizeof(long long) * 2 * 8192) == hipSuccess ? 0 : -1; }
 extern "C" __attribute__((visibility("default"))) int s2v_attn_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
-#endif
 // one work item = the 256 query rows (wg % nqb) of (sample, head) wg / nqb; all eight waves enter and leave it together
 template <bool ACCT>
 __device__ __forceinline__ void attn_pp_item(const AttnArgs& a, int nqb, int wg, char* smem) {
@@ -248,9 +247,7 @@ __device__ __forceinline__ void attn_pp_item(const AttnArgs& a, int nqb, int wg,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int grp = wave >> 2;
     const int fr = lane & 31, hi = lane >> 5;
-#ifdef S2V_DIAG
     if (ACCT && tid == 0 && wg < 8192) g_attn_blk[2 * wg] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
     const int bh = wg / nqb, qb = wg - bh * nqb;
     const int b = bh / a.H, h = bh - b * a.H;
     const int D = a.H * 64;
@@ -438,13 +435,11 @@ __device__ __forceinline__ void attn_pp_item(const AttnArgs& a, int nqb, int wg,
             tacc[4] += u5 - u4;  // barrier after M
         }
     }
-#ifdef S2V_DIAG
     if (ACCT) {
         tacc[5] = now() - tl0;
         if (wg == 100 && lane == 0)
             for (int e = 0; e < 6; ++e) g_attn_dbg[wave * 8 + e] = tacc[e];
     }
-#endif
     if (!grp) __builtin_amdgcn_s_barrier();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -468,9 +463,7 @@ __device__ __forceinline__ void attn_pp_item(const AttnArgs& a, int nqb, int wg,
         u32x4 v = {rx[0], ry[0], rx[1], ry[1]};
         if (q_row < a.Ntok) *(u32x4*)(o + 8 * g) = v;
     }
-#ifdef S2V_DIAG
     if (ACCT && tid == 0 && wg < 8192) g_attn_blk[2 * wg + 1] = (long long)__builtin_amdgcn_s_memrealtime();
-#endif
 }
 
 // XCD-aware order of the work items: XCD x owns a contiguous range, so all q-blocks of one (sample, head) run on one XCD and its
@@ -527,8 +520,10 @@ __global__ __launch_bounds__(512, 2) void attn_pp_persist_k(const AttnArgs a, in
 }
 
 
+#endif  // S2V_DIAG
+
 #ifdef S2V_DIAG
-int g_attn_variant = 0;  // 0 = product kernel, 1 = product kernel with stall accounting, 2 = round-1 lock-step kernel (A/B reference)
+int g_attn_variant = 0;  // see launch_attn_bf16
 extern "C" __attribute__((visibility("default"))) int s2v_set_attn_variant(int v) { g_attn_variant = v; return 0; }
 static int* g_attn_queue = nullptr;  // harness: a queue for op-level launches (variants 4, 5 = persistent product / accounting kernel)
 static int g_attn_ncu = 0;
@@ -540,39 +535,38 @@ int launch_attn_bf16(const AttnArgs& a_in, hipStream_t st) {
     S2V_REQUIRE(a.vt != nullptr, "attn_bf16: V^T buffer missing");
     S2V_REQUIRE(a.ld_qkv % 8 == 0 && a.ntok_pad % 64 == 0, "attn_bf16: bad leading dims");
     S2V_REQUIRE(a.ntok_pad >= ((a.Ntok + 63) / 64) * 64, "attn_bf16: ntok_pad too small");
-    const int nqb8 = (a.Ntok + 255) / 256;  // eight waves x 32 query rows per block
+    const int nqb8 = (a.Ntok + 255) / 256;  // 256 query rows per work item
     const int total = nqb8 * a.B * a.H;
-    const dim3 g8(total), b8(512);
-    const void* fn = (const void*)attn_pp_k<false>;
-    size_t lds = 65536;
 #ifdef S2V_DIAG
-    if ((g_attn_variant == 4 || g_attn_variant == 5) && !a.queue) { a.queue = g_attn_queue; a.num_cus = g_attn_ncu; }
-#endif
-    bool persist = a.queue != nullptr && total > 2 * a.num_cus && a.num_cus >= 8;
-#ifdef S2V_DIAG
-    if (g_attn_variant == 1 || g_attn_variant == 5) fn = (const void*)attn_pp_k<true>;
-    if (g_attn_variant == 2) { fn = (const void*)attn_bf16_k<0, 8>; lds = 4 * ATT_TILE_BYTES; persist = false; }
-    if (g_attn_variant == 3) persist = false;  // the one-workgroup-per-item launch of the product kernel
-    if (g_attn_variant == 6 || g_attn_variant == 7) {  // four-wave kernel: per item / persistent
-        if (!a.queue) { a.queue = g_attn_queue; a.num_cus = g_attn_ncu; }
-        return launch_attn_q4(a, g_attn_variant == 7, st);
-    }
-#endif
-    if (persist) {
-        fn = (const void*)attn_pp_persist_k<false>;
-#ifdef S2V_DIAG
-        if (g_attn_variant == 1 || g_attn_variant == 5) fn = (const void*)attn_pp_persist_k<true>;
-#endif
+    // variants: 0 = product (attn_q4; persistent when the caller brought a queue), 3 = product, one workgroup per item,
+    //   4 = product, persistent on the harness queue, 6 / 7 = attn_q4 per item / persistent, 8 / 9 = attn_q8 (the same stream, eight
+    //   waves x 32 rows), 10 / 11 = attn_pp (round-2 kernel) per item / persistent, 1 / 5 = attn_pp with stall accounting, 2 = round-1 kernel
+    const int v = g_attn_variant;
+    if ((v == 4 || v == 5 || v == 7 || v == 9 || v == 11) && !a.queue) { a.queue = g_attn_queue; a.num_cus = g_attn_ncu; }
+    if (v == 3 || v == 6 || v == 8 || v == 10 || v == 1 || v == 2) a.queue = nullptr;
+    if (v == 8 || v == 9) return launch_attn_q8(a, v == 9, st);
+    if (v == 1 || v == 2 || v == 5 || v == 10 || v == 11) {
+        const dim3 g8(total), b8(512);
+        const void* fn = (v == 1) ? (const void*)attn_pp_k<true> : (const void*)attn_pp_k<false>;
+        size_t lds = 65536;
+        if (v == 2) { fn = (const void*)attn_bf16_k<0, 8>; lds = 4 * ATT_TILE_BYTES; }
+        if ((v == 5 || v == 11) && a.queue != nullptr) {
+            fn = (v == 5) ? (const void*)attn_pp_persist_k<true> : (const void*)attn_pp_persist_k<false>;
+            S2V_TRY(ensure_lds_attr(fn, 65536));
+            int* queue = a.queue;
+            void* args[] = {(void*)&a, (void*)&nqb8, (void*)&total, (void*)&queue};
+            S2V_CHECK_HIP(hipLaunchKernel(fn, dim3((a.num_cus / 8) * 8), b8, args, lds, st));
+            return 0;
+        }
         S2V_TRY(ensure_lds_attr(fn, 65536));
-        int* queue = a.queue;
-        void* args[] = {(void*)&a, (void*)&nqb8, (void*)&total, (void*)&queue};
-        S2V_CHECK_HIP(hipLaunchKernel(fn, dim3((a.num_cus / 8) * 8), b8, args, lds, st));
+        void* args[] = {(void*)&a, (void*)&nqb8};
+        S2V_CHECK_HIP(hipLaunchKernel(fn, g8, b8, args, lds, st));
         return 0;
     }
-    S2V_TRY(ensure_lds_attr(fn, 65536));
-    void* args[] = {(void*)&a, (void*)&nqb8};
-    S2V_CHECK_HIP(hipLaunchKernel(fn, g8, b8, args, lds, st));
-    return 0;
+#endif
+    // persistent (work-pulling) launch when the caller owns a queue and there is more than two rounds of work; else one workgroup per item
+    const bool persist = a.queue != nullptr && total > 2 * a.num_cus && a.num_cus >= 8;
+    return launch_attn_q4(a, persist, st);
 }
 
 // ---------------------------------------------------------------------------------------------------

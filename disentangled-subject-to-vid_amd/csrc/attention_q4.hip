@@ -52,8 +52,22 @@ typedef __attribute__((ext_vector_type(32))) float f32x32;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(32))) unsigned int u32x32;
 typedef __attribute__((ext_vector_type(8))) unsigned int u32x8;
-template <bool ACCT>
-__device__ __forceinline__ void attn_q4_item(const AttnArgs& a, int nqb, int wg, char* smem) {
+#ifdef S2V_DIAG
+__device__ unsigned long long g_qx_slow[2];
+extern "C" __attribute__((visibility("default"))) int s2v_attn_slow_read(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_qx_slow), 16) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z[2] = {0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_qx_slow), z, 16) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
+// JB = 32-row blocks per wave: 2 = attn_q4 (four waves x 64 rows, one per SIMD), 1 = attn_q8 (eight waves x 32 rows, two per SIMD, the
+// same fine-grained stream in both: gen_attn_q4.py)
+template <int JB>
+__device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg, char* smem) {
+    constexpr int NW = 8 / JB;  // waves per work item
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, hi = lane >> 5;
@@ -67,8 +81,8 @@ __device__ __forceinline__ void attn_q4_item(const AttnArgs& a, int nqb, int wg,
     const int nt = (a.Ntok + KV_TILE - 1) / KV_TILE;
     const unsigned lds0 = lds_base_u32(smem);
 
-    // staging: pieces `wave` and `wave + 4` of a tile (8 rows x 128 B each), lane = (row, 16-B chunk), chunk XOR on the SOURCE
-    // address ((row + 32) has the same XOR term: the second piece is the first one's lane offset + 32 rows)
+    // staging: a tile is eight pieces of 8 rows x 128 B; wave w stages piece w (and w + 4 when there are four waves), lane = (row,
+    // 16-B chunk), chunk XOR on the SOURCE address ((row + 32) has the same XOR term: the second piece is the lane offset + 32 rows)
     const int srow = wave * 8 + (lane >> 3);
     const int sc = (lane & 7) ^ ((srow >> 1) & 7);
     u32x8 vin;  // [0..3] fragment address of k-step kk in slot 0 (the 32-row half and the slot are immediates), [4..7] staging offsets
@@ -84,23 +98,22 @@ __device__ __forceinline__ void attn_q4_item(const AttnArgs& a, int nqb, int wg,
     auto k_src = [&](int t) __attribute__((always_inline)) { return Kg + (size_t)min(t, nt - 1) * k_tile_stride; };
     auto v_src = [&](int t) __attribute__((always_inline)) { return VTg + (size_t)min(t, nt - 1) * (KV_TILE * 2); };
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        glds16_saddr_m0(k_src(i), vin[4], m0w + i * 16384);
-        glds16_saddr_m0(k_src(i), vin[5], m0w + i * 16384 + 4096);
-    }
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        glds16_saddr_m0(v_src(i), vin[6], m0w + i * 16384 + 8192);
-        glds16_saddr_m0(v_src(i), vin[7], m0w + i * 16384 + 8192 + 4096);
-    }
+        for (int p = 0; p < JB; ++p) glds16_saddr_m0(k_src(i), vin[4 + p], m0w + i * 16384 + p * 4096);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < JB; ++p) glds16_saddr_m0(v_src(i), vin[6 + p], m0w + i * 16384 + 8192 + p * 4096);
 
-    // Q fragments of both row blocks, pre-multiplied by scale * log2(e) and rounded to bf16 once (as attn_pp_item); word 16 j + 4 kk
+    // Q fragments of the wave's row blocks, pre-multiplied by scale * log2(e) and rounded to bf16 once (as attn_pp_item); word 16 j + 4 kk
     const float c0 = a.scale * 1.4426950408889634f;
-    u32x32 qf;
-    int q_row[2];
+    typedef __attribute__((ext_vector_type(16 * JB))) unsigned int qf_t;
+    qf_t qf;
+    int q_row[JB];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        q_row[j] = qb * 256 + wave * 64 + j * 32 + fr;
+    for (int j = 0; j < JB; ++j) {
+        q_row[j] = qb * 256 + wave * (32 * JB) + j * 32 + fr;
         const int q_ld = min(q_row[j], a.Ntok - 1);
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -112,25 +125,39 @@ __device__ __forceinline__ void attn_q4_item(const AttnArgs& a, int nqb, int wg,
     u32x4 ptr, sin;  // sources of the next K / V^T tile to stage (64-bit each); nt, K tile stride, Ntok, LDS address of the wave's first piece
     {
         const unsigned long long kp = (unsigned long long)k_src(4), vp = (unsigned long long)v_src(2);
-        ptr[0] = (unsigned)kp; ptr[1] = (unsigned)(kp >> 32); ptr[2] = (unsigned)vp; ptr[3] = (unsigned)(vp >> 32);
-        ptr[0] = __builtin_amdgcn_readfirstlane(ptr[0]); ptr[1] = __builtin_amdgcn_readfirstlane(ptr[1]);
-        ptr[2] = __builtin_amdgcn_readfirstlane(ptr[2]); ptr[3] = __builtin_amdgcn_readfirstlane(ptr[3]);
+        ptr[0] = __builtin_amdgcn_readfirstlane((unsigned)kp); ptr[1] = __builtin_amdgcn_readfirstlane((unsigned)(kp >> 32));
+        ptr[2] = __builtin_amdgcn_readfirstlane((unsigned)vp); ptr[3] = __builtin_amdgcn_readfirstlane((unsigned)(vp >> 32));
         sin[0] = (unsigned)nt; sin[1] = k_tile_stride; sin[2] = (unsigned)a.Ntok; sin[3] = m0w;
     }
-    f32x32 OT[2];  // ot(j, db)[e] = OT[j][16 db + e]
+    f32x32 OT[JB];  // ot(j, db)[e] = OT[j][16 db + e]
     f32x2 LR;
+    unsigned slow_cnt;  // slow paths this wave took (diagnostics)
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    asm volatile(
+    if constexpr (JB == 2) {
+        asm volatile(
 #include "attn_q4_body.inc"
-        : "=" Q4_OT0(OT[0]), "=" Q4_OT1(OT[1]), "=" Q4_LRUN(LR), "+" Q4_PTR(ptr)
-        : Q4_QF(qf), Q4_VIN(vin), Q4_SIN(sin)
-        : Q4_CLOBBERS);
+            : "=" Q4_OT0(OT[0]), "=" Q4_OT1(OT[JB - 1]), "=" Q4_LRUN(LR), "+" Q4_PTR(ptr), "=" Q4_CNT(slow_cnt)
+            : Q4_QF(qf), Q4_VIN(vin), Q4_SIN(sin)
+            : Q4_CLOBBERS);
+    } else {
+        asm volatile(
+#include "attn_q8_body.inc"
+            : "=" Q8_OT0(OT[0]), "=" Q8_LRUN(LR), "+" Q8_PTR(ptr), "=" Q8_CNT(slow_cnt)
+            : Q8_QF(qf), Q8_VIN(vin), Q8_SIN(sin)
+            : Q8_CLOBBERS);
+    }
 
+#ifdef S2V_DIAG
+    if (lane == 0) {  // slow-path census of tools/attn_harness: (wave, tile) pairs that took the slow path / that ran
+        atomicAdd(&g_qx_slow[0], (unsigned long long)slow_cnt);
+        atomicAdd(&g_qx_slow[1], (unsigned long long)nt);
+    }
+#endif
     // epilogue: as attn_pp_item, once per row block
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < JB; ++j) {
         const float l_tot = LR[j] + __shfl_xor(LR[j], 32, 64);
         const float inv = 1.0f / l_tot;
         u32x2 og[8];
@@ -150,15 +177,15 @@ __device__ __forceinline__ void attn_q4_item(const AttnArgs& a, int nqb, int wg,
         }
     }
 }
-template <bool ACCT>
-__global__ __launch_bounds__(256, 1) void attn_q4_k(const AttnArgs a, int nqb) {
+template <int JB>
+__global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_k(const AttnArgs a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 slots][K tile | VT tile]
     int first, cnt;
     attn_xcd_range((int)gridDim.x, blockIdx.x & 7, first, cnt);
-    attn_q4_item<ACCT>(a, nqb, first + (int)(blockIdx.x >> 3), smem);
+    attn_qx_item<JB>(a, nqb, first + (int)(blockIdx.x >> 3), smem);
 }
-template <bool ACCT>
-__global__ __launch_bounds__(256, 1) void attn_q4_persist_k(const AttnArgs a, int nqb, int total, int* __restrict__ queue) {
+template <int JB>
+__global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const AttnArgs a, int nqb, int total, int* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_item;
     const int xcd = blockIdx.x & 7;
@@ -179,7 +206,7 @@ __global__ __launch_bounds__(256, 1) void attn_q4_persist_k(const AttnArgs a, in
         const int wg = s_item;
         __syncthreads();
         if (wg < 0) break;
-        attn_q4_item<ACCT>(a, nqb, wg, smem);
+        attn_qx_item<JB>(a, nqb, wg, smem);
     }
     if (threadIdx.x == 0) {
         __threadfence();
@@ -190,22 +217,25 @@ __global__ __launch_bounds__(256, 1) void attn_q4_persist_k(const AttnArgs a, in
     }
 }
 
-
-int launch_attn_q4(const AttnArgs& a, bool persistent, hipStream_t st) {
-    const int nqb = (a.Ntok + 255) / 256;  // four waves x 64 query rows per item
+template <int JB>
+static int launch_attn_qx(const AttnArgs& a, bool persistent, hipStream_t st) {
+    const int nqb = (a.Ntok + 255) / 256;  // 256 query rows per item in both forms
     const int total = nqb * a.B * a.H;
     const size_t lds = 65536;
+    const dim3 blk(64 * (8 / JB));
     if (persistent && a.queue != nullptr && a.num_cus >= 8) {
-        const void* fn = (const void*)attn_q4_persist_k<false>;
+        const void* fn = (const void*)attn_qx_persist_k<JB>;
         S2V_TRY(ensure_lds_attr(fn, 65536));
         int* queue = a.queue;
         void* args[] = {(void*)&a, (void*)&nqb, (void*)&total, (void*)&queue};
-        S2V_CHECK_HIP(hipLaunchKernel(fn, dim3((a.num_cus / 8) * 8), dim3(256), args, lds, st));
+        S2V_CHECK_HIP(hipLaunchKernel(fn, dim3((a.num_cus / 8) * 8), blk, args, lds, st));
         return 0;
     }
-    const void* fn = (const void*)attn_q4_k<false>;
+    const void* fn = (const void*)attn_qx_k<JB>;
     S2V_TRY(ensure_lds_attr(fn, 65536));
     void* args[] = {(void*)&a, (void*)&nqb};
-    S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(total), dim3(256), args, lds, st));
+    S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(total), blk, args, lds, st));
     return 0;
 }
+int launch_attn_q4(const AttnArgs& a, bool persistent, hipStream_t st) { return launch_attn_qx<2>(a, persistent, st); }
+int launch_attn_q8(const AttnArgs& a, bool persistent, hipStream_t st) { return launch_attn_qx<1>(a, persistent, st); }

@@ -10,7 +10,11 @@ shuttling tuples through AGPRs; the loop is issue-bound (about six fillers per M
 A first version kept the rare paths in C++ and left the asm at the checks: the register shuffling and scratch spills hipcc put
 around each exit cost 3.8 ms of a 10.9 ms launch, so everything between the prologue's DMA and the epilogue is in here.
 
-Register file (per lane):
+Two forms from one generator (Q4_JB = 32-row blocks per wave): JB = 2 -> attn_q4, four waves x 64 rows, one wave per SIMD, a K / V^T
+fragment feeds two MFMAs; JB = 1 -> attn_q8, eight waves x 32 rows, two waves per SIMD running the SAME fine-grained stream
+(MFMA, five fillers, MFMA ...) side by side -- a lone wave issues one VALU per 4.9 cycles (8.9 for v_exp_f32), so at head
+dimension 64 (16 MFMA = 512 matrix-pipe cycles against 80 softmax VALU per 32 rows) one wave per SIMD is issue-bound.
+Register file (per lane; numbers for JB = 2, the JB = 1 map is the same list packed):
   v[0:127]    S^T accumulators st[buf][j][kb] (16 each): buf = tile parity, j = 32-row block, kb = 32-key half
   v[128:159]  -m of the rows of block j (16 copies: the C operand of the first MFMA of a chain)
   v[160:191]  P as bf16 pairs pk[j][s] (4 each): B operand of the P.V step s (16 keys)
@@ -22,17 +26,34 @@ Register file (per lane):
   s[36:37] IN: K source, s[38:39] IN: V^T source (next tile to stage: K(4), V^T(2), clamped)
   s44 IN: nt, s45 IN: K tile stride (bytes), s46 IN: Ntok, s47 IN: LDS address of the wave's first piece in slot 0
   s40 t, s41 end of the current phase, s42 / s43 K / V^T source advance per iteration, s48 threshold (f32 bits), s49 return position,
-  s[50:51] scratch
+  s[50:51] scratch, s52 OUT: slow paths taken
 Phases: A = iterations t < nt - 5 (threshold 2^13: a check fires only for a genuine slow path); B = the last five (threshold -1:
 every check enters the rare-path handler, which applies the staging clamp, the tail mask and the real threshold).
 """
 import os
+import sys
 
-ST, NEGM, PK, TMP, PS, VIN, LRUN = 0, 128, 160, 192, 200, 208, 216
-VS = 218  # scratch v218..v229
-OT, QF, KF, VF = 0, 64, 96, 128
-S_KPTR, S_VPTR, S_T, S_END, S_KADV, S_VADV, S_NT, S_KSTR, S_NTOK, S_M0W, S_THR, S_RET, S_X0, S_X1 = 36, 38, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51
+JB = 2  # set by main() per output
+ORDER = os.environ.get("Q4_ORDER", "")  # placement experiments
+READPOS = os.environ.get("Q4_READPOS", "first")  # fragment read first in its gap: -3 % against last (A/B, profiles/r03_attn_q4_placement.txt)
+READS = os.environ.get("Q4_READS", "")
+DMAPOS = os.environ.get("Q4_DMAPOS", "")
+SPLIT = os.environ.get("Q4_SPLIT", "")
 ABLATE = set(filter(None, os.environ.get("Q4_ABLATE", "").split(",")))  # timing experiments only (results are wrong)
+S_KPTR, S_VPTR, S_T, S_END, S_KADV, S_VADV, S_NT, S_KSTR, S_NTOK, S_M0W, S_THR, S_RET, S_X0, S_X1, S_CNT = 36, 38, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52
+
+
+def layout(jb):
+    global JB, ST, NEGM, PK, TMP, PS, VIN, LRUN, VS, OT, QF, KF, VF, NM
+    JB = jb
+    ST, NEGM, PK, TMP = 0, 64 * jb, 80 * jb, 96 * jb
+    PS = TMP + 8
+    VIN = PS + 4 * jb
+    LRUN = VIN + 8
+    VS = LRUN + 2          # scratch: 12 registers
+    OT, QF, KF = 0, 32 * jb, 48 * jb
+    VF = KF + 32
+    NM = 8 * jb            # MFMAs per segment
 
 
 def vr(base, n=1):
@@ -44,11 +65,11 @@ def ar(base, n=1):
 
 
 def st(buf, j, kb):
-    return ST + 64 * buf + 32 * j + 16 * kb
+    return ST + 32 * JB * buf + 32 * j + 16 * kb
 
 
 def ps(sset, j, x):
-    return PS + 4 * sset + 2 * j + x
+    return PS + 2 * JB * sset + 2 * j + x
 
 
 def pk(j, s):
@@ -60,7 +81,7 @@ def tmp(g, x):
 
 
 def soft_stream(sb, kb, sset):
-    """80 ops turning half kb of the scores in st[sb] into P: groups g of four values (row block g >> 2, accumulator elements
+    """40 JB ops turning half kb of the scores in st[sb] into P: groups g of four values (row block g >> 2, accumulator elements
     4 (g & 3) ..); exp2 of group g interleaved with the row-sum adds and the two v_cvt_pk of group g - 1."""
     def exp(g, x):
         return f"v_exp_f32 {vr(tmp(g, x))}, {vr(st(sb, g >> 2, kb) + (g & 3) * 4 + x)}"
@@ -76,12 +97,32 @@ def soft_stream(sb, kb, sset):
         dst = pk(g >> 2, kb * 2 + (e0 >> 3)) + ((e0 & 7) >> 1) + c
         return f"v_cvt_pk_bf16_f32 {vr(dst)}, {vr(tmp(g, 2 * c))}, {vr(tmp(g, 2 * c + 1))}"
 
-    ops = [exp(0, x) for x in range(4)]
-    for g in range(1, 8):
-        ops += [exp(g, 0), exp(g, 1), add(g - 1, 0), add(g - 1, 1), exp(g, 2), exp(g, 3), add(g - 1, 2), add(g - 1, 3),
-                cvt(g - 1, 0), cvt(g - 1, 1)]
-    ops += [add(7, x) for x in range(4)] + [cvt(7, 0), cvt(7, 1)]
-    assert len(ops) == 80
+    ng = 4 * JB
+    if ORDER == "uniform":  # every gap of five = [exp, add, exp, add, cvt]: two exp2 per gap; adds / cvt belong to the group before
+        ops = []
+        for g in range(ng + 1):
+            for h in range(2):
+                if g < ng:
+                    ops.append(exp(g, 2 * h))
+                if g > 0:
+                    ops.append(add(g - 1, 2 * h))
+                if g < ng:
+                    ops.append(exp(g, 2 * h + 1))
+                if g > 0:
+                    ops.append(add(g - 1, 2 * h + 1))
+                    ops.append(cvt(g - 1, h))
+    elif ORDER == "explast":  # per pair of gaps: [add add cvt cvt exp][add add exp exp exp]: exp2 at the END of a gap
+        ops = [exp(0, x) for x in range(4)]
+        for g in range(1, ng):
+            ops += [add(g - 1, 0), add(g - 1, 1), cvt(g - 1, 0), add(g - 1, 2), add(g - 1, 3), cvt(g - 1, 1), exp(g, 0), exp(g, 1), exp(g, 2), exp(g, 3)]
+        ops += [add(ng - 1, x) for x in range(4)] + [cvt(ng - 1, 0), cvt(ng - 1, 1)]
+    else:
+        ops = [exp(0, x) for x in range(4)]
+        for g in range(1, ng):
+            ops += [exp(g, 0), exp(g, 1), add(g - 1, 0), add(g - 1, 1), exp(g, 2), exp(g, 3), add(g - 1, 2), add(g - 1, 3),
+                    cvt(g - 1, 0), cvt(g - 1, 1)]
+        ops += [add(ng - 1, x) for x in range(4)] + [cvt(ng - 1, 0), cvt(ng - 1, 1)]
+    assert len(ops) == 40 * JB
     return ops
 
 
@@ -92,20 +133,36 @@ def frag_read(dst_base, i, slot, is_v):
 
 
 def qk_mfma(buf, i):
-    kk, kb, j = i >> 2, (i >> 1) & 1, i & 1
+    j, kb, kk = i % JB, (i // JB) & 1, i // (2 * JB)
     d = vr(st(buf, j, kb), 16)
     c = vr(NEGM + 16 * j, 16) if kk == 0 else d
     return f"v_mfma_f32_32x32x16_bf16 {d}, {ar(KF + 4 * (kk * 2 + kb), 4)}, {ar(QF + 16 * j + 4 * kk, 4)}, {c}"
 
 
+def pv_mfma(i):
+    db, j, s = i & 1, (i >> 1) % JB, i // (2 * JB)
+    d = ar(OT + 32 * j + 16 * db, 16)
+    return f"v_mfma_f32_32x32x16_bf16 {d}, {ar(VF + 4 * (s * 2 + db), 4)}, {vr(pk(j, s), 4)}, {d}"
+
+
+def max_ps(emit, cur):
+    """v[VS] = maximum of the partial row sums of tile set `cur`"""
+    regs = [ps(cur, j, x) for j in range(JB) for x in range(2)]
+    if len(regs) == 2:
+        emit(f"v_max_f32 {vr(VS)}, {vr(regs[0])}, {vr(regs[1])}")
+    else:
+        emit(f"v_max3_f32 {vr(VS)}, {vr(regs[0])}, {vr(regs[1])}, {vr(regs[2])}")
+        emit(f"v_max_f32 {vr(VS)}, {vr(VS)}, {vr(regs[3])}")
+
+
 def slow_path(emit, cur, first):
-    """raise the running maximum of both row blocks to the true maximum of the tile in st[cur], rescale everything at the old
+    """raise the running maximum of the row blocks to the true maximum of the tile in st[cur], rescale everything at the old
     scale, redo P and the row sums of the whole tile; S of the next tile (other buffer) was computed against the old maximum and
     is shifted as well.  first: tile 0 adopts its maximum (O and l are zero, exp2(-d) could overflow) and only the first half of
     P(0) is built: segment 1 of iteration 0 builds the second half, as for every tile"""
     nxt = cur ^ 1
-    vA, vB, vD, vAl, T = VS, VS + 1, VS + 2, VS + 3, VS + 4  # T: 8 temporaries v222..v229
-    for j in range(2):
+    vA, vB, vD, vAl, T = VS, VS + 1, VS + 2, VS + 3, VS + 4  # T: 8 temporaries
+    for j in range(JB):
         s = [st(cur, j, 0) + e for e in range(16)] + [st(cur, j, 1) + e for e in range(16)]
         emit(f"v_max3_f32 {vr(vA)}, {vr(s[0])}, {vr(s[1])}, {vr(s[2])}")
         for x in range(3, 31, 2):
@@ -166,13 +223,14 @@ def mask_tile(emit, buf, s_kv0):
         for e in range(16):
             c = kb * 32 + (e & 3) + 8 * (e >> 2)
             emit(f"v_cmp_ge_i32 vcc, {c}, {vr(vBase)}")
-            for j in range(2):
+            for j in range(JB):
                 r = st(buf, j, kb) + e
                 emit(f"v_cndmask_b32 {vr(r)}, {vr(r)}, {vr(vInf)}, vcc")
 
 
 def gen():
     L = []
+    ctx = set()
 
     def emit(ln):
         op = ln.split()[0]
@@ -190,17 +248,30 @@ def gen():
             return
         if "nomfma" in ABLATE and op.startswith("v_mfma"):
             return
+        if "noadd" in ABLATE and (op == "v_add_f32" or (op == "v_mov_b32" and "main" in ctx)):  # row sums off the VALU (timing of a sum-by-MFMA form)
+            return
         L.append(ln)
 
-    emit("; ---- attn_q4 body (generated by gen_attn_q4.py; do not edit)")
+    def soft_lo(i):  # first softmax op of gap i: five per gap, or (SPLIT = "64") six in gaps without a fragment read and four in those with one
+        if SPLIT == "64" and JB == 2:
+            return 5 * i + (i & 1)
+        return 5 * i
+
+    # where the extra fillers of a segment go (gap index -> instruction), besides five softmax ops per gap
+    gap_m0 = [3, 9] if JB == 2 else [2]     # M0 <- LDS address of the wave's piece p
+    gap_dma = [5, 11] if JB == 2 else [4]   # the piece's LDS-DMA (at least one instruction after the M0 write)
+    read_gaps = range(0, NM, JB) if READS != "front" else range(8)            # eight fragment reads per segment
+
+    emit(f"; ---- attn_q{8 // JB} body (generated by gen_attn_q4.py; do not edit)")
     # ---------------- state
-    for r in range(64):
+    for r in range(32 * JB):
         emit(f"v_accvgpr_write_b32 {ar(OT + r)}, 0")
-    for r in range(32):
+    for r in range(16 * JB):
         emit(f"v_mov_b32 {vr(NEGM + r)}, 0")
-    emit(f"v_mov_b32 {vr(LRUN)}, 0")
-    emit(f"v_mov_b32 {vr(LRUN + 1)}, 0")
+    for j in range(JB):
+        emit(f"v_mov_b32 {vr(LRUN + j)}, 0")
     emit(f"s_mov_b32 s{S_T}, 0")
+    emit(f"s_mov_b32 s{S_CNT}, 0")               # OUT: slow paths taken by this wave (diagnostics)
     emit(f"s_mov_b32 s{S_THR}, 0x46000000")      # 8192.0
     emit(f"s_mov_b32 s{S_KADV}, s{S_KSTR}")
     emit(f"s_mov_b32 s{S_VADV}, 128")
@@ -215,7 +286,7 @@ def gen():
     for i in range(8):
         emit(frag_read(KF, i, 0, False))
     emit("s_waitcnt lgkmcnt(0)")
-    for i in range(16):
+    for i in range(NM):
         emit(qk_mfma(0, i))
     for i in range(8):
         emit(frag_read(KF, i, 1, False))
@@ -229,32 +300,28 @@ def gen():
     slow_path(emit, 0, True)
     emit("s_branch L_q4_e0_%=")
     # ---------------- main loop, unrolled over four tiles (U = t mod 4: st buffers and LDS slots are immediates)
+    ctx.add("main")
     for U in range(4):
         cur, nxt = U & 1, (U & 1) ^ 1
         # segment 1: S(t+1) = K(t+1).Q^T -> st[nxt]; second half of P(t); V^T(t) fragments; K(t+4) pieces
         emit(f"L_q4_e{U}_%=:")
         emit("s_waitcnt lgkmcnt(0)")
         soft = soft_stream(cur, 1, cur)
-        for i in range(16):
-            emit(qk_mfma(nxt, i))
-            for op in soft[5 * i:5 * i + 5]:
-                emit(op)
-            if i % 2 == 0:
-                emit(frag_read(VF, i >> 1, U, True))
-            if i == 3:
-                emit(f"s_add_u32 m0, s{S_M0W}, {U * 16384}")
-            if i == 5:
-                emit(f"global_load_lds_dwordx4 {vr(VIN + 4)}, s[{S_KPTR}:{S_KPTR + 1}]")
-            if i == 9:
-                emit(f"s_add_u32 m0, s{S_M0W}, {U * 16384 + 4096}")
-            if i == 11:
-                emit(f"global_load_lds_dwordx4 {vr(VIN + 5)}, s[{S_KPTR}:{S_KPTR + 1}]")
-            if i == 14:
-                emit(f"s_add_u32 s{S_KPTR}, s{S_KPTR}, s{S_KADV}")
-                emit(f"s_addc_u32 s{S_KPTR + 1}, s{S_KPTR + 1}, 0")
-        # check of tile t: the four partial row sums against the threshold (any lane)
-        emit(f"v_max3_f32 {vr(VS)}, {vr(ps(cur, 0, 0))}, {vr(ps(cur, 0, 1))}, {vr(ps(cur, 1, 0))}")
-        emit(f"v_max_f32 {vr(VS)}, {vr(VS)}, {vr(ps(cur, 1, 1))}")
+        for i in range(NM):
+            first, last = [], []
+            if i in read_gaps:
+                (first if READPOS == "first" else last).append(frag_read(VF, list(read_gaps).index(i), U, True))
+            for p in range(JB):
+                if i == gap_m0[p]:
+                    last.append(f"s_add_u32 m0, s{S_M0W}, {U * 16384 + p * 4096}")
+                if i == gap_dma[p]:
+                    (first if DMAPOS == "first" else last).append(f"global_load_lds_dwordx4 {vr(VIN + 4 + p)}, s[{S_KPTR}:{S_KPTR + 1}]")
+            if i == NM - 2:
+                last += [f"s_add_u32 s{S_KPTR}, s{S_KPTR}, s{S_KADV}", f"s_addc_u32 s{S_KPTR + 1}, s{S_KPTR + 1}, 0"]
+            for ln in [qk_mfma(nxt, i)] + first + soft[soft_lo(i):soft_lo(i + 1)] + last:
+                emit(ln)
+        # check of tile t: the partial row sums against the threshold (any lane)
+        max_ps(emit, cur)
         emit(f"v_cmp_nge_f32 vcc, s{S_THR}, {vr(VS)}")  # row sum > threshold, or NaN
         emit(f"s_cbranch_vccnz L_q4_x{U}_%=")
         # segment 2: O += V^T(t).P(t); first half of P(t+1); K(t+2) fragments; V^T(t+2) pieces; l += row sums of t
@@ -262,35 +329,35 @@ def gen():
         emit("s_waitcnt lgkmcnt(0)")
         soft = soft_stream(nxt, 0, nxt)
         slot2 = (U + 2) & 3
-        ladd = {1: (0, 0), 7: (0, 1), 13: (1, 0), 15: (1, 1)}
-        for i in range(16):
-            s, j, db = i >> 2, (i >> 1) & 1, i & 1
-            d = ar(OT + 32 * j + 16 * db, 16)
-            emit(f"v_mfma_f32_32x32x16_bf16 {d}, {ar(VF + 4 * (s * 2 + db), 4)}, {vr(pk(j, s), 4)}, {d}")
-            for op in soft[5 * i:5 * i + 5]:
-                emit(op)
-            if i % 2 == 0:
-                emit(frag_read(KF, i >> 1, slot2, False))
+        ladd = {1: (0, 0), 7: (0, 1), 13: (1, 0), 15: (1, 1)} if JB == 2 else {1: (0, 0), 7: (0, 1)}
+        for i in range(NM):
+            first, last = [], []
+            if i in read_gaps:
+                (first if READPOS == "first" else last).append(frag_read(KF, list(read_gaps).index(i), slot2, False))
             if i in ladd:
                 jj, x = ladd[i]
-                emit(f"v_add_f32 {vr(LRUN + jj)}, {vr(LRUN + jj)}, {vr(ps(cur, jj, x))}")
-            if i == 3:
-                emit(f"s_add_u32 m0, s{S_M0W}, {slot2 * 16384 + 8192}")
-            if i == 5:
-                emit(f"global_load_lds_dwordx4 {vr(VIN + 6)}, s[{S_VPTR}:{S_VPTR + 1}]")
-            if i == 9:
-                emit(f"s_add_u32 m0, s{S_M0W}, {slot2 * 16384 + 8192 + 4096}")
-            if i == 11:
-                emit(f"global_load_lds_dwordx4 {vr(VIN + 7)}, s[{S_VPTR}:{S_VPTR + 1}]")
+                last.append(f"v_add_f32 {vr(LRUN + jj)}, {vr(LRUN + jj)}, {vr(ps(cur, jj, x))}")
+            for p in range(JB):
+                if i == gap_m0[p]:
+                    last.append(f"s_add_u32 m0, s{S_M0W}, {slot2 * 16384 + 8192 + p * 4096}")
+                if i == gap_dma[p]:
+                    (first if DMAPOS == "first" else last).append(f"global_load_lds_dwordx4 {vr(VIN + 6 + p)}, s[{S_VPTR}:{S_VPTR + 1}]")
+            extra = []
+            if "summfma" in ABLATE and (i & 1) == 1:  # timing only: one more MFMA per (row block, k-step), as a sum-by-MFMA form would issue
+                jx = (i >> 1) % JB
+                extra = [f"v_mfma_f32_32x32x16_bf16 {ar(VF + 32 + 16 * jx, 16)}, {ar(VF + 64, 4)}, {vr(pk(jx, i // (2 * JB)), 4)}, {ar(VF + 32 + 16 * jx, 16)}"]
+            for ln in [pv_mfma(i)] + first + soft[soft_lo(i):soft_lo(i + 1)] + last + extra:
+                emit(ln)
         emit(f"s_add_u32 s{S_VPTR}, s{S_VPTR}, s{S_VADV}")
         emit(f"s_addc_u32 s{S_VPTR + 1}, s{S_VPTR + 1}, 0")
-        emit("s_waitcnt vmcnt(4)")
+        emit(f"s_waitcnt vmcnt({2 * JB})")
         emit("s_barrier")
         emit(f"s_add_u32 s{S_T}, s{S_T}, 1")
         emit(f"s_cmp_lt_u32 s{S_T}, s{S_END}")
         emit("s_cbranch_scc0 L_q4_phase_%=")
         if U == 3:
             emit("s_branch L_q4_e0_%=")
+    ctx.discard("main")
     # ---------------- end of a phase: A -> B (threshold -1, no more K advance), or finished
     emit("L_q4_phase_%=:")
     emit(f"s_cmp_ge_u32 s{S_T}, s{S_NT}")
@@ -323,11 +390,11 @@ def gen():
         emit(f"s_cbranch_scc0 L_q4_nomask{1 + cur}_%=")
         mask_tile(emit, nxt, S_X0)
         emit(f"L_q4_nomask{1 + cur}_%=:")
-        emit(f"v_max3_f32 {vr(VS)}, {vr(ps(cur, 0, 0))}, {vr(ps(cur, 0, 1))}, {vr(ps(cur, 1, 0))}")
-        emit(f"v_max_f32 {vr(VS)}, {vr(VS)}, {vr(ps(cur, 1, 1))}")
+        max_ps(emit, cur)
         emit(f"s_mov_b32 s{S_X0}, 0x46000000")
         emit(f"v_cmp_nge_f32 vcc, s{S_X0}, {vr(VS)}")
         emit(f"s_cbranch_vccz L_q4_ret{cur}_%=")
+        emit(f"s_add_u32 s{S_CNT}, s{S_CNT}, 1")
         slow_path(emit, cur, False)
         emit(f"L_q4_ret{cur}_%=:")
         emit("s_nop 7")
@@ -344,17 +411,20 @@ def gen():
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
-    with open(os.path.join(here, "attn_q4_body.inc"), "w") as f:
-        for ln in gen():
-            f.write('"' + ln + '\\n\\t"\n')
-    clob = [f"v{r}" for r in list(range(0, VIN)) + list(range(VS, VS + 12))] + [f"a{r}" for r in range(KF, VF + 32)]
-    clob += [f"s{r}" for r in (S_T, S_END, S_KADV, S_VADV, S_THR, S_RET, S_X0, S_X1)]
     with open(os.path.join(here, "attn_q4_regs.h"), "w") as f:
-        f.write("// generated by gen_attn_q4.py: the physical registers the body of attn_q4 owns\n#pragma once\n")
-        for name, cls, base, n in (("VIN", "v", VIN, 8), ("LRUN", "v", LRUN, 2), ("OT0", "a", OT, 32), ("OT1", "a", OT + 32, 32),
-                                   ("QF", "a", QF, 32), ("PTR", "s", S_KPTR, 4), ("SIN", "s", S_NT, 4)):
-            f.write(f'#define Q4_{name} "{{{cls}[{base}:{base + n - 1}]}}"\n')
-        f.write("#define Q4_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + ', "vcc", "scc", "m0", "memory"\n')
+        f.write("// generated by gen_attn_q4.py: the physical registers the bodies of attn_q4 (JB = 2) / attn_q8 (JB = 1) own\n#pragma once\n")
+        for jb, name in ((2, "Q4"), (1, "Q8")):
+            layout(jb)
+            with open(os.path.join(here, f"attn_{name.lower()}_body.inc"), "w") as g:
+                for ln in gen():
+                    g.write('"' + ln + '\\n\\t"\n')
+            clob = [f"v{r}" for r in list(range(0, VIN)) + list(range(VS, VS + 12))] + [f"a{r}" for r in range(KF, VF + 32)]
+            clob += [f"s{r}" for r in (S_T, S_END, S_KADV, S_VADV, S_THR, S_RET, S_X0, S_X1)]
+            for nm, cls, base, n in [("VIN", "v", VIN, 8), ("LRUN", "v", LRUN, 2), ("QF", "a", QF, 16 * jb), ("PTR", "s", S_KPTR, 4),
+                                     ("SIN", "s", S_NT, 4)] + [(f"OT{j}", "a", OT + 32 * j, 32) for j in range(jb)]:
+                f.write(f'#define {name}_{nm} "{{{cls}[{base}:{base + n - 1}]}}"\n')
+            f.write(f'#define {name}_CNT "{{s{S_CNT}}}"\n')
+            f.write(f"#define {name}_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + ', "vcc", "scc", "m0", "memory"\n')
 
 
 if __name__ == "__main__":

@@ -85,6 +85,8 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t st);
 int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st);
 // four-wave form of the bf16 kernel (attention_q4.hip); persistent needs a.queue / a.num_cus
 int launch_attn_q4(const AttnArgs& a, bool persistent, hipStream_t st);
+// eight waves x 32 rows running the same fine-grained stream, two waves per SIMD
+int launch_attn_q8(const AttnArgs& a, bool persistent, hipStream_t st);
 
 // ---- elementwise / normalisation ------------------------------------------------
 // LayerNorm(eps, affine w,b) then (1+scale)*y+shift with per-row-range modulation sets.

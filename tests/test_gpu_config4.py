@@ -1,0 +1,156 @@
+"""BASELINE.json configs[4] AS A WORKLOAD: "CogVideoX-5B fp8 (CDNA4 fp8 MFMA) weights, 49 frames 720x1280" -- latent 13 x 90 x 160,
+N = 226 + 3600 + 46800 = 50626 tokens per sample, M = 101252 GEMM rows for the CFG pair.  What only this geometry exercises:
+the M = 101252 launches and their row-tail split (api.hip), the workspace carving at that size, the persistent attention queue at
+198 q-blocks x 96 heads, and the 4 x 5 = 20 tiles of the tiled VAE decode (autoencoder_kl_cogvideox.py:1102-1114,1400-1406).
+
+  * one CogVideoXBlock at N = 50626, B = 2, through s2v_block_forward on the bf16 MFMA path against
+    oracle.transformer_ref.block_forward (cogvideox_transformer_3d.py:122-186) -- relative L2 <= 2e-2, max-abs <= 6e-2 * max|ref|;
+  * the fp8 engine (weight_format = "fp8": parity unpinned, the reference has no fp8 path) at the full geometry, 2 layers: finite,
+    CFG-symmetric, deterministic, graph replay == eager, and within 5e-2 relative L2 of the bf16 engine on the same weights;
+  * the tiled VAE decode at 13 x 90 x 160: the real-width decoder finite / deterministic / (1,3,49,720,1280), and a narrow decoder
+    (8, 8, 16, 16 channels) against oracle.vae_ref.decode_latents at the SAME tile geometry (20 tiles, blends both ways, two frame
+    batches), fp32 <= 1e-3.
+"""
+import copy
+import time
+
+import pytest
+import torch
+
+from oracle import transformer_ref as tr
+from oracle import vae_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+F4, H4, W4, T4 = 13, 90, 160, 226  # 49 frames 720 x 1280
+N4 = T4 + (H4 // 2) * (W4 // 2) * (1 + F4)
+
+
+def rel_l2(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def test_config4_one_block_50626_tokens_vs_oracle(s2v):
+    assert N4 == 50626
+    cfg = s2v.cogvideox_5b()
+    cfg.num_layers = 1
+    D, heads = cfg.inner_dim, cfg.num_attention_heads
+    R = (H4 // 2) * (W4 // 2)
+    V = F4 * R
+    B, dt = 2, torch.bfloat16
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=41, parity=True)
+    sd = {k: v.to(dt).float() for k, v in sd.items()}  # the oracle sees exactly the values the device holds
+    g = torch.Generator().manual_seed(42)
+    h = torch.randn(B, V, D, generator=g).to(dt).float()
+    e0 = torch.randn(B, T4, D, generator=g).to(dt).float()
+    e1 = torch.randn(B, R, D, generator=g).to(dt).float()
+    temb = torch.randn(B, cfg.time_embed_dim, generator=g).to(dt).float()
+    ref_rope, rope = tr.pipeline_rope(H4 * 8, W4 * 8, F4)
+    t0 = time.time()
+    with torch.no_grad():
+        exp = tr.block_forward(sd, "transformer_blocks.0.", heads, h, e0, e1, temb, rope, ref_rope)
+    t_cpu = time.time() - t0
+    m = s2v.HipCogVideoXTransformer3DModel(cfg, dt, DEV)
+    m.load_state_dict(sd)
+    kw = dict(image_rotary_emb=tuple(x.to(DEV) for x in rope), ref_image_rotary_emb=tuple(x.to(DEV) for x in ref_rope))
+    got = m.transformer_blocks[0](hidden_states=h.to(DEV, dt), encoder_hidden_states=e0.to(DEV, dt), temb=temb.to(DEV, dt),
+                                  enc_hidden_states1=e1.to(DEV, dt), embed_ref_img=True, ref_img_seq_start=T4,
+                                  ref_img_seq_end=T4 + R, position_delta=0, timestep=None, layer=0, **kw)
+    torch.cuda.synchronize()
+    for name, y, e in zip(("video", "text", "ref"), got, exp):
+        y = y.float().cpu()
+        assert torch.isfinite(y).all(), name
+        r, err = rel_l2(y, e), (y - e).abs().max().item()
+        assert r <= 2e-2 and err <= 6e-2 * e.abs().max().item(), f"{name}: rel-l2 {r}, max-abs {err}"
+    print(f"configs[4] block: oracle took {t_cpu:.1f} s on the host cores")
+
+
+def _engine_forward(s2v, cfg, sd, lat, text, ref, t):
+    m = s2v.HipCogVideoXTransformer3DModel(cfg, torch.bfloat16, DEV)
+    m.load_state_dict(sd)
+    eng = m.engine
+    eng.set_geometry(2, text.shape[1], lat.shape[1], lat.shape[3], lat.shape[4])
+    eng.prepare_tables(lat.shape[3] * 8, lat.shape[4] * 8)
+    eng.set_conditioning(text, ref)
+    y = eng.forward(lat, torch.tensor([t, t]), shared_latent=True)
+    torch.cuda.synchronize()
+    return m, y
+
+
+def test_config4_fp8_engine_full_geometry(s2v):
+    cfg = s2v.cogvideox_5b()
+    cfg.num_layers = 2
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=43, device=DEV, parity=True)
+    g = torch.Generator(device=DEV).manual_seed(44)
+    t1 = torch.randn(1, T4, 4096, generator=g, device=DEV)
+    text = torch.cat([t1, t1])
+    ref = torch.randn(1, 1, 16, H4, W4, generator=g, device=DEV) * 0.7
+    lat = torch.randn(1, F4, 16, H4, W4, generator=g, device=DEV).bfloat16()
+    m16, y16 = _engine_forward(s2v, cfg, sd, lat, text, ref, 500.0)
+    del m16
+    cfg8 = copy.copy(cfg)
+    cfg8.weight_format = "fp8"
+    m8, y8 = _engine_forward(s2v, cfg8, sd, lat, text, ref, 500.0)
+    del sd
+    assert y8.shape == (2, F4, 16, H4, W4)
+    assert torch.isfinite(y8.float()).all()
+    assert torch.equal(y8[0], y8[1]), "CFG pair with identical conditioning must be symmetric"
+    rel = rel_l2(y8.float(), y16.float())
+    assert 0 < rel <= 5e-2, rel  # > 0: the fp8 path really ran
+    eng = m8.engine
+    y8b = eng.forward(lat, torch.tensor([500.0, 500.0]), shared_latent=True)
+    torch.cuda.synchronize()
+    assert torch.equal(y8, y8b), "forward must be deterministic"
+    sch = s2v.CogVideoXDDIMScheduler(snr_shift_scale=1.0)
+    sch.set_timesteps(50)
+    a, b = lat.clone(), lat.clone()
+    for x, graph in ((a, False), (b, True)):
+        for i in range(2):
+            t = sch.timesteps[i]
+            eng.denoise_step(x, float(t), sch.coef(t, torch.bfloat16, 6.0), use_graph=graph)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a.float()).all()
+    assert torch.equal(a, b), "graph replay must equal the eager launch sequence"
+
+
+def test_config4_tiled_vae_decode_real_width_properties(s2v):
+    cfg = s2v.VAEConfig(scaling_factor=0.7, sample_height=480, sample_width=720)
+    sd = s2v.weights.synthetic_vae_state_dict(cfg, seed=45, device=DEV)
+    vae = s2v.HipAutoencoderKLCogVideoX(cfg, torch.bfloat16, DEV)
+    vae.load_state_dict(sd)
+    del sd
+    vae.enable_tiling()
+    lat = torch.randn(1, F4, 16, H4, W4, generator=torch.Generator(device=DEV).manual_seed(46), device=DEV).bfloat16()
+    y1 = vae.decode_latents(lat)
+    y2 = vae.decode_latents(lat)
+    torch.cuda.synchronize()
+    assert tuple(y1.shape) == (1, 3, 49, 720, 1280)
+    assert torch.isfinite(y1.float()).all()
+    assert torch.equal(y1, y2)
+
+
+def test_config4_tile_geometry_vs_oracle_narrow_decoder(s2v):
+    """sample size 480 x 720 and a 90 x 160 latent: tile_latent_min 30 x 45, overlaps 25 x 36 -> rows 0, 25, 50, 75 and columns 0, 36,
+    72, 108, 144 (autoencoder_kl_cogvideox.py:1400-1406), row limits 200 x 288, the last row / column of tiles partial -- 20 tiles,
+    blended both ways.  A narrow decoder keeps the CPU oracle to tens of seconds; 5 latent frames = two frame batches with conv cache."""
+    cfgd = dict(latent_channels=16, out_channels=3, block_out_channels=(8, 8, 16, 16), layers_per_block=1, norm_num_groups=4,
+                temporal_compression_ratio=4, sample_height=480, sample_width=720, scaling_factor=0.7)
+    geo = vae_ref.tile_geometry(cfgd)
+    cfg = s2v.VAEConfig(**cfgd)
+    sd = {k: v.float() for k, v in s2v.weights.synthetic_vae_state_dict(cfg, seed=47).items()}
+    lat = torch.randn(1, 5, 16, H4, W4, generator=torch.Generator().manual_seed(48))
+    t0 = time.time()
+    with torch.no_grad():
+        exp = vae_ref.decode_latents(sd, cfgd, lat, True)
+    t_cpu = time.time() - t0
+    vae = s2v.HipAutoencoderKLCogVideoX(cfg, torch.float32, DEV)
+    vae.load_state_dict(sd)
+    vae.enable_tiling()
+    y = vae.decode_latents(lat.to(DEV)).float().cpu()
+    torch.cuda.synchronize()
+    assert y.shape == exp.shape == (1, 3, 17, 720, 1280), (y.shape, exp.shape, geo)
+    assert torch.isfinite(y).all()
+    err = (y - exp).abs().max().item()
+    assert err <= 1e-3, err
+    print(f"configs[4] tile geometry {geo}: oracle took {t_cpu:.1f} s")

@@ -1,7 +1,8 @@
 // Stand-alone A/B harness for the attention kernels of libs2v_hip_diag.so (no torch: starts in a second on a fresh GPU box).
-//   variants: 0 = product kernel (attn_pp_k), 1 = the same with stall accounting, 2 = round-1 lock-step kernel,
-//             4 = product kernel in its persistent, work-pulling launch (what the engine runs), 5 = 4 with accounting,
-//             6 = four-wave kernel (attention_q4.hip) one workgroup per item, 7 = the same, persistent
+//   variants: 0 = product kernel (attn_q4, attention_q4.hip; one workgroup per item here: no queue), 4 = the same in its persistent,
+//             work-pulling launch (what the engine runs), 6 / 7 = attn_q4 per item / persistent (explicit), 8 / 9 = the same stream with
+//             eight waves x 32 rows (attn_q8), 10 / 11 = the round-2 eight-wave ping-pong kernel (attn_pp_k) per item / persistent,
+//             1 / 5 = attn_pp_k with stall accounting, 2 = round-1 lock-step kernel
 //   checks: every variant against attn_simple_k (fp32 math on the same bf16 inputs) on small / ragged shapes, with rare
 //           outliers and with a block of keys whose scores jump by ~+40 at a late tile (forces the deferred-maximum slow
 //           path after O and l have accumulated), and against the first variant at full size;
@@ -22,6 +23,7 @@ int s2v_set_attn_variant(int v);
 int s2v_attn_debug_read(long long* out);
 int s2v_attn_debug_read_blocks(long long* out);
 int s2v_set_attn_queue(int* q, int ncu);
+int s2v_attn_slow_read(unsigned long long* out, int reset);
 const char* s2v_last_error(void);
 }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -52,6 +54,15 @@ __global__ void jump_k(unsigned short* qkv, int B, int H, int N, int k0, int nk,
     const float q = __builtin_bit_cast(float, u);
     qkv[rowk + D + h * 64 + d] = __builtin_bit_cast(unsigned short, (__bf16)(q * g));
 }
+// q columns of every row *= s: the score spread of the softmax (scores = q.k / 8: unit-variance q, k give std 1 at s = 1)
+__global__ void scale_q_k(unsigned short* qkv, size_t rows, int D, float s) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * D) return;
+    const size_t r = i / D, c = i % D;
+    unsigned short* p = qkv + r * 3 * D + c;
+    const unsigned u = (unsigned)*p << 16;
+    *p = __builtin_bit_cast(unsigned short, (__bf16)(__builtin_bit_cast(float, u) * s));
+}
 static float bf2f(unsigned short h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
 struct Bufs { unsigned short *qkv, *vt, *out; int B, H, N; size_t n_out; };
@@ -68,7 +79,7 @@ static Bufs make(int B, int H, int N, float scale, float spike) {
     return b;
 }
 static void release(Bufs& b) { CK(hipFree(b.qkv)); CK(hipFree(b.vt)); CK(hipFree(b.out)); }
-static void run(const Bufs& b, int variant, int impl = 0) {
+static void run(const Bufs& b, int variant, int impl) {
     static int* queue = nullptr;  // variants 4 / 5: the persistent, work-pulling launch (product / accounting kernel)
     if (!queue) {
         int dev = 0, ncu = 0;
@@ -87,7 +98,74 @@ static std::vector<unsigned short> fetch(const Bufs& b) {
     return h;
 }
 
+static Bufs make(int B, int H, int N, float scale, float spike);
+static void run(const Bufs& b, int variant, int impl);
+static std::vector<unsigned short> fetch(const Bufs& b);
+static void release(Bufs& b);
+// `attn_harness slow`: the deferred-maximum slow path as a function of the score spread.  Q is scaled by s (score std = s in natural
+// units); for each s: correctness of the product kernel (persistent) and of the round-2 kernel against the fp32-math kernel at N = 4096,
+// then ms per launch at the C3 shape and the fraction of (wave, KV tile) pairs of attn_q4 that took the slow path
+static int slow_sweep() {
+    int bad = 0;
+    printf("score std | check q4 (max|diff|) | check pp | q4 persistent ms | pp persistent ms | slow-path fraction of (wave, tile) pairs (attn_q4)\n");
+    for (float qs : {1.f, 2.f, 3.f, 4.f, 6.f, 8.f, 12.f}) {
+        double md[2] = {0, 0};
+        {
+            Bufs b = make(1, 2, 4096, 1.0f, 0.f);
+            scale_q_k<<<(unsigned)(((size_t)4096 * 128 + 255) / 256), 256>>>(b.qkv, 4096, 128, qs);
+            CK(hipDeviceSynchronize());
+            run(b, 0, 1);
+            CK(hipDeviceSynchronize());
+            auto ref = fetch(b);
+            int k = 0;
+            for (int v : {4, 11}) {
+                CK(hipMemset(b.out, 0xff, b.n_out * 2));
+                run(b, v, 0);
+                CK(hipDeviceSynchronize());
+                auto got = fetch(b);
+                double maxr = 0;
+                for (size_t i = 0; i < ref.size(); ++i) {
+                    const float r = bf2f(ref[i]), g = bf2f(got[i]);
+                    if (!std::isfinite(g)) { md[k] = 1e30; break; }
+                    md[k] = std::max(md[k], (double)fabsf(r - g));
+                    maxr = std::max(maxr, (double)fabsf(r));
+                }
+                if (md[k] > 2e-2 * std::max(1.0, maxr)) ++bad;
+                ++k;
+            }
+            release(b);
+        }
+        const int B = 2, H = 48, N = 19126;
+        Bufs b = make(B, H, N, 1.0f, 0.f);
+        scale_q_k<<<(unsigned)(((size_t)B * N * H * 64 + 255) / 256), 256>>>(b.qkv, (size_t)B * N, H * 64, qs);
+        CK(hipDeviceSynchronize());
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        double ms[2]; unsigned long long cnt[2] = {0, 0};
+        int k = 0;
+        for (int v : {4, 11}) {
+            run(b, v, 0);
+            std::vector<float> t;
+            for (int r = 0; r < 5; ++r) {
+                if (v == 4 && r == 4) { CK(hipDeviceSynchronize()); s2v_attn_slow_read(cnt, 1); }
+                CK(hipEventRecord(e0));
+                run(b, v, 0);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float x; CK(hipEventElapsedTime(&x, e0, e1));
+                t.push_back(x);
+            }
+            if (v == 4) { CK(hipDeviceSynchronize()); s2v_attn_slow_read(cnt, 1); }
+            std::sort(t.begin(), t.end());
+            ms[k++] = t[2];
+        }
+        printf("%9.1f | %.3e | %.3e | %8.3f | %8.3f | %.4f %% (%llu of %llu)\n", qs, md[0], md[1], ms[0], ms[1], cnt[1] ? 100.0 * cnt[0] / cnt[1] : 0.0, cnt[0], cnt[1]);
+        release(b);
+    }
+    printf(bad ? "SLOW SWEEP: %d FAILURES\n" : "SLOW SWEEP: all checks ok\n", bad);
+    return bad ? 1 : 0;
+}
+
 int main(int argc, char** argv) {
+    if (argc > 1 && !strcmp(argv[1], "slow")) return slow_sweep();
     std::vector<int> vars;
     {
         const char* s = argc > 1 ? argv[1] : "0,2";
@@ -115,7 +193,7 @@ int main(int argc, char** argv) {
             auto ref = fetch(b);
             for (int v : vars) {
                 CK(hipMemset(b.out, 0xff, b.n_out * 2));
-                run(b, v);
+                run(b, v, 0);
                 CK(hipDeviceSynchronize());
                 auto got = fetch(b);
                 double maxd = 0, maxr = 0;
@@ -139,7 +217,7 @@ int main(int argc, char** argv) {
         std::vector<unsigned short> ref;
         for (size_t vi = 0; vi < vars.size(); ++vi) {
             CK(hipMemset(b.out, 0xff, b.n_out * 2));
-            run(b, vars[vi]);
+            run(b, vars[vi], 0);
             CK(hipDeviceSynchronize());
             auto got = fetch(b);
             if (vi == 0) ref = got;
@@ -156,16 +234,16 @@ int main(int argc, char** argv) {
         for (int r = 0; r < rounds; ++r)
             for (size_t vi = 0; vi < vars.size(); ++vi) {
                 s2v_set_attn_variant(vars[vi]);
-                run(b, vars[vi]);  // warm
+                run(b, vars[vi], 0);  // warm
                 CK(hipEventRecord(e0));
-                for (int k = 0; k < 3; ++k) run(b, vars[vi]);
+                for (int k = 0; k < 3; ++k) run(b, vars[vi], 0);
                 CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
                 float t; CK(hipEventElapsedTime(&t, e0, e1));
                 ms[vi].push_back(t / 3);
             }
         for (size_t vi = 0; vi < vars.size(); ++vi) {
             if (vars[vi] == 1 || vars[vi] == 5) {  // stall accounting
-                run(b, vars[vi]); CK(hipDeviceSynchronize());
+                run(b, vars[vi], 0); CK(hipDeviceSynchronize());
                 long long d[64]; s2v_attn_debug_read(d);
                 const double nt = (N + 63) / 64;
                 printf("variant %d: cycles per KV tile per wave [softmax seg | vmcnt | barrier after S | matrix seg | barrier after M | loop total]\n", vars[vi]);
