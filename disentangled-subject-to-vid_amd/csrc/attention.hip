@@ -361,7 +361,7 @@ __device__ __forceinline__ void attn_pp_item(const AttnArgs& a, int nqb, int wg,
         // Deferred maximum: the slow path runs for the first tile (adopts its maximum; its first exp2 pass may overflow, the
         // vote is NaN-safe) and whenever some p of the wave grew past ~2^8: m_run rises to the true maximum, everything at
         // the old scale is rescaled once, and the tile's exp2 is redone at the new scale.
-        if (t == 0 || __any(!(psum <= 8192.f))) {
+        if (t == 0 || __any(!(psum <= 18446744073709551616.f))) {
             float m0 = max3f(st[0][0], st[0][1], st[0][2]), m1 = max3f(st[1][0], st[1][1], st[1][2]);
 #pragma unroll
             for (int e = 3; e < 15; e += 2) { m0 = max3f(m0, st[0][e], st[0][e + 1]); m1 = max3f(m1, st[1][e], st[1][e + 1]); }

@@ -27,13 +27,19 @@ Register file (per lane; numbers for JB = 2, the JB = 1 map is the same list pac
   s44 IN: nt, s45 IN: K tile stride (bytes), s46 IN: Ntok, s47 IN: LDS address of the wave's first piece in slot 0
   s40 t, s41 end of the current phase, s42 / s43 K / V^T source advance per iteration, s48 threshold (f32 bits), s49 return position,
   s[50:51] scratch, s52 OUT: slow paths taken
-Phases: A = iterations t < nt - 5 (threshold 2^13: a check fires only for a genuine slow path); B = the last five (threshold -1:
+Phases: A = iterations t < nt - 5 (threshold 2^64: a check fires only for a genuine slow path); B = the last five (threshold -1:
 every check enters the rare-path handler, which applies the staging clamp, the tail mask and the real threshold).
 """
 import os
 import sys
 
 JB = 2  # set by main() per output
+# Deferred maximum: a row keeps the maximum its first tile adopted until a partial row sum of a later tile exceeds 2^64, i.e. until some
+# p = exp2(s - m) does -- fp32 and bf16 share the exponent range, sums and P.V stay below 2^64 * N * |v| << 2^127, and every quantity is
+# scale-free, so nothing is lost by letting m lag (keys 2^126 below the adopted maximum flush to zero, as they would below any maximum).
+# Round 2 used 2^13: with a score spread of 4 / 8 / 12 (natural units) 0.9 / 6 / 11 % of the (wave, tile) pairs took the slow path and
+# a launch cost 3 / 15 / 27 % more (profiles/r03_attn_slow_path.txt); at 2^64 the scores must rise 44 above the first tile's maximum.
+THR_BITS = 0x5F800000
 ORDER = os.environ.get("Q4_ORDER", "")  # placement experiments
 READPOS = os.environ.get("Q4_READPOS", "first")  # fragment read first in its gap: -3 % against last (A/B, profiles/r03_attn_q4_placement.txt)
 READS = os.environ.get("Q4_READS", "")
@@ -272,7 +278,7 @@ def gen():
         emit(f"v_mov_b32 {vr(LRUN + j)}, 0")
     emit(f"s_mov_b32 s{S_T}, 0")
     emit(f"s_mov_b32 s{S_CNT}, 0")               # OUT: slow paths taken by this wave (diagnostics)
-    emit(f"s_mov_b32 s{S_THR}, 0x46000000")      # 8192.0
+    emit(f"s_mov_b32 s{S_THR}, 0x{THR_BITS:08x}")      # 2^64
     emit(f"s_mov_b32 s{S_KADV}, s{S_KSTR}")
     emit(f"s_mov_b32 s{S_VADV}, 128")
     emit(f"s_sub_u32 s{S_END}, s{S_NT}, 5")      # phase A ends at nt - 5 ...
@@ -391,7 +397,7 @@ def gen():
         mask_tile(emit, nxt, S_X0)
         emit(f"L_q4_nomask{1 + cur}_%=:")
         max_ps(emit, cur)
-        emit(f"s_mov_b32 s{S_X0}, 0x46000000")
+        emit(f"s_mov_b32 s{S_X0}, 0x{THR_BITS:08x}")
         emit(f"v_cmp_nge_f32 vcc, s{S_X0}, {vr(VS)}")
         emit(f"s_cbranch_vccz L_q4_ret{cur}_%=")
         emit(f"s_add_u32 s{S_CNT}, s{S_CNT}, 1")

@@ -323,6 +323,39 @@ def test_op_attention_strongly_negative_and_positive_scores(s2v):
         assert rel <= 3e-2, (sign, rel)
 
 
+def test_op_attention_late_score_jump_takes_the_slow_path(s2v):
+    """deferred maximum (attention_q4.hip / gen_attn_q4.py): a row keeps the maximum of its first KV tile until a later tile's row sum
+    exceeds 2^64.  Forty keys far into the sequence are set to 12 x (query row 17): against that row (and its like) their scores jump by
+    60-110 natural units (90-160 in the exp2 domain: one head's first exp2 pass overflows to inf, the other's stays finite) after O and
+    l have accumulated eleven tiles at the old scale -- the slow path (true
+    maximum, rescale of O / l, exp2 redone, next tile's scores shifted) must take over.  Reference: fp64 softmax on the SAME bf16
+    rounding of q * scale * log2(e) the kernel (and the reference's bf16 math path) applies -- at scores of this size that rounding
+    alone moves the weights by percent, it is not what this test is about."""
+    L = s2v._lib
+    B, H, N, k0, nk, r0 = 1, 2, 700, 437, 40, 17
+    D = H * 64
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B * N, 3 * D, generator=g).bfloat16()
+    for h in range(H):
+        qkv[k0:k0 + nk, D + h * 64:D + (h + 1) * 64] = (12.0 * qkv[r0, h * 64:(h + 1) * 64].float()).bfloat16()
+    qd = torch.cat([qkv, torch.zeros(64, 3 * D, dtype=torch.bfloat16)]).to(DEV)
+    out = torch.full((B * N, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    vt = torch.zeros(B * H * 64 * ((N + 63) // 64 * 64), dtype=torch.bfloat16, device=DEV)
+    L.check(L.lib().s2v_op_attention(L.ptr(qd), L.ptr(vt), L.ptr(out), B, H, N, L.DTYPE_BF16, 0, L.stream_ptr()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().double()
+    assert torch.isfinite(got).all()
+    c0 = 0.125 * 1.4426950408889634
+    q, k, v = (qkv.float()[:, i * D:(i + 1) * D].reshape(N, H, 64).transpose(0, 1) for i in range(3))
+    qs = (q * c0).bfloat16().double()
+    s = qs @ k.double().transpose(-1, -2)                       # exp2-domain scores
+    assert (s[:, r0, k0] - s[:, r0, :k0].max(dim=-1).values).min() > 70.0   # the jump really is beyond the 2^64 threshold
+    p = torch.exp2(s - s.max(dim=-1, keepdim=True).values)
+    ref = ((p @ v.double()) / p.sum(dim=-1, keepdim=True)).transpose(0, 1).reshape(N, D)
+    err = (got - ref).abs().max().item()
+    assert err <= 2e-2 * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("dt_name", ["f32", "bf16"])
 def test_lora_adaln_scope_intended_vs_oracle(s2v, dt_name):
     """lora_adaln_scope = "intended" (normalization.py:468-478 as its comments read: base weights for the video / text
