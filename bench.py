@@ -261,8 +261,9 @@ def main():
             per_kernel[name] = e
         dom = max((n for n in per_kernel if n in flops), key=lambda n: per_kernel[n]["avg_ms"] * per_kernel[n]["launches"])
         ach = per_kernel[dom]["tflops"]
-        roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic_bytes(dom),
+        peak = per_kernel[dom]["peak_tflops"]  # the dominant kernel's own matrix-core peak (fp8 GEMMs: 5 PF, everything else 2.5 PF)
+        roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": pmc_traffic_bytes(dom),
                     "traffic_unit": "bytes/launch (profiles/rNN_pmc_{fetch,write}.csv, FETCH_SIZE x2 per MI355X_MICROARCH)",
                     "algorithmic_flops_per_launch": flops[dom], "avg_launch_ms": per_kernel[dom]["avg_ms"],
                     "measured": f"HIP events on the launch stream in a separate eager pass of {prof_steps} steps after the timed region",

@@ -148,16 +148,16 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
-        delete c;
+        s2v_destroy(c);
         return s2v_fail(__FILE__, __LINE__, "s2v_create: stream / event creation failed", -2);
     }
     c->mfma = (cfg->dtype == S2V_DTYPE_BF16) && !cfg->force_simple;
     if (hipMalloc((void**)&c->attn_queue, 64) != hipSuccess || hipMemset(c->attn_queue, 0, 64) != hipSuccess) {
-        delete c;
+        s2v_destroy(c);
         return s2v_fail(__FILE__, __LINE__, "s2v_create: attention queue allocation failed", -2);
     }
-    if (c->D > 4096) { delete c; return s2v_fail(__FILE__, __LINE__, "s2v_create: D > 4096 unsupported", -1); }
-    if (c->temb % 8 != 0 || c->D % 8 != 0) { delete c; return s2v_fail(__FILE__, __LINE__, "bad dims", -1); }
+    if (c->D > 4096) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "s2v_create: D > 4096 unsupported", -1); }
+    if (c->temb % 8 != 0 || c->D % 8 != 0) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "bad dims", -1); }
 
     const int64_t D = c->D, E = c->esz, L = c->L, TE = c->temb;
     const int64_t Kp = cfg->in_channels * 4, Cout = cfg->out_channels * 4, TX = cfg->text_embed_dim;
@@ -181,15 +181,15 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     const int64_t o_te1_w = carve(TE * D), o_te1_b = carve(TE), o_te2_w = carve(TE * TE), o_te2_b = carve(TE);
     const int64_t o_nf_w = carve(D), o_nf_b = carve(D), o_no_w = carve(D), o_no_b = carve(D);
     const int64_t o_po_w = carve(rup(Cout, 256) * D), o_po_b = carve(Cout);
-    if (cfg->lora_adaln_scope != 0 && cfg->lora_adaln_scope != 1) { delete c; return s2v_fail(__FILE__, __LINE__, "s2v_create: lora_adaln_scope must be 0 or 1", -1); }
+    if (cfg->lora_adaln_scope != 0 && cfg->lora_adaln_scope != 1) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "s2v_create: lora_adaln_scope must be 0 or 1", -1); }
     c->mc = cfg->lora_adaln_scope ? 9 : 6;
     const int64_t MC = c->mc;
     c->mod_rows = 2 * L * MC * D + 2 * D;
     const int64_t o_mod_w = carve(c->mod_rows * TE), o_mod_b = carve(c->mod_rows);
     // fp8 copies live in the same arena (one broadcast replicates everything a replica needs)
     c->fp8 = cfg->weight_format == 1;
-    if (cfg->weight_format != 0 && cfg->weight_format != 1) { delete c; return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format must be 0 or 1", -1); }
-    if (c->fp8 && (!c->mfma || D % 128 != 0)) { delete c; return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format 1 (fp8) needs the bf16 MFMA path and inner_dim % 128 == 0", -1); }
+    if (cfg->weight_format != 0 && cfg->weight_format != 1) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format must be 0 or 1", -1); }
+    if (c->fp8 && (!c->mfma || D % 128 != 0)) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format 1 (fp8) needs the bf16 MFMA path and inner_dim % 128 == 0", -1); }
     struct QOffs { int64_t q_qkv, q_o, q_1, q_2, s_qkv, s_o, s_1, s_2; };
     std::vector<QOffs> qo(c->fp8 ? L : 0);
     auto carve_b = [&](int64_t bytes) { int64_t o = off; off += rup(bytes, 256); return o; };
@@ -199,7 +199,7 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     }
     c->arena_bytes = off;
     hipError_t e = hipMalloc((void**)&c->arena, c->arena_bytes);
-    if (e != hipSuccess) { delete c; return s2v_fail(__FILE__, __LINE__, hipGetErrorString(e), -2); }
+    if (e != hipSuccess) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, hipGetErrorString(e), -2); }
     e = hipMemset(c->arena, 0, c->arena_bytes);
     if (e != hipSuccess) { hipFree(c->arena); delete c; return s2v_fail(__FILE__, __LINE__, hipGetErrorString(e), -2); }
     char* A = c->arena;
@@ -452,7 +452,14 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
 
 extern "C" int s2v_set_rope(s2v_ctx* c, const float* cos_dev, const float* sin_dev, s2v_stream stream) {
     S2V_REQUIRE(c && c->ws, "s2v_set_rope: call s2v_set_geometry first");
-    if (!cos_dev || !sin_dev) { c->have_rope = false; return 0; }
+    // the captured step bakes in have_rope and the fused-epilogue decision (rope_paired): a change of either drops the graph
+    auto drop_graph = [&]() { if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; } };
+    if (!cos_dev || !sin_dev) {
+        if (c->have_rope) drop_graph();
+        c->have_rope = false;
+        return 0;
+    }
+    const bool had_rope = c->have_rope, was_paired = c->rope_paired;
     const size_t bytes = (size_t)(c->R + c->V) * 64 * 4;
     S2V_CHECK_HIP(hipMemcpyAsync(c->rope_cos, cos_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     S2V_CHECK_HIP(hipMemcpyAsync(c->rope_sin, sin_dev, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -468,6 +475,7 @@ extern "C" int s2v_set_rope(s2v_ctx* c, const float* cos_dev, const float* sin_d
     bool paired = true;
     for (size_t i = 0; i < n && paired; i += 2) paired = hc[i] == hc[i + 1] && hs[i] == hs[i + 1];
     c->rope_paired = paired;
+    if (!had_rope || was_paired != paired) drop_graph();
     if (paired) {
         for (size_t p = 0; p < n / 64; ++p)
             for (int k = 0; k < 32; ++k) {
@@ -753,7 +761,8 @@ extern "C" int s2v_attn_forward(s2v_ctx* c, int32_t layer, const void* hidden, c
     const LayerW& w = c->layers[layer];
     GemmArgs g{};
     g.A = c->Xn; g.lda = D; g.W = w.wo; g.ldw = D; g.bias = w.bo; g.C = c->Hb; g.ldc = D; g.M = (int)c->M; g.N = D; g.K = D;
-    S2V_TRY(linear(c, g, EPI_BIAS, st));
+    if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS, w.q_o, w.s_o, st));  // the same operands run_block feeds its out-projection
+    else S2V_TRY(linear(c, g, EPI_BIAS, st));
     for (int b = 0; b < B; ++b) {
         const char* xb = c->Hb + (int64_t)b * c->Ntok * D * E;
         S2V_TRY(launch_copy_rows(xb, D, nullptr, 0, (char*)out_encoder + (int64_t)b * TR * D * E, D, TR, D, c->dtype, st));

@@ -46,6 +46,7 @@ class S2VEngine:
         # bumped by every write of the engine-side RoPE / positional table ("rope") and conditioning ("cond"): the seam
         # adapters' caches (transformer._Cache) are valid only for the epoch they were stored at
         self.epoch = {"rope": 0, "cond": 0}
+        self._rope_key, self.have_rope = None, None  # ensure_rope / ensure_no_rope
 
     def close(self):
         if self._h:
@@ -118,11 +119,31 @@ class S2VEngine:
     def set_geometry(self, B, T, F, H, W):
         _lib.check(_lib.lib().s2v_set_geometry(self._h, B, T, F, H, W))
         self.geometry = (B, T, F, H, W)
+        self._rope_key, self.have_rope = None, None
         self._bump("rope", "cond")
 
     def clear_rope(self):
         _lib.check(_lib.lib().s2v_set_rope(self._h, None, None, _lib.stream_ptr()))
+        self._rope_key, self.have_rope = None, False
         self._bump("rope")
+
+    # One rotary-table cache PER ENGINE: the transformer object, its 42 block objects and an AttnProcessor all write the same device
+    # table, so the "did the caller's tensors change" key lives here (a per-object key made every block re-upload the tables --
+    # a stream sync, two D2H copies and a host scan each -- because its neighbour's upload had invalidated it).
+    def ensure_rope(self, key_tensors, build):
+        """key_tensors: the caller's table tensors (or None entries), compared by identity + in-place version, held by STRONG reference
+        so their storage cannot be recycled under the key; build() -> (cos, sin) for set_rope when they changed"""
+        k = self._rope_key
+        same = (k is not None and len(k) == len(key_tensors)
+                and all((a is None and t is None) or (a is not None and t is not None and a[0] is t and a[1] == t._version)
+                        for a, t in zip(k, key_tensors)))
+        if not same:
+            self.set_rope(*build())
+            self._rope_key = tuple(None if t is None else (t, t._version) for t in key_tensors)
+
+    def ensure_no_rope(self):
+        if self.have_rope is not False:
+            self.clear_rope()
 
     def set_rope(self, cos, sin):
         cos = cos.to(self.device, torch.float32).contiguous()
@@ -133,12 +154,14 @@ class S2VEngine:
             raise _lib.S2VError(f"RoPE tables must be [{n}, 64] ([ref | video] rows)")
         _lib.check(_lib.lib().s2v_set_rope(self._h, _lib.ptr(cos), _lib.ptr(sin), _lib.stream_ptr()))
         torch.cuda.current_stream().synchronize()
+        self._rope_key, self.have_rope = None, True
         self._bump("rope")
 
     def set_pos_embed(self, table):
         t = table.to(self.device, self.dtype).contiguous()
         _lib.check(_lib.lib().s2v_set_pos_embed(self._h, _lib.ptr(t), _lib.stream_ptr()))
         torch.cuda.current_stream().synchronize()
+        self._rope_key = None
         self._bump("rope")
 
     def prepare_tables(self, height, width):

@@ -29,7 +29,8 @@ def _rope_pair(image_rotary_emb, ref_image_rotary_emb, R):
 
 
 class _Cache:
-    """re-upload a table / recompute conditioning only when the caller's tensor changed.
+    """recompute the conditioning only when the caller's tensors changed (the rotary tables have the same kind of key on the engine
+    itself: S2VEngine.ensure_rope).
 
     The key holds STRONG references to the tensors (so their storage cannot be freed and handed to a different tensor at the
     same address) and compares object identity + in-place version; it also records the engine's epoch for its kind of state
@@ -64,7 +65,7 @@ class HipCogVideoXTransformer3DModel:
         self.dtype = dtype
         self.device = self.engine.device
         self.qk_replace = False  # set by CustomCogVideoXPipeline.__init__ (custom_cogvideox_pipe.py:41); never read
-        self._rope_cache, self._cond_cache = _Cache("rope"), _Cache("cond")
+        self._cond_cache = _Cache("cond")
         self.transformer_blocks = [HipCogVideoXBlock(self.engine, i) for i in range(cfg.num_layers)]
 
     def eval(self):
@@ -104,9 +105,7 @@ class HipCogVideoXTransformer3DModel:
         if image_rotary_emb is not None:
             ref = ref_image_rotary_emb
             key = (image_rotary_emb[0], image_rotary_emb[1], None if ref is None else ref[0], None if ref is None else ref[1])
-            if self._rope_cache.changed(eng, *key):
-                eng.set_rope(*_rope_pair(image_rotary_emb, ref, (H // 2) * (W // 2)))
-                self._rope_cache.store(eng, *key)
+            eng.ensure_rope(key, lambda: _rope_pair(image_rotary_emb, ref, (H // 2) * (W // 2)))
         if self._cond_cache.changed(eng, encoder_hidden_states, ref_img_states):
             eng.set_conditioning(encoder_hidden_states, ref_img_states)
             self._cond_cache.store(eng, encoder_hidden_states, ref_img_states)
@@ -119,14 +118,16 @@ class HipCogVideoXTransformer3DModel:
     forward = __call__
 
 
-class HipCogVideoXBlock:
-    """transformer.transformer_blocks[i] replacement (Block-module seam)."""
+class HipCogVideoXBlock(torch.nn.Module):
+    """transformer.transformer_blocks[i] replacement (Block-module seam).  An nn.Module (without parameters: the weights live in the
+    engine's arena) so that `transformer.transformer_blocks[i] = HipCogVideoXBlock(engine, i)` is accepted by the reference's
+    nn.ModuleList (cogvideox_transformer_3d.py:315-330)."""
 
     def __init__(self, engine: S2VEngine, layer: int):
+        super().__init__()
         self.engine, self.layer = engine, layer
-        self._rope_cache = _Cache("rope")
 
-    def __call__(self, hidden_states, encoder_hidden_states, temb, enc_hidden_states1=None, image_rotary_emb=None,
+    def forward(self, hidden_states, encoder_hidden_states, temb, enc_hidden_states1=None, image_rotary_emb=None,
                  embed_ref_img=False, ref_img_seq_start=None, ref_img_seq_end=None, position_delta=None,
                  timestep=None, layer=None, ref_image_rotary_emb=None):
         if enc_hidden_states1 is None:
@@ -144,14 +145,10 @@ class HipCogVideoXBlock:
         if image_rotary_emb is not None:
             ref = ref_image_rotary_emb if embed_ref_img else None
             key = (image_rotary_emb[0], image_rotary_emb[1], None if ref is None else ref[0], None if ref is None else ref[1])
-            if self._rope_cache.changed(eng, *key):
-                eng.set_rope(*_rope_pair(image_rotary_emb, ref, R))
-                self._rope_cache.store(eng, *key)
+            eng.ensure_rope(key, lambda: _rope_pair(image_rotary_emb, ref, R))
         else:
-            eng.clear_rope()
+            eng.ensure_no_rope()
         return eng.block_forward(self.layer, hidden_states, encoder_hidden_states, enc_hidden_states1, temb)
-
-    forward = __call__
 
 
 class HipCogVideoXAttnProcessor2_0:
@@ -177,7 +174,7 @@ class HipCogVideoXAttnProcessor2_0:
                 eng.load_weight(p + name + ".bias", mod.bias.detach())
             torch.cuda.synchronize()
             eng.mark_weights_loaded()  # only attn1 is used through s2v_attn_forward
-            self._engines[key] = (eng, _Cache("rope"), attn)  # the module is kept alive: id(attn) stays unique
+            self._engines[key] = (eng, attn)  # the module is kept alive: id(attn) stays unique
         return self._engines[key]
 
     def __call__(self, attn, hidden_states, encoder_hidden_states, attention_mask=None, image_rotary_emb=None,
@@ -195,7 +192,7 @@ class HipCogVideoXAttnProcessor2_0:
             raise NotImplementedError("the fork always calls with embed_ref_img=True and the reference-image tokens at "
                                       "the tail of encoder_hidden_states (cogvideox_transformer_3d.py:510-512)")
         T, R = ref_img_seq_start, ref_img_seq_end - ref_img_seq_start
-        eng, cache, _ = self._engine_for(attn, hidden_states.dtype, hidden_states.device)
+        eng, _ = self._engine_for(attn, hidden_states.dtype, hidden_states.device)
         geo = (B, T, V // R, 2, 2 * R)
         if V % R != 0:
             raise RuntimeError("video tokens must be a whole number of frames of the reference image's token count")
@@ -204,9 +201,7 @@ class HipCogVideoXAttnProcessor2_0:
         if image_rotary_emb is not None:
             ref = ref_image_rotary_emb
             key = (image_rotary_emb[0], image_rotary_emb[1], None if ref is None else ref[0], None if ref is None else ref[1])
-            if cache.changed(eng, *key):
-                eng.set_rope(*_rope_pair(image_rotary_emb, ref, R))
-                cache.store(eng, *key)
+            eng.ensure_rope(key, lambda: _rope_pair(image_rotary_emb, ref, R))
         else:
-            eng.clear_rope()
+            eng.ensure_no_rope()
         return eng.attn_forward(0, hidden_states, encoder_hidden_states)

@@ -221,3 +221,12 @@ def test_export_to_video_writes_a_readable_file_without_imageio(s2v, tmp_path):
         assert np.abs(first.astype(int) - frames[0].astype(int)).mean() < 6.0
     with pytest.raises(ValueError):
         vg.export_to_video(frames.astype(np.float32) / 255.0, str(tmp_path / "bad.mp4"))
+
+
+def test_block_object_is_assignable_into_the_reference_module_list(s2v):
+    """`transformer.transformer_blocks[i] = HipCogVideoXBlock(engine, i)`: the reference keeps its blocks in an nn.ModuleList
+    (cogvideox_transformer_3d.py:315-330), which only accepts nn.Module entries; the drop-in has no parameters of its own"""
+    blocks = torch.nn.ModuleList([torch.nn.Identity(), torch.nn.Identity()])
+    blocks[1] = s2v.HipCogVideoXBlock(None, 1)
+    assert isinstance(blocks[1], torch.nn.Module) and blocks[1].layer == 1 and not list(blocks[1].parameters())
+    assert "forward" in type(blocks[1]).__dict__
