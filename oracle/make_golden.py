@@ -5,6 +5,7 @@
 Never runs on the GPU box (the reference does not exist there); only its outputs -- inputs and expected outputs,
 weights of the tiny seeded modules included -- are committed.  Nothing from the reference is copied.
 """
+import functools
 import os
 import sys
 import tempfile
@@ -312,6 +313,14 @@ def gen_t5():
     np.savez_compressed(os.path.join(OUT, "t5_tiny.npz"), **out)
 
 
+def put_steps(out, name, tensors):
+    """per-step tensors [1, F, C, H, W]: every second row and column (a quarter of the elements) + fp64 sum and abs-sum of the whole
+    tensor per step, to keep the fixture small"""
+    x = torch.stack(tensors).float()
+    out[name + "_sub2"] = x[..., ::2, ::2].numpy()
+    out[name + "_sums"] = torch.stack([x.double().sum(dim=(1, 2, 3, 4, 5)), x.double().abs().sum(dim=(1, 2, 3, 4, 5))], dim=1).numpy()
+
+
 def gen_pipeline():
     """Full CustomCogVideoXPipeline.__call__ (src/custom_cogvideox_pipe.py:125-326) with tiny modules, 480x720
     (the only geometry the shipped harness supports: 1350 tokens per frame), 3 steps, DDIM and DPM."""
@@ -332,16 +341,48 @@ def gen_pipeline():
     weights = {k: v for k, v in tr.state_dict().items() if "pos_embedding" not in k}
     out = npsd(weights)
     out.update(prompt_embeds=pe.numpy(), negative_prompt_embeds=ne.numpy(), ref=ref.numpy(), latents0=lat0.numpy())
+    randomize(vae, torch.Generator().manual_seed(10), std=0.15)
+    out.update({"vae:" + k: v.numpy() for k, v in vae.state_dict().items()})
+
+    def run(pipe, trace=None, **kw):
+        """one CustomCogVideoXPipeline.__call__; trace collects what the loop hands to scheduler.step (the CFG-combined noise
+        prediction, custom_cogvideox_pipe.py:273-277) and what it gets back (the latents after the step, :280-295).  Not through
+        callback_on_step_end: the reference builds its callback arguments with `{k: locals()[k] for k in ...}` (:300), which raises
+        KeyError under Python < 3.12 (a comprehension has its own locals there) -- that seam cannot be exercised with this
+        interpreter, so the trace wraps scheduler.step instead."""
+        g = torch.Generator().manual_seed(77)
+        args = dict(prompt=None, prompt_embeds=pe, negative_prompt_embeds=ne, ref_img_states=ref, height=480, width=720,
+                    num_frames=5, num_inference_steps=3, guidance_scale=6.0, latents=lat0.clone(), generator=g,
+                    output_type="latent", return_dict=False)
+        args.update(kw)
+        if trace is not None:
+            step = pipe.scheduler.step
+
+            @functools.wraps(step)  # prepare_extra_step_kwargs inspects the signature for `eta` / `generator` (pipeline_cogvideox.py:355-370)
+            def spy(model_output, *a, **k):
+                trace["noise_pred"].append(model_output.detach().float().clone())
+                ret = step(model_output, *a, **k)
+                trace["latents"].append(ret[0].detach().to(pe.dtype).float().clone())  # `latents.to(prompt_embeds.dtype)`, :296
+                return ret
+
+            pipe.scheduler.step = spy
+        try:
+            return pipe(**args)[0], g
+        finally:
+            if trace is not None:
+                pipe.scheduler.step = step
+
     for kind, cls in (("ddim", CogVideoXDDIMScheduler), ("dpm", CogVideoXDPMScheduler)):
         sched = cls(**sched_kwargs(1.0))
         pipe = CustomCogVideoXPipeline(tokenizer=None, text_encoder=None, transformer=tr, vae=vae, scheduler=sched,
                                        customization=True)
-        g = torch.Generator().manual_seed(77)
-        st = g.get_state()
-        res = pipe(prompt=None, prompt_embeds=pe, negative_prompt_embeds=ne, ref_img_states=ref, height=480, width=720,
-                   num_frames=5, num_inference_steps=3, guidance_scale=6.0, latents=lat0.clone(), generator=g,
-                   output_type="latent", return_dict=False)[0]
+        st = torch.Generator().manual_seed(77).get_state()
+        trace = {"noise_pred": [], "latents": []}
+        res, _ = run(pipe, trace)
         out[f"final_{kind}"] = res.float().numpy()
+        put_steps(out, f"steps_noise_pred_{kind}", trace["noise_pred"])  # [steps, 1, F, C, H, W], after CFG, fp32
+        put_steps(out, f"steps_latents_{kind}", trace["latents"])
+        assert torch.equal(trace["latents"][-1], res.float())
         if kind == "dpm":  # the randn draws the DPM steps consumed, in order (2 per step after step 0, 1 on step 0... )
             g3 = torch.Generator()
             g3.set_state(st)
@@ -349,6 +390,22 @@ def gen_pipeline():
             nz = torch.stack([torch.randn(lat0.shape, generator=g3) for _ in range(6)])
             out["dpm_noise_seed"] = np.array(77)
             out["dpm_noise_sums"] = nz.double().sum(dim=(1, 2, 3, 4, 5)).numpy()
+        if kind == "ddim":
+            # use_dynamic_cfg=True (custom_cogvideox_pipe.py:268-271): the guidance scale follows a cosine power schedule
+            trace = {"noise_pred": [], "latents": []}
+            res, _ = run(pipe, trace, use_dynamic_cfg=True)
+            out["final_ddim_dyncfg"] = res.float().numpy()
+            put_steps(out, "steps_latents_ddim_dyncfg", trace["latents"])
+            # output_type="np" through the VAE with tiling on, as src/inference.py:204-207 runs it: decode_latents (:309-311) +
+            # VideoProcessor.postprocess_video.  The frames are 8 x 480 x 720 x 3 floats: the fixture keeps every 8th pixel of every
+            # frame plus fp64 sums per frame and per colour plane (a checksum of the rest)
+            vae.enable_tiling()
+            frames, _ = run(pipe, None, output_type="np")
+            vae.disable_tiling()
+            frames = np.asarray(frames)
+            out["frames_ddim_tiled_shape"] = np.array(frames.shape)
+            out["frames_ddim_tiled_sub8"] = frames[:, :, ::8, ::8, :].astype(np.float32)
+            out["frames_ddim_tiled_sums"] = frames.astype(np.float64).sum(axis=(2, 3))  # [1, F, 3]
     np.savez_compressed(os.path.join(OUT, "pipeline_tiny.npz"), **out)
 
 

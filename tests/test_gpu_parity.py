@@ -204,25 +204,88 @@ def test_scheduler_step_bit_exact_vs_reference_golden(s2v, kind, dt_name):
 
 
 # ------------------------------------------------------------------------------------------------ denoise loop
-@pytest.mark.parametrize("kind", ["ddim", "dpm"])
-@pytest.mark.parametrize("mode", ["fused", "fused_graph", "seams"])
-def test_pipeline_three_steps_vs_reference_golden(s2v, kind, mode):
-    g = load_golden("pipeline_tiny.npz")
+def _pipe_from_golden(s2v, g, kind, with_vae=False):
     cfg = s2v.tiny(use_rope=True, text_dim=64, temb=64)
     cfg.max_text_seq_length = 6
     m = s2v.HipCogVideoXTransformer3DModel(cfg, torch.float32, DEV)
     m.load_state_dict(weights_of(g))
     sch = (s2v.CogVideoXDDIMScheduler if kind == "ddim" else s2v.CogVideoXDPMScheduler)(snr_shift_scale=1.0)
-    pipe = s2v.S2VPipeline(m, sch)
-    gen = torch.Generator().manual_seed(int(g["dpm_noise_seed"]))
-    out = pipe(prompt_embeds=t(g["prompt_embeds"]), negative_prompt_embeds=t(g["negative_prompt_embeds"]),
-               ref_img_states=t(g["ref"]), height=480, width=720, num_frames=5, num_inference_steps=3,
-               guidance_scale=6.0, generator=gen, latents=t(g["latents0"]), output_type="latent", return_dict=False,
-               fused=mode != "seams", use_graph=mode == "fused_graph")[0]
+    vae = None
+    if with_vae:
+        vcfg = s2v.VAEConfig(block_out_channels=(8, 8, 8, 8), layers_per_block=1, norm_num_groups=2, latent_channels=16,
+                             sample_height=480, sample_width=720, scaling_factor=0.7, temporal_compression_ratio=4)
+        vae = s2v.HipAutoencoderKLCogVideoX(vcfg, torch.float32, DEV)
+        vae.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("vae:")})
+    return s2v.S2VPipeline(m, sch, vae)
+
+
+def _pipe_args(g):
+    return dict(prompt_embeds=t(g["prompt_embeds"]), negative_prompt_embeds=t(g["negative_prompt_embeds"]), ref_img_states=t(g["ref"]),
+                height=480, width=720, num_frames=5, num_inference_steps=3, guidance_scale=6.0,
+                generator=torch.Generator().manual_seed(int(g["dpm_noise_seed"])), latents=t(g["latents0"]), return_dict=False)
+
+
+def _check_steps(got, g, name, atol=1e-3):
+    x = torch.stack([y.float().cpu() for y in got])
+    exp = t(g[name + "_sub2"])
+    assert (x[..., ::2, ::2] - exp).abs().max().item() <= atol
+    sums = torch.stack([x.double().sum(dim=(1, 2, 3, 4, 5)), x.double().abs().sum(dim=(1, 2, 3, 4, 5))], dim=1).numpy()
+    np.testing.assert_allclose(sums[:, 1], g[name + "_sums"][:, 1], rtol=1e-4)
+
+
+@pytest.mark.parametrize("kind", ["ddim", "dpm"])
+@pytest.mark.parametrize("mode", ["fused", "fused_graph", "seams"])
+def test_pipeline_three_steps_vs_reference_golden(s2v, kind, mode):
+    """S2VPipeline against CustomCogVideoXPipeline.__call__ itself (tests/golden/pipeline_tiny.npz): the latents after EVERY step
+    (what scheduler.step returned to the reference loop, custom_cogvideox_pipe.py:280-296), the CFG-combined noise prediction of
+    every step (what the loop handed to scheduler.step, :273-277; the fused modes expose it through s2v_last_noise_pred) and the
+    final latents, in the three execution modes"""
+    g = load_golden("pipeline_tiny.npz")
+    pipe = _pipe_from_golden(s2v, g, kind)
+    eng = pipe.transformer.engine
+    lats, nps = [], []
+
+    def on_step(p_, i, tt, kw):
+        lats.append(kw["latents"].clone())
+        if mode != "seams":
+            npr = eng.last_noise_pred().float()
+            u, c = npr.chunk(2)
+            nps.append(u + 6.0 * (c - u))
+
+    out = pipe(output_type="latent", fused=mode != "seams", use_graph=mode == "fused_graph", callback_on_step_end=on_step, **_pipe_args(g))[0]
     torch.cuda.synchronize()
-    exp = t(g[f"final_{kind}"])
-    err = (out.float().cpu() - exp).abs().max().item()
+    err = (out.float().cpu() - t(g[f"final_{kind}"])).abs().max().item()
     assert err <= 1e-3, err
+    _check_steps(lats, g, f"steps_latents_{kind}")
+    if nps:
+        _check_steps(nps, g, f"steps_noise_pred_{kind}")
+
+
+@pytest.mark.parametrize("mode", ["fused_graph", "seams"])
+def test_pipeline_dynamic_cfg_vs_reference_golden(s2v, mode):
+    """use_dynamic_cfg=True (custom_cogvideox_pipe.py:268-271): the guidance scale changes every step, so the captured graph must read
+    it from device memory like the scheduler scalars"""
+    g = load_golden("pipeline_tiny.npz")
+    pipe = _pipe_from_golden(s2v, g, "ddim")
+    lats = []
+    out = pipe(output_type="latent", use_dynamic_cfg=True, fused=mode != "seams", use_graph=mode == "fused_graph",
+               callback_on_step_end=lambda p_, i, tt, kw: lats.append(kw["latents"].clone()), **_pipe_args(g))[0]
+    torch.cuda.synchronize()
+    err = (out.float().cpu() - t(g["final_ddim_dyncfg"])).abs().max().item()
+    assert err <= 1e-3, err
+    _check_steps(lats, g, "steps_latents_ddim_dyncfg")
+
+
+def test_pipeline_frames_with_tiled_vae_vs_reference_golden(s2v):
+    """output_type="np" with VAE tiling enabled, as src/inference.py:204-207 runs the reference: denoise (graph) -> decode_latents over
+    nine blended tiles -> postprocess_video, against the REFERENCE PIPELINE's own frames (8 x 480 x 720 x 3)"""
+    g = load_golden("pipeline_tiny.npz")
+    pipe = _pipe_from_golden(s2v, g, "ddim", with_vae=True)
+    pipe.vae.enable_tiling()
+    frames = pipe(output_type="np", fused=True, use_graph=True, **_pipe_args(g))[0]
+    assert list(frames.shape) == list(g["frames_ddim_tiled_shape"]) == [1, 8, 480, 720, 3]
+    assert np.abs(frames[:, :, ::8, ::8, :] - g["frames_ddim_tiled_sub8"]).max() <= 1e-3
+    np.testing.assert_allclose(frames.astype(np.float64).sum(axis=(2, 3)), g["frames_ddim_tiled_sums"], rtol=1e-4)
 
 
 # ------------------------------------------------------------------------------------------------ on-box oracle

@@ -155,10 +155,18 @@ def test_lora_merge_matches_runtime_adapter():
 
 
 # ---------------------------------------------------------------------------------------------------- pipeline
-@pytest.mark.parametrize("kind", ["ddim", "dpm"])
-def test_pipeline_three_steps(kind):
-    """The oracle denoise loop vs CustomCogVideoXPipeline.__call__ (3 steps, tiny modules, 480x720, fp32)."""
-    g = load_golden("pipeline_tiny.npz")
+def _check_steps(got, g, name, atol):
+    """per-step tensors against the fixture's quarter subsample and its fp64 sums (oracle/make_golden.py:put_steps)"""
+    x = torch.stack([y.float() for y in got])
+    exp = g[name + "_sub2"]
+    np.testing.assert_allclose(x[..., ::2, ::2].numpy(), exp, atol=atol * max(1.0, np.abs(exp).max()), rtol=0)
+    sums = torch.stack([x.double().sum(dim=(1, 2, 3, 4, 5)), x.double().abs().sum(dim=(1, 2, 3, 4, 5))], dim=1).numpy()
+    np.testing.assert_allclose(sums[:, 1], g[name + "_sums"][:, 1], rtol=1e-4)
+    np.testing.assert_allclose(sums[:, 0], g[name + "_sums"][:, 0], atol=1e-4 * g[name + "_sums"][:, 1].max())
+
+
+def _oracle_loop(g, kind, dyn=False):
+    """the oracle denoise loop on the fixture's inputs: returns per-step CFG-combined noise predictions and latents"""
     sd = weights_of(g)
     cfg = dict(TINY_CFG, use_rope=True)
     pe, ne, ref, lat = t(g["prompt_embeds"]), t(g["negative_prompt_embeds"]), t(g["ref"]), t(g["latents0"])
@@ -168,11 +176,14 @@ def test_pipeline_three_steps(kind):
     ts = sched_ref.trailing_timesteps(3)
     gen = torch.Generator().manual_seed(int(g["dpm_noise_seed"]))
     old = None
+    nps, lats = [], []
     with torch.no_grad():
         for i, tt in enumerate(ts):
             x = torch.cat([lat] * 2)
             npred = tr.transformer_forward(sd, cfg, x, text, ref, torch.tensor([tt, tt]), rope, ref_rope)
-            v = sched_ref.cfg_combine(npred, 6.0)
+            gs = sched_ref.dynamic_guidance(6.0, 3, i) if dyn else 6.0
+            v = sched_ref.cfg_combine(npred, gs)
+            nps.append(v)
             if kind == "ddim":
                 lat, _ = sched_ref.ddim_step(ac, 3, v, int(tt), lat)
             else:
@@ -181,8 +192,43 @@ def test_pipeline_three_steps(kind):
                 n2 = torch.randn(lat.shape, generator=gen) if (old is not None and prev_t >= 0) else None
                 lat, old = sched_ref.dpm_step(ac, 3, v, old, int(tt), int(ts[i - 1]) if i > 0 else None, lat, n1, n2)
             lat = lat.float()
+            lats.append(lat)
+    return nps, lats
+
+
+@pytest.mark.parametrize("kind", ["ddim", "dpm"])
+def test_pipeline_three_steps(kind):
+    """The oracle denoise loop vs CustomCogVideoXPipeline.__call__ (3 steps, tiny modules, 480x720, fp32): what the loop hands to
+    scheduler.step and gets back at EVERY step (custom_cogvideox_pipe.py:255-296), and the final latents."""
+    g = load_golden("pipeline_tiny.npz")
+    nps, lats = _oracle_loop(g, kind)
     exp = g[f"final_{kind}"]
-    np.testing.assert_allclose(lat.numpy(), exp, atol=5e-5 * max(1.0, np.abs(exp).max()), rtol=0)
+    np.testing.assert_allclose(lats[-1].numpy(), exp, atol=5e-5 * max(1.0, np.abs(exp).max()), rtol=0)
+    _check_steps(nps, g, f"steps_noise_pred_{kind}", 5e-5)
+    _check_steps(lats, g, f"steps_latents_{kind}", 5e-5)
+
+
+def test_pipeline_dynamic_cfg_and_tiled_frames():
+    """use_dynamic_cfg=True (custom_cogvideox_pipe.py:268-271) and output_type="np" with VAE tiling on (src/inference.py:204-207;
+    decode_latents + postprocess_video, :309-311): the reference pipeline's own frames, 8 x 480 x 720 x 3, nine blended tiles"""
+    g = load_golden("pipeline_tiny.npz")
+    _, lats = _oracle_loop(g, "ddim", dyn=True)
+    exp = g["final_ddim_dyncfg"]
+    np.testing.assert_allclose(lats[-1].numpy(), exp, atol=5e-5 * max(1.0, np.abs(exp).max()), rtol=0)
+    _check_steps(lats, g, "steps_latents_ddim_dyncfg", 5e-5)
+    assert np.abs(g["final_ddim_dyncfg"] - g["final_ddim"]).max() > 1e-2  # the schedule really changed the guidance
+    # frames of the constant-guidance DDIM run through the tiny VAE, tiled
+    vsd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("vae:")}
+    with torch.no_grad():
+        video = vae_ref.decode_latents(vsd, PIPE_VAE_CFG, t(g["final_ddim"]), True)
+        frames = vae_ref.postprocess_np(video)
+    assert list(frames.shape) == list(g["frames_ddim_tiled_shape"]) == [1, 8, 480, 720, 3]
+    np.testing.assert_allclose(frames[:, :, ::8, ::8, :], g["frames_ddim_tiled_sub8"], atol=2e-5)
+    np.testing.assert_allclose(frames.astype(np.float64).sum(axis=(2, 3)), g["frames_ddim_tiled_sums"], rtol=1e-5)
+
+
+PIPE_VAE_CFG = dict(block_out_channels=(8, 8, 8, 8), layers_per_block=1, norm_num_groups=2, latent_channels=16, sample_height=480,
+                    sample_width=720, scaling_factor=0.7, temporal_compression_ratio=4)
 
 
 # ---------------------------------------------------------------------------------------------------- VAE
