@@ -24,7 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak (block-scaled f8f6f4 instructions), same guide
-CLASSES = ["gemm_qkv", "attention", "gemm_out", "gemm_ff1_gelu", "gemm_ff2", "ln_modulate", "qknorm_rope_vt"]
+PEAK_HBM_GBS = 8000.0     # HBM3E spec peak; ~6300 GB/s is what a float4 copy reaches (same guide)
+CLASSES = ["gemm_qkv", "attention", "gemm_out", "gemm_ff1_gelu", "gemm_ff2", "ln_modulate", "qknorm_rope_vt", "mod_gemv"]
 
 WORKLOADS = {
     # name: (preset, latent F, H, W, text tokens)
@@ -38,7 +39,7 @@ WORKLOADS = {
 }
 
 
-def load_synthetic(s2v, eng, cfg, seed):
+def load_synthetic(s2v, eng, cfg, seed, lora_rank=128):
     """near-identity N(0, 0.02^2) weights generated tensor by tensor on the GPU (timing weights)"""
     shapes = s2v.weights.state_dict_shapes(cfg)
     gen = torch.Generator(device=eng.device).manual_seed(seed)
@@ -52,8 +53,20 @@ def load_synthetic(s2v, eng, cfg, seed):
         eng.load_weight(k, t)
         eng._keep.clear()
         del t
+    # BASELINE configs[2] is "5B + subject-LoRA merged": a synthetic rank-128 adapter on every target of the reference's LoRA
+    # (src/inference.py:218-229: alpha / r = 64 / 128) is merged as W + 0.5 B A before the weights are finalised (and, for the fp8
+    # workloads, quantised) -- shapes and therefore timing are those of the merged model, as the reference runs it
+    n_lora = 0
+    for k in s2v.weights.lora_target_keys(cfg):
+        shp = shapes[k]
+        A = (torch.randn((lora_rank,) + tuple(shp[1:]), generator=gen, device=eng.device) * 0.02).reshape(lora_rank, -1).contiguous()
+        Bm = (torch.randn((shp[0], lora_rank), generator=gen, device=eng.device) * 0.02).contiguous()
+        s2v._lib.check(s2v.lib().s2v_merge_lora(eng._h, k.encode(), s2v._lib.ptr(A), s2v._lib.ptr(Bm), lora_rank, 0.5, s2v._lib.stream_ptr()))
+        torch.cuda.synchronize()
+        n_lora += 1
     s2v._lib.check(s2v.lib().s2v_finalize_weights(eng._h, s2v._lib.stream_ptr()))
     torch.cuda.synchronize()
+    return n_lora
 
 
 def cpu_baseline(s2v, cfg, F, H, W, T, dev):
@@ -94,16 +107,54 @@ def cpu_baseline(s2v, cfg, F, H, W, T, dev):
     torch.cuda.synchronize()
     y, e = torch.cat([x.float().cpu().flatten() for x in got]), torch.cat([x.flatten() for x in exp])
     step_s = dts * 2 * cfg.num_layers
+    N = T + R + V
+    blk_flop = 2 * N * D * 12 * D + 4 * N * N * D  # one block, one sample: QKV + out + FF1 + FF2 linears, QK^T + PV
+    vae_leg = cpu_baseline_vae(s2v, dev, cores)
     return {"value": 1.0 / step_s, "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": f"1 of {cfg.num_layers} transformer blocks x 1 of 2 CFG samples at the full token count, torch "
                       f"fp32 on {cores} threads: {dts:.1f} s, extrapolated x{2 * cfg.num_layers}",
+            "gflops": round(blk_flop / dts / 1e9, 1), "vae_decode": vae_leg,
             "max_abs_vs_hip": round((y - e).abs().max().item(), 5), "rel_l2_vs_hip": round(((y - e).norm() / e.norm()).item(), 6),
             "max_abs_ref": round(e.abs().max().item(), 3),
             "vs_hip_note": "the same block through s2v_block_forward in bf16 on the same bf16-rounded weights / inputs"}
 
 
+def cpu_baseline_vae(s2v, dev, cores):
+    """the second half of the metric (wall-clock per video) on the host cores: ONE frame batch (2 latent frames -> 8 frames) of a
+    12 x 16 latent window (96 x 128 pixels; torch's CPU conv3d runs at ~65 GFLOP/s on this box, a whole 30 x 45 tile takes two minutes)
+    of the real-width decoder through oracle.vae_ref, extrapolated by area to a tile and then to the tiled decode of 13 x 60 x 90 latents
+    (9 tiles x [one 3-frame + five 2-frame batches] = 58.5 tile-batches; autoencoder_kl_cogvideox.py:1237-1245, 1400-1406); the same
+    window through s2v_vae_decode is the check"""
+    from oracle import vae_ref
+
+    vcfg = s2v.VAEConfig(scaling_factor=0.7)
+    cfgd = dict(block_out_channels=tuple(vcfg.block_out_channels), layers_per_block=vcfg.layers_per_block, norm_num_groups=vcfg.norm_num_groups,
+                latent_channels=vcfg.latent_channels, out_channels=vcfg.out_channels, temporal_compression_ratio=vcfg.temporal_compression_ratio,
+                sample_height=vcfg.sample_height, sample_width=vcfg.sample_width, scaling_factor=vcfg.scaling_factor)
+    dt = torch.bfloat16
+    sd = {k: v.to(dt).float() for k, v in s2v.weights.synthetic_vae_state_dict(vcfg, seed=7).items()}
+    wh, ww = 12, 16
+    lat = torch.randn(1, 2, 16, wh, ww, generator=torch.Generator().manual_seed(23)).to(dt).float()
+    with torch.no_grad():
+        t0 = time.time()
+        exp = vae_ref.decode_latents(sd, cfgd, lat, False)
+        dts = time.time() - t0
+    vae = s2v.HipAutoencoderKLCogVideoX(vcfg, dt, dev)
+    vae.load_state_dict(sd)
+    got = vae.decode_latents(lat.to(dev, dt)).float().cpu()
+    torch.cuda.synchronize()
+    vae.close()
+    units = 9 * (5 + 1.5) * (30 * 45) / (wh * ww)
+    unit_flop = 441e12 / units  # BASELINE.md section 2: 441 TFLOP for the tiled decode of 49 x 480 x 720
+    return {"value": round(units * dts, 1), "unit": "s per tiled decode of 49 x 480 x 720 (extrapolated)", "cores": cores, "kind": "port",
+            "sample": f"one two-frame batch of a {wh} x {ww} latent window of the real-width decoder, torch fp32 on {cores} threads: {dts:.1f} s, "
+                      f"extrapolated x{units:.0f} (area, 9 tiles, 6.5 two-frame batches)",
+            "gflops": round(unit_flop / dts / 1e9, 1), "rel_l2_vs_hip": round(((got - exp).norm() / exp.norm()).item(), 6),
+            "max_abs_vs_hip": round((got - exp).abs().max().item(), 5), "max_abs_ref": round(exp.abs().max().item(), 3)}
+
+
 # kernel names as rocprofv3 prints them (template arguments included)
-KERNEL_OF_CLASS = {"attention": "attn_pp_persist_k<false>", "gemm_qkv": "gemm_bf16_pp64<4>", "gemm_ff1_gelu": "gemm_bf16_pp64<1>",
+KERNEL_OF_CLASS = {"attention": "attn_qx_persist_k<2>", "gemm_qkv": "gemm_bf16_pp64<4>", "gemm_ff1_gelu": "gemm_bf16_pp64<1>",
                    "gemm_out": "gemm_bf16_pp64<2>", "gemm_ff2": "gemm_bf16_pp64<2>"}  # <4>: QKV with the fused q/k norm + rotary epilogue
 
 
@@ -168,8 +219,9 @@ def main():
     dt = torch.bfloat16
     eng = s2v.S2VEngine(cfg, dt, dev)
     t_load = time.time()
+    n_lora = 0
     if rank == 0:
-        load_synthetic(s2v, eng, cfg, 1234)
+        n_lora = load_synthetic(s2v, eng, cfg, 1234)
     bcast_s = None
     if world > 1:
         torch.cuda.synchronize()
@@ -241,13 +293,18 @@ def main():
         torch.cuda.synchronize()
         prof_elapsed = time.perf_counter() - tp
         ms = (ctypes.c_float * 8)()
-        cnt = (ctypes.c_int32 * 8)()
+        cnt = (ctypes.c_int32 * 8)()  # eight classes: CLASSES
         s2v._lib.check(s2v.lib().s2v_profile_read(eng._h, ms, cnt, 8))
         s2v._lib.check(s2v.lib().s2v_profile_enable(eng._h, 0))
         N = T + (F + 1) * (H // 2) * (W // 2)
         D = cfg.inner_dim
         flops = {"gemm_qkv": 2 * 2 * N * D * 3 * D, "attention": 4 * 2 * N * N * D, "gemm_out": 2 * 2 * N * D * D,
                  "gemm_ff1_gelu": 2 * 2 * N * D * 4 * D, "gemm_ff2": 2 * 2 * N * D * 4 * D}
+        # HBM-bound kernels: algorithmic bytes per launch: LayerNorm + modulate reads and writes the residual
+        # stream once; the V transpose reads V and writes V^T; the modulation GEMV streams every norm linear's weights once per step
+        E = 2
+        mod_rows = 2 * cfg.num_layers * 6 * D + 2 * D
+        hbm_bytes = {"ln_modulate": 2 * (2 * N * D * E), "qknorm_rope_vt": 2 * (2 * N * D * E), "mod_gemv": mod_rows * cfg.time_embed_dim * E}
         per_kernel = {}
         for k, name in enumerate(CLASSES):
             if cnt[k] == 0:
@@ -258,6 +315,10 @@ def main():
                 e["tflops"] = round(flops[name] / avg / 1e9, 1)
                 e["peak_tflops"] = PEAK_FP8_TFLOPS if (fp8 and name.startswith("gemm_")) else PEAK_BF16_TFLOPS
                 e["frac_of_peak"] = round(e["tflops"] / e["peak_tflops"], 4)
+            if name in hbm_bytes:
+                e["bound"] = "hbm"
+                e["gb_per_s"] = round(hbm_bytes[name] / avg / 1e6, 1)
+                e["frac_of_hbm_peak"] = round(e["gb_per_s"] / PEAK_HBM_GBS, 4)
             per_kernel[name] = e
         dom = max((n for n in per_kernel if n in flops), key=lambda n: per_kernel[n]["avg_ms"] * per_kernel[n]["launches"])
         ach = per_kernel[dom]["tflops"]
@@ -336,7 +397,7 @@ def main():
                        "hipgraph": bool(args.graph), "graph_ms_per_step": None if graph_ms is None else round(graph_ms, 2),
                        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 2),
                        "per_gpu_steps_per_s": round(args.steps / elapsed, 4),
-                       "weight_load_s": round(t_load, 2), "weight_broadcast_s": None if bcast_s is None else round(bcast_s, 3),
+                       "lora_merged": f"rank-128 synthetic adapter on {n_lora} weights (alpha / r = 0.5)" if n_lora else None, "weight_load_s": round(t_load, 2), "weight_broadcast_s": None if bcast_s is None else round(bcast_s, 3),
                        "outputs_finite": finite},
             "roofline": roofline,
             "wall_clock_per_video": video,

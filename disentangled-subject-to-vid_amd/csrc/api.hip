@@ -676,7 +676,10 @@ static int forward_impl(s2v_ctx* c, const void* latents, int64_t lat_bstride, co
     const int64_t E = c->esz;
     // 1. timestep embedding + every AdaLN modulation of the step in one batched GEMV (temb is block-invariant)
     S2V_TRY(launch_time_embed(t_dev, B, D, c->te1_w, c->te1_b, c->te2_w, c->te2_b, c->temb, c->tmp_te, c->emb, c->dtype, st));
-    S2V_TRY(launch_mod_gemv(c->emb, B, c->temb, c->mod_w, c->mod_b, c->mod_rows, c->mod, c->dtype, st));
+    {
+        ProfScope ps(c, PK_OTHER, st);  // the step's modulation GEMV: every norm1 / norm2 / norm_out linear in one launch
+        S2V_TRY(launch_mod_gemv(c->emb, B, c->temb, c->mod_w, c->mod_b, c->mod_rows, c->mod, c->dtype, st));
+    }
     // 2. residual streams: [text | ref | video] per sample
     const int K = c->cfg.in_channels * 4;
     S2V_TRY(launch_patchify(latents, lat_bstride, B, c->F, c->cfg.in_channels, c->H, c->W, c->patches, c->dtype, st));
