@@ -104,7 +104,7 @@ def diag_lib():
     if _diag is None:
         if not os.path.exists(DIAG_LIB_PATH):
             raise S2VError(f"{DIAG_LIB_PATH} is missing: build it with `python {os.path.join(_HERE, 'build.py')} --diag`")
-        l = ctypes.CDLL(DIAG_LIB_PATH)
+        l = ctypes.CDLL(os.environ.get("S2V_DIAG_LIB", DIAG_LIB_PATH))  # S2V_DIAG_LIB: an experiment build (tools/g4_ablate.sh)
         _apply_sigs(l, {k: v for k, v in _SIGS.items() if k.startswith("s2v_op_")})
         l.s2v_last_error.restype = ctypes.c_char_p
         for name in ("s2v_set_gemm_impl", "s2v_set_attn_variant"):

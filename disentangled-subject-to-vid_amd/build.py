@@ -6,11 +6,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libs2v_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "attention.hip", "attention_q4.hip", "elementwise.hip", "vae.hip", "vae_api.hip", "t5.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_g4.hip", "attention.hip", "attention_q4.hip", "elementwise.hip", "vae.hip", "vae_api.hip", "t5.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value", "-Wno-inline-asm"]
 # the HBM-bound kernels mirror the reference's separately-rounded elementwise ops: no fma contraction there
 # (hipcc defaults to -ffp-contract=fast); the scheduler step is bit-exact against the CPU reference because of it
-EXTRA = {"attention_q4.hip": ["-fno-slp-vectorize"], "elementwise.hip": ["-ffp-contract=off"], "vae.hip": ["-ffp-contract=off"], "t5.hip": ["-ffp-contract=off"]}
+EXTRA = {"attention_q4.hip": ["-fno-slp-vectorize"], "gemm_g4.hip": ["-fno-slp-vectorize"], "elementwise.hip": ["-ffp-contract=off"], "vae.hip": ["-ffp-contract=off"], "t5.hip": ["-ffp-contract=off"]}
 
 
 def _stale(out, deps):
@@ -34,6 +34,9 @@ def build_library(force=False, verbose=True, diag=False):
     os.makedirs(objdir, exist_ok=True)
     gen = os.path.join(CSRC, "gen_attn_q4.py")  # generated asm of attention_q4.hip (outputs are committed; regenerated when stale)
     if _stale(os.path.join(CSRC, "attn_q4_body.inc"), [gen]):
+        subprocess.check_call([sys.executable, gen])
+    gen = os.path.join(CSRC, "gen_gemm_g4.py")
+    if _stale(os.path.join(CSRC, "gemm_g4_body.inc"), [gen]):
         subprocess.check_call([sys.executable, gen])
     headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "s2v_hip.h"))

@@ -16,60 +16,9 @@
 #include "kernels.h"
 #include <type_traits>
 #include <algorithm>
+#include <cstdlib>
 
-// ---------------------------------------------------------------------------------------------------
-// shared epilogue: 4 consecutive columns n..n+3 of row m
-template <typename T, int EPI>
-__device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, const float v[4]) {
-    if (m >= a.M) return;
-    const T* bias = (const T*)a.bias;
-    float y[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float bv = (bias && n + i < a.N) ? ET<T>::ld(bias + n + i) : 0.f;
-        y[i] = ET<T>::rnd(v[i] + bv);
-    }
-    if (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = ET<T>::rnd(gelu_tanh_f(y[i]));
-    }
-    if (EPI == EPI_BIAS_GATE_RES) {
-        const int b = m / a.tok_per_batch;
-        const int r = m - b * a.tok_per_batch;
-        const void* gsel = r < a.text_len ? a.gate_txt : (a.gate_ref != nullptr && r < a.text_len + a.ref_len) ? a.gate_ref : a.gate_vid;
-        const T* gate = (const T*)gsel + (size_t)b * a.gate_stride;
-        T* x = (T*)a.X + (size_t)m * a.ldx + n;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (n + i < a.N) {
-                float t = ET<T>::rnd(ET<T>::ld(gate + n + i) * y[i]);
-                ET<T>::st(x + i, ET<T>::ld(x + i) + t);
-            }
-        }
-        return;
-    }
-    if (EPI == EPI_BIAS_ADD) {
-        const T* r = (const T*)a.R + (size_t)m * a.ldr + n;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (n + i < a.N) y[i] = y[i] + ET<T>::ld(r + i);
-    }
-    T* c = (T*)a.C + (size_t)m * a.ldc + n;
-    if (n + 3 < a.N && (a.ldc & 3) == 0) {
-        if (sizeof(T) == 2) {
-            u32x2 p;
-            p.x = pack2bf(y[0], y[1]);
-            p.y = pack2bf(y[2], y[3]);
-            *(u32x2*)c = p;
-        } else {
-            *(f32x4*)c = (f32x4){y[0], y[1], y[2], y[3]};
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (n + i < a.N) ET<T>::st(c + i, y[i]);
-    }
-}
+#include "gemm_epi.h"
 
 // ---------------------------------------------------------------------------------------------------
 // bf16 MFMA kernel
@@ -134,200 +83,6 @@ __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ g, int ld,
 __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int cl) {
     const int off = row * 128 + ((cl ^ ((row >> 1) & 7)) << 4);
     return *(const bf16x8*)(tile + off);
-}
-
-// bias of a wave's 64 columns, 4 per lane and (i, rq).  The whole-tile case is ONE clause of eight independent loads (a per-load
-// bounds branch serialised them: eight global latencies, ~6000 cycles of a 128 x 64 epilogue)
-__device__ __forceinline__ void load_bias64(const GemmArgs& a, int nw, int hi, u32x2 (&bvec)[8]) {
-    const bf16_t* bias = (const bf16_t*)a.bias;
-    if (bias && nw + 64 <= a.N) {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) bvec[q] = *(const u32x2*)(bias + nw + (q >> 2) * 32 + 8 * (q & 3) + 4 * hi);  // 8-byte aligned
-    } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int nl = (q >> 2) * 32 + 8 * (q & 3) + 4 * hi;
-            unsigned short t[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (bias && nw + nl + e < a.N) t[e] = ((const unsigned short*)bias)[nw + nl + e];
-            bvec[q] = u32x2{(unsigned)t[0] | ((unsigned)t[1] << 16), (unsigned)t[2] | ((unsigned)t[3] << 16)};
-        }
-    }
-}
-
-// Epilogue of one wave's 64(m) x 64(n) accumulator tile (2x2 MFMA 32x32 blocks, D[i = n][j = m]).
-// Accumulator layout -> +bias, (GELU), round to bf16 in registers -> the wave's private 8 KiB LDS patch (rows of
-// 128 B, 16-B chunks XOR-swizzled by row&7) -> read back row-major, 16 B per lane, 8 lanes per 128-B line -> gate /
-// residual in that layout -> full-line global stores.  A row-per-lane epilogue (8-B stores at a row stride) was
-// store-issue bound: ~0.7 ms of a 3.4 ms FF1 launch.
-// GRP = rows-of-8 groups whose patch reads and gate / residual loads are in flight together (one memory latency per GRP groups)
-template <int EPI, int MB, bool SC = false, int GRP = 4>
-__device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 (&acc)[2][MB], int mw, int nw, char* patch, int lane,
-                                                const u32x2 (&bvec)[8]) {
-    // MB 32-row blocks: the patch holds MB*32 rows of 128 B (8 KiB for MB = 2, 16 KiB for MB = 4); all accumulator blocks are
-    // written first, then read back, so the LDS round trip is paid once per wave tile
-    const int fr = lane & 31, hi = lane >> 5;
-    const int c16 = lane & 7;
-    // EPI_BIAS_QKNORM: this wave's 64 columns are ONE head of q, k or v (nw % 64 == 0); 8 lanes hold a row of it.  The rotary
-    // values of a row group (4 cos + 4 sin per lane: the table stores every duplicated pair once) are requested one group AHEAD of
-    // their use -- fetched with the read-back they cost the epilogue a memory latency per group (0.16 ms per QKV launch at C3)
-    const bool qk_head = EPI == EPI_BIAS_QKNORM && nw < 2 * a.qk_D;
-    const bool qk_rot = qk_head && a.qk_cs != nullptr;
-    float qw[8], qb[8];
-    f32x4 rc[2][GRP], rs[2][GRP];
-    bool rope[2][GRP];
-    auto rot_load = [&](int it0, int buf) {
-        const float inv_tok = 1.0f / (float)a.tok_per_batch;
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) {
-            const int m = min(mw + (it0 + u) * 8 + (lane >> 3), a.M - 1);
-            int b = (int)((float)m * inv_tok);  // m / tok_per_batch without the integer division (corrected below)
-            int r = m - b * a.tok_per_batch;
-            if (r < 0) r += a.tok_per_batch;
-            if (r >= a.tok_per_batch) r -= a.tok_per_batch;
-            rope[buf][u] = qk_rot && r >= a.text_len;
-            const float* tp = a.qk_cs + (size_t)(rope[buf][u] ? r - a.text_len : 0) * 64 + c16 * 4;
-            if (qk_rot) {
-                rc[buf][u] = *(const f32x4*)tp;
-                rs[buf][u] = *(const f32x4*)(tp + 32);
-            }
-        }
-    };
-    if (EPI == EPI_BIAS_QKNORM) {
-        const int which = nw >= a.qk_D;
-        const u32x4 w4 = *(const u32x4*)((const bf16_t*)a.qk_w[which] + c16 * 8), b4 = *(const u32x4*)((const bf16_t*)a.qk_b[which] + c16 * 8);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            qw[2 * e] = __uint_as_float(w4[e] << 16); qw[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
-            qb[2 * e] = __uint_as_float(b4[e] << 16); qb[2 * e + 1] = __uint_as_float(b4[e] & 0xffff0000u);
-        }
-        rot_load(0, 0);
-    }
-    // SC (fp8 operands): acc * a_scale[row] * w_scale[column] first -- the dequantisation of the per-token / per-channel scales
-    float sa[MB];
-#pragma unroll
-    for (int j = 0; j < MB; ++j) sa[j] = SC ? a.a_scale[min(mw + j * 32 + fr, a.M - 1)] : 1.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const int nl = i * 32 + 8 * rq + 4 * hi;  // local column of 4 consecutive outputs
-            const u32x2 bq = bvec[i * 4 + rq];
-            f32x4 sw = {1.f, 1.f, 1.f, 1.f};
-            if (SC) sw = *(const f32x4*)(a.w_scale + nw + nl);  // the scale array is padded to the 256-column tile
-            const float bv[4] = {__uint_as_float(bq.x << 16), __uint_as_float(bq.x & 0xffff0000u), __uint_as_float(bq.y << 16),
-                                 __uint_as_float(bq.y & 0xffff0000u)};
-#pragma unroll
-            for (int j = 0; j < MB; ++j) {
-                float y[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) y[e] = (SC ? acc[i][j][rq * 4 + e] * (sa[j] * sw[e]) : acc[i][j][rq * 4 + e]) + bv[e];
-                const int row = j * 32 + fr;
-                u32x2 p;
-                p.x = pack2bf(y[0], y[1]);  // the linear's bf16 output (one rounding; a single wave per SIMD issues a VALU
-                p.y = pack2bf(y[2], y[3]);  // instruction every ~5 cycles, so the instruction count of this loop is its time)
-                if (EPI == EPI_BIAS_GELU) {  // GELU of the ROUNDED linear output, rounded again
-                    p.x = pack2bf(gelu_tanh_fast(__uint_as_float(p.x << 16)), gelu_tanh_fast(__uint_as_float(p.x & 0xffff0000u)));
-                    p.y = pack2bf(gelu_tanh_fast(__uint_as_float(p.y << 16)), gelu_tanh_fast(__uint_as_float(p.y & 0xffff0000u)));
-                }
-                *(u32x2*)(patch + row * 128 + ((((nl >> 3) ^ (row & 7))) << 4) + (nl & 4) * 2) = p;
-            }
-        }
-    // same-wave LDS accesses are ordered; the compiler inserts the lgkmcnt wait for the dependent reads
-    const int n = nw + c16 * 8;
-    const bool n_ok = n < a.N;            // epi_vec_ok: N % 8 == 0, so a started 8-column group is whole
-    const int nc = n_ok ? n : 0;          // loads stay in range (and unconditional: four rows' worth in flight at a time)
-#pragma unroll
-    for (int it0 = 0; it0 < MB * 4; it0 += GRP) {
-        u32x4 v[GRP], g[GRP], xo[GRP];
-        int mrow[GRP];
-        const int cur = (it0 / GRP) & 1;
-        if (EPI == EPI_BIAS_QKNORM && it0 + GRP < MB * 4) rot_load(it0 + GRP, cur ^ 1);
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) {
-            const int row = (it0 + u) * 8 + (lane >> 3);
-            mrow[u] = mw + row;
-            v[u] = *(const u32x4*)(patch + row * 128 + ((c16 ^ (row & 7)) << 4));
-            const int m = min(mrow[u], a.M - 1);
-            if (EPI == EPI_BIAS_GATE_RES) {
-                const int b = m / a.tok_per_batch;
-                const int r = m - b * a.tok_per_batch;
-                const void* gsel = r < a.text_len ? a.gate_txt : (a.gate_ref != nullptr && r < a.text_len + a.ref_len) ? a.gate_ref : a.gate_vid;
-                g[u] = *(const u32x4*)((const bf16_t*)gsel + (size_t)b * a.gate_stride + nc);
-                xo[u] = *(const u32x4*)((const bf16_t*)a.X + (size_t)m * a.ldx + nc);
-            } else if (EPI == EPI_BIAS_ADD) {
-                xo[u] = *(const u32x4*)((const bf16_t*)a.R + (size_t)m * a.ldr + nc);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) {
-            u32x4 o = v[u];
-            if (EPI == EPI_BIAS_QKNORM && qk_head) {  // qk_norm_rope_k's arithmetic on the rounded projection, lane = (row, octet)
-                float x[8];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(v[u][e] << 16); x[2 * e + 1] = __uint_as_float(v[u][e] & 0xffff0000u); }
-                float s = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) s += x[e];
-                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
-                const float mean = s * (1.0f / 64.0f);
-                float q = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { const float d = x[e] - mean; q += d * d; }
-                q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
-                const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + a.qk_eps);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = bf2f(f2bf((x[e] - mean) * rstd * qw[e] + qb[e]));
-                if (rope[cur][u]) {
-#pragma unroll
-                    for (int e = 0; e < 8; e += 2) {
-                        const float x0 = x[e], x1 = x[e + 1];
-                        const float cc = rc[cur][u][e >> 1], ss = rs[cur][u][e >> 1];  // cos / sin of the pair (e, e + 1)
-                        x[e] = bf2f(f2bf(x0 * cc + (-x1) * ss));
-                        x[e + 1] = bf2f(f2bf(x1 * cc + x0 * ss));
-                    }
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = pack2bf(x[2 * e], x[2 * e + 1]);
-            }
-            if (EPI == EPI_BIAS_GATE_RES) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t0 = bf2f(f2bf(__uint_as_float(g[u][e] << 16) * __uint_as_float(v[u][e] << 16)));
-                    const float t1 = bf2f(f2bf(__uint_as_float(g[u][e] & 0xffff0000u) * __uint_as_float(v[u][e] & 0xffff0000u)));
-                    o[e] = pack2bf(__uint_as_float(xo[u][e] << 16) + t0, __uint_as_float(xo[u][e] & 0xffff0000u) + t1);
-                }
-            } else if (EPI == EPI_BIAS_ADD) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    o[e] = pack2bf(__uint_as_float(v[u][e] << 16) + __uint_as_float(xo[u][e] << 16),
-                                   __uint_as_float(v[u][e] & 0xffff0000u) + __uint_as_float(xo[u][e] & 0xffff0000u));
-            }
-            if (mrow[u] < a.M && n_ok) {
-                if (EPI == EPI_BIAS_GATE_RES) *(u32x4*)((bf16_t*)a.X + (size_t)mrow[u] * a.ldx + n) = o;
-                else *(u32x4*)((bf16_t*)a.C + (size_t)mrow[u] * a.ldc + n) = o;
-            }
-        }
-    }
-}
-template <int EPI, int MB, bool SC = false>
-__device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x16 (&acc)[2][MB], int mw, int nw, char* patch, int lane) {
-    u32x2 bvec[8];
-    load_bias64(a, nw, lane >> 5, bvec);
-    epilogue_wave_b<EPI, MB, SC, 4>(a, acc, mw, nw, patch, lane, bvec);
-}
-template <int EPI>
-__device__ __forceinline__ void epilogue_wave64(const GemmArgs& a, const f32x16 (&acc)[2][2], int mw, int nw, char* patch,
-                                                int lane) {
-    epilogue_wave<EPI, 2>(a, acc, mw, nw, patch, lane);
-}
-// vectorised epilogue is usable when whole 8-column groups exist and rows are 16-byte aligned
-__host__ __device__ __forceinline__ bool epi_vec_ok(const GemmArgs& a, int epi) {
-    if ((a.N & 7) != 0) return false;
-    if (epi == EPI_BIAS_GATE_RES) return (a.ldx & 7) == 0 && (a.gate_stride & 7) == 0;
-    if (epi == EPI_BIAS_ADD && (a.ldr & 7) != 0) return false;
-    return (a.ldc & 7) == 0;
 }
 
 template <int EPI>
@@ -1393,11 +1148,11 @@ static int launch_stag_t(const GemmArgs& a, hipStream_t st) {
 // lock-step ring and the compile-time ablations of gemm_bf16_pp64 (tools/ablate_gemm.py, tools/stall_pp64.py).
 #ifdef S2V_DIAG
 int g_gemm_ablate = 0;
-int g_gemm_impl = 7;
+int g_gemm_impl = 9;  // 9: gemm_g4 where it qualifies, gemm_bf16_pp64 otherwise (the product's choice); 7: gemm_bf16_pp64; 5 / 8: A/B references
 extern "C" __attribute__((visibility("default"))) int s2v_set_gemm_impl(int impl) { g_gemm_impl = impl & 0xff; g_gemm_ablate = impl >> 8; return 0; }
 #else
 static constexpr int g_gemm_ablate = 0;
-static constexpr int g_gemm_impl = 7;
+static constexpr int g_gemm_impl = 9;  // 9: gemm_g4 where it qualifies, gemm_bf16_pp64 otherwise (the product's choice); 7: gemm_bf16_pp64; 5 / 8: A/B references
 #endif
 
 template <int EPI>
@@ -1467,7 +1222,12 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
         return epi == EPI_BIAS ? launch_q4_t<EPI_BIAS>(a, st) : launch_q4_t<EPI_BIAS_GELU>(a, st);
     }
 #endif
-    if ((g_gemm_impl == 7 || g_gemm_impl == 8) && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+    bool g4_epi = true;
+#ifdef S2V_DIAG
+    if (const char* e = getenv("S2V_G4_EPI_MASK")) g4_epi = (atoi(e) >> epi) & 1;  // bisecting aid: g4 for the epilogues of the mask only
+#endif
+    if (g_gemm_impl == 9 && g4_epi && w_tile_ok(a) && gemm_g4_ok(a, epi)) return launch_gemm_g4(a, epi, st);  // four-wave generated-asm K loop
+    if ((g_gemm_impl == 7 || g_gemm_impl == 8 || g_gemm_impl == 9) && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
             case EPI_BIAS: return launch_pp64_t<EPI_BIAS>(a, st);

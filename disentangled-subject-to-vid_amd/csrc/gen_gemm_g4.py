@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Generator of the K loop of gemm_g4 (csrc/gemm_g4.hip): writes gemm_g4_body.inc -- ONE asm statement that takes a 256 x 256 output
+tile from "nothing staged" to "accumulators complete" -- and gemm_g4_regs.h (its register constraints, clobbers and LDS size).  Run by
+build.py when the outputs are older than this script; the outputs are committed.
+
+Shape of the kernel: four waves (2 x 2), ONE per SIMD, 128 x 128 wave tiles (256 accumulator registers in the AGPR half of the file),
+K-tiles of 64 bf16 = 128-byte LDS rows in two 64-KiB stages ([A 256 rows | W 256 rows] each), operands by LDS-DMA.  A wave tile of
+128 x 128 reads 8 fragments per 16 MFMA where the eight-wave 128 x 64 tiling of gemm_bf16_pp64 reads 12, and with one wave per SIMD
+nothing arbitrates: the stream below IS the schedule.  Per K-tile and wave: 64 MFMA (2065 matrix-pipe cycles), 32 ds_read_b128,
+16 LDS-DMA pieces + 16 M0 writes, 4 SALU of pointer arithmetic, ONE barrier -- 1.1 fillers per MFMA where the
+pipe hides ~5.
+Why asm (as attention_q4): with more than 256 registers hipcc selects AGPR-form MFMAs and moves operands through v_accvgpr copies, puts
+s_nop / s_waitcnt where its hazard model wants them and the 64-bit-vaddr form of the LDS-DMA inside loops; the round-2 C++ kernel of
+this shape (gemm_q4, diagnostics library) ran 2300-2500 cycles per K-tile.
+
+What the measurements said (tools/stall_g4.py, tools/g4_ablate.sh; cycles per K-tile, floor 2065):
+  * without the LDS-DMA instructions the loop runs AT the floor (2063.5) with every read, wait and barrier in place: all overhead is
+    DMA -- its issue cost or its latency;
+  * pieces one per two MFMAs over the two steps after the stage's barrier (this schedule, without the prefetch): 2136 (QKV), 2177 (FF1),
+    2250 (out), 2400 (FF2); without the barrier (waits kept) FF2 drops to 2092: waves wait at the barrier for data that had
+    1500-2000 cycles to arrive;
+  * all 16 pieces right behind the barrier (earliest possible issue): 2770 -- back-to-back LDS-DMA instructions stall the issuing wave
+    for hundreds of cycles: pieces must be SPREAD;
+  * a ring of five K32 stages (64-byte rows, pieces four tiles ahead, one per four MFMAs): 2410-2750 -- a piece then touches sixteen
+    half cache lines instead of eight whole ones.
+  * an L2 prefetch (G4_PF > 0: PF K-tiles ahead each wave touches the 128 cache lines of its own future pieces with two
+    global_load_dword, one lane per line, result discarded): 2470-3070 -- a load with 64 distinct lines per instruction occupies the
+    CU's address path longer than the latency it was meant to hide.
+So the schedule below stands: 3-4 % faster than gemm_bf16_pp64 on the four C3 shapes (profiles/r03_gemm_g4.txt); what is left above the
+floor is the latency of operands that come from beyond the XCD's L2, which two stages cannot cover.
+
+Schedule of K-tile t (stage g = t & 1), four steps s of 16 MFMA (acc[i][j] += W-fragment i x A-fragment j of k-step s):
+  every step : first 8 MFMA slots carry the 8 fragment reads of the NEXT step (step 3: of step 0 of K-tile t+1, other stage)
+  step 0     : W pieces of K-tile t+1 -> stage g^1 (its W region was last read in step 2 of K-tile t-1)
+  step 1     : (G4_PF > 0 only) the two prefetch loads of K-tile t+PF
+  step 3     : s_waitcnt vmcnt(0) lgkmcnt(0) (vmcnt(2) with the prefetch) + s_barrier first, then A pieces of K-tile t+2 -> stage g (free since that barrier)
+RAW: K-tile t+1 (A issued in step 3 of t-1, W in step 0 of t) is awaited by every wave's vmcnt before the barrier of step 3 of t; its first read is that step's prefetch.  WAR: the last reads of stage g's
+A (W) region are the prefetch of step 2 of K-tile t (step 2 of t-1 for stage g^1's W region), completed (lgkmcnt(0)) before the barrier
+that precedes the overwriting DMA.
+Registers: a[0:255] acc[i][j] at 64 i + 16 j (OUT); v[0:63] fragments [buffer][W 0-3 | A 0-3]; v[64:79] IN fragment addresses
+[A | W][stage][step]; v[80:95] IN staging offsets [A | W][piece]; v[96:97] IN prefetch offsets A / W (lane = one cache line of the wave's
+pieces); v[98:99] prefetch results (never read); s[36:37] / s[38:39] IN next A / W K-tile to stage; s40 IN LDS address of the wave's
+piece 0 of A in stage 0; s41 IN number of [odd, even] K-tile pairs of the loop = (nT - 2 - max(PF, 2)) / 2; nT = K / 64 even, >= 4.
+"""
+import os
+
+ACC, FRAG, VADDR, VOFF, VPF, VPFD = 0, 0, 64, 80, 96, 98
+S_A, S_W, S_M0W, S_CNT = 36, 38, 40, 41
+ABLATE = set(filter(None, os.environ.get("G4_ABLATE", "").split(",")))
+PF = int(os.environ.get("G4_PF", "0"))  # K-tiles between the L2 prefetch of a tile and its staging (0: none -- the default, see above); even
+
+
+def vr(b, n=1):
+    return f"v{b}" if n == 1 else f"v[{b}:{b + n - 1}]"
+
+
+def ar(b, n):
+    return f"a[{b}:{b + n - 1}]"
+
+
+def wf(buf, i):
+    return FRAG + 32 * buf + 4 * i
+
+
+def af(buf, j):
+    return FRAG + 32 * buf + 16 + 4 * j
+
+
+def vaddr(is_w, g, s):
+    return VADDR + (8 if is_w else 0) + 4 * g + s
+
+
+def ktile(emit, g, first=False, dma_w=True, dma_a=True, last=False, prefetch=False):
+    for s in range(4):
+        cur, nxt = s & 1, (s & 1) ^ 1
+        if s == 3 and not last:
+            emit(f"s_waitcnt vmcnt({2 if (prefetch and PF) else 0}) lgkmcnt(0)")
+            emit("s_barrier")
+        else:
+            emit("s_waitcnt lgkmcnt(0)")
+        for k in range(16):
+            i, j = k >> 2, k & 3
+            acc = ar(ACC + 64 * i + 16 * j, 16)
+            c = "0" if (first and s == 0) else acc
+            emit(f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(wf(cur, i), 4)}, {vr(af(cur, j), 4)}, {c}")
+            if k < 8 and not (last and s == 3):
+                gs, ss = (g, s + 1) if s < 3 else (g ^ 1, 0)
+                if k < 4:
+                    emit(f"ds_read_b128 {vr(wf(nxt, k), 4)}, {vr(vaddr(True, gs, ss))} offset:{k * 4096}")
+                else:
+                    emit(f"ds_read_b128 {vr(af(nxt, k - 4), 4)}, {vr(vaddr(False, gs, ss))} offset:{(k - 4) * 4096}")
+            p = k >> 1
+            if s == 0 and dma_w:  # W piece p of K-tile t+1 -> stage g^1
+                if k & 1 == 0:
+                    emit(f"s_add_u32 m0, s{S_M0W}, {(g ^ 1) * 65536 + 32768 + p * 4096}")
+                else:
+                    emit(f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]")
+            if s == 3 and dma_a:  # A piece p of K-tile t+2 -> stage g
+                if k & 1 == 0:
+                    emit(f"s_add_u32 m0, s{S_M0W}, {g * 65536 + p * 4096}")
+                else:
+                    emit(f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]")
+            if s == 1 and prefetch and PF:  # the A pointer is at K-tile t+2, the W pointer (advanced in step 0) too
+                if k == 3:
+                    emit(f"global_load_dword {vr(VPFD)}, {vr(VPF)}, s[{S_A}:{S_A + 1}] offset:{(PF - 2) * 128}")
+                if k == 11:
+                    emit(f"global_load_dword {vr(VPFD + 1)}, {vr(VPF + 1)}, s[{S_W}:{S_W + 1}] offset:{(PF - 2) * 128}")
+        if s == 0 and dma_w:
+            emit(f"s_add_u32 s{S_W}, s{S_W}, 128")
+            emit(f"s_addc_u32 s{S_W + 1}, s{S_W + 1}, 0")
+        if s == 3 and dma_a:
+            emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
+            emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
+
+
+def gen():
+    L = []
+
+    def emit(ln):
+        op = ln.split()[0]
+        if "nodma" in ABLATE and op == "global_load_lds_dwordx4":
+            return
+        if "noread" in ABLATE and op == "ds_read_b128":
+            return
+        if "nobar" in ABLATE and op == "s_barrier":
+            return
+        L.append(ln)
+
+    emit("; ---- gemm_g4 K loop (generated by gen_gemm_g4.py; do not edit)")
+    # prologue: K-tile 0 whole -> stage 0, A half of K-tile 1 -> stage 1 (its W half follows in step 0 of K-tile 0)
+    for p in range(8):
+        emit(f"s_add_u32 m0, s{S_M0W}, {p * 4096}")
+        emit("s_nop 0")
+        emit(f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]")
+    for p in range(8):
+        emit(f"s_add_u32 m0, s{S_M0W}, {32768 + p * 4096}")
+        emit("s_nop 0")
+        emit(f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]")
+    emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
+    emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
+    emit(f"s_add_u32 s{S_W}, s{S_W}, 128")
+    emit(f"s_addc_u32 s{S_W + 1}, s{S_W + 1}, 0")
+    for p in range(8):
+        emit(f"s_add_u32 m0, s{S_M0W}, {65536 + p * 4096}")
+        emit("s_nop 0")
+        emit(f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]")
+    emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
+    emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
+    for k in range(2, PF):  # the lines of K-tiles 2 .. PF-1 (pointer + (k - 2) * 128: the A pointer is at K-tile 2, the W pointer at 1)
+        emit(f"global_load_dword {vr(VPFD)}, {vr(VPF)}, s[{S_A}:{S_A + 1}] offset:{(k - 2) * 128}")
+        emit(f"global_load_dword {vr(VPFD + 1)}, {vr(VPF + 1)}, s[{S_W}:{S_W + 1}] offset:{(k - 1) * 128}")
+    emit(f"s_waitcnt vmcnt({8 + 2 * max(0, PF - 2)})")  # K-tile 0 landed; the A half of K-tile 1 (and the prefetches) stay in flight
+    emit("s_barrier")
+    for n in range(8):  # fragments of step 0 of K-tile 0
+        if n < 4:
+            emit(f"ds_read_b128 {vr(wf(0, n), 4)}, {vr(vaddr(True, 0, 0))} offset:{n * 4096}")
+        else:
+            emit(f"ds_read_b128 {vr(af(0, n - 4), 4)}, {vr(vaddr(False, 0, 0))} offset:{(n - 4) * 4096}")
+    # K-tile t prefetches K-tile t+PF (valid while t + PF <= nT - 1).  Sequence: FIRST (t = 0), then pairs [odd, even] with prefetch
+    # (s41 of them: t = 1 .. nT-PF-1), then PF/2 - 1 pairs and one odd tile without prefetch (t = nT-PF .. nT-3), then the two last tiles
+    emit("; K-tile 0")
+    ktile(emit, 0, first=True, prefetch=True)
+    emit("L_g4_loop_%=:")
+    emit(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    emit("s_cbranch_scc1 L_g4_nopf_%=")
+    ktile(emit, 1, prefetch=True)
+    ktile(emit, 0, prefetch=True)
+    emit(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    emit("s_branch L_g4_loop_%=")
+    emit("L_g4_nopf_%=:")
+    for _ in range(max(0, PF // 2 - 1)):
+        ktile(emit, 1)
+        ktile(emit, 0)
+    ktile(emit, 1)                            # K-tile nT-3: the last one that stages both halves
+    ktile(emit, 0, dma_a=False)               # K-tile nT-2: still stages the W half of K-tile nT-1
+    ktile(emit, 1, dma_w=False, dma_a=False, last=True)
+    emit("s_waitcnt vmcnt(0)")
+    emit("s_nop 15")  # the epilogue reads the accumulators next
+    emit("s_nop 15")
+    return L
+
+
+def main():
+    here = os.path.dirname(os.path.abspath(__file__))
+    with open(os.path.join(here, "gemm_g4_body.inc"), "w") as f:
+        for ln in gen():
+            f.write('"' + ln + '\\n\\t"\n')
+    clob = [f"v{r}" for r in range(0, 64)] + [f"v{VPFD}", f"v{VPFD + 1}"]
+    with open(os.path.join(here, "gemm_g4_regs.h"), "w") as f:
+        f.write("// generated by gen_gemm_g4.py: the physical registers the K loop of gemm_g4 owns, and its LDS size\n#pragma once\n")
+        f.write(f"#define G4_PF {PF}\n#define G4_LDS_BYTES 131072\n")
+        for k in range(8):
+            f.write(f'#define G4_ACC{k} "{{a[{32 * k}:{32 * k + 31}]}}"\n')
+        f.write(f'#define G4_VADDR "{{v[{VADDR}:{VADDR + 15}]}}"\n#define G4_VOFF "{{v[{VOFF}:{VOFF + 15}]}}"\n#define G4_VPF "{{v[{VPF}:{VPF + 1}]}}"\n')
+        f.write(f'#define G4_PTR "{{s[{S_A}:{S_A + 3}]}}"\n#define G4_SIN "{{s[{S_M0W}:{S_M0W + 1}]}}"\n')
+        f.write("#define G4_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + ', "vcc", "scc", "m0", "memory"\n')
+
+
+if __name__ == "__main__":
+    main()

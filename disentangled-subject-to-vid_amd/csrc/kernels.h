@@ -63,6 +63,9 @@ enum { EPI_BIAS_QKNORM = 4 };
 
 int launch_gemm_bf16(const GemmArgs& a, int epi, hipStream_t st);              // MFMA path, bf16 only
 int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st);  // any dtype, any shape
+// gemm_g4.hip: 256 x 256 tiles, four waves, generated-asm K loop (plain bf16 operands; gemm_g4_ok says whether a call qualifies)
+bool gemm_g4_ok(const GemmArgs& a, int epi);
+int launch_gemm_g4(const GemmArgs& a, int epi, hipStream_t st);
 // generic strided fp32 GEMM used at load time (LoRA merge): C[m,n] += alpha * sum_k A[m*sam+k*sak]*B[n*sbn+k*sbk]
 int launch_gemm_strided_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
                             float* C, int64_t ldc, int M, int N, int K, float alpha, hipStream_t st);

@@ -22,7 +22,7 @@ def run(L, A, W, b, M, N, K, epi, impl):
     assert rc == 0, lib.s2v_last_error()
     torch.cuda.synchronize()
     if impl is not None:
-        lib.s2v_set_gemm_impl(7)
+        lib.s2v_set_gemm_impl(9)  # the diagnostics library's default: the product's choice
     return C[:M]
 
 
@@ -46,6 +46,25 @@ def test_pingpong_matches_ring_bitwise_and_is_repeatable(s2v, M, N, K, epi):
     rel = ((ref.float() - y).norm() / y.norm()).item()
     assert rel <= 1e-2, rel
 
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (768, 512, 384), (1024, 768, 3072), (4096, 3072, 1024), (2560, 1024, 12288), (1152, 768, 1024)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_g4_generated_asm_kernel_matches_ring_bitwise_and_is_repeatable(s2v, M, N, K, epi):
+    """gemm_g4 (gemm_g4.hip: four waves, generated-asm K loop, the product's kernel for plain operands with an even number of K-tiles
+    >= 4) against the lock-step ring kernel: same products, same fp32 accumulation order per output element (k ascending in steps of
+    16), same epilogue code -- so BIT-IDENTICAL, launch after launch; shapes: the minimum of four K-tiles, six, the C3 depths, a padded
+    last column tile, an M of 4.5 row tiles (the op-level entry then takes the 128-row kernel for all of it: gemm_g4_ok refuses)"""
+    L = s2v._lib
+    g = torch.Generator().manual_seed(M + N + K + 1)
+    A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)
+    b = (torch.randn(N, generator=g) * 0.1).bfloat16().to(DEV)
+    ref = run(L, A, W, b, M, N, K, epi, 5)
+    assert torch.isfinite(ref.float()).all()
+    for rep in range(6):
+        out = run(L, A, W, b, M, N, K, epi, 9 if rep % 2 else None)  # diagnostics build with g4 selected / product build
+        assert torch.equal(out, ref), f"rep {rep}: max diff {(out.float() - ref.float()).abs().max().item()}"
 
 
 @pytest.mark.parametrize("epi", [0, 1])

@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 s2v = importlib.import_module("disentangled-subject-to-vid_amd")
 L = s2v._lib
 DEV = "cuda:0"
-LABELS = {0: "tile128x128", 2: "stag256x128", 5: "w8-lockstep", 7: "pp64-pingpong", 8: "q4-fourwave"}
+LABELS = {0: "tile128x128", 2: "stag256x128", 5: "w8-lockstep", 7: "pp64-pingpong", 8: "q4-fourwave", 9: "g4-asm"}
 IMPLS = [int(x) for x in os.environ.get("S2V_IMPLS", "7,5").split(",")]
 
 
