@@ -12,6 +12,8 @@
 #include <string>
 #include <unordered_map>
 #include <vector>
+#include <algorithm>
+#include <cstdlib>
 
 static inline int64_t rup64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
@@ -52,6 +54,22 @@ struct s2v_vae {
     std::vector<void*> geo_allocs;
     std::vector<char*> tiles; std::vector<int> tile_h, tile_w;
     int tiles_F = 0;
+    // Tiled decode: the tiles are independent until the blends, and at the latent levels a tile's GEMMs are a handful of workgroups
+    // (30 x 45 x 2 rows = 11 row tiles on 256 CUs).  NWS workspace sets -- every geometry-dependent buffer above, once per set -- let
+    // tiles k, k + 1, ... run concurrently on side streams; the members above always alias the ACTIVE set (ws_activate), so the launch
+    // sequences are written once.
+    struct WS {
+        std::vector<char*> pads;  // in for_each_conv order
+        char* dense[3] = {nullptr, nullptr, nullptr};
+        char *zq = nullptr, *yt = nullptr, *bt = nullptr;
+        double *sums = nullptr, *gn_part = nullptr;
+        int cur_h = 0, cur_w = 0;
+    };
+    std::vector<WS> ws;
+    int ws_active = 0, ws_req = 0;  // ws_req: sets asked for when ws was built (memory may have granted fewer)
+    std::vector<hipStream_t> side;  // one per workspace set beyond the first
+    std::vector<hipEvent_t> ev_side;
+    hipEvent_t ev_fork = nullptr;
     // every weight lives in ONE arena (replicas receive it by one broadcast, s2v_vae_weight_arena): the plan is built twice,
     // a sizing pass (arena == nullptr) that only adds up the carve-outs, then the real pass that bumps through the arena
     char* arena = nullptr;
@@ -115,6 +133,11 @@ static int make_resnet(s2v_vae* v, ResnetL& r, const std::string& name, int cin,
 }
 
 extern "C" void s2v_vae_destroy(s2v_vae* v) {
+    if (v) {
+        for (auto st_ : v->side) (void)hipStreamDestroy(st_);
+        for (auto e : v->ev_side) (void)hipEventDestroy(e);
+        if (v->ev_fork) (void)hipEventDestroy(v->ev_fork);
+    }
     if (!v) return;
     (void)hipDeviceSynchronize();
     for (void* p : v->allocs) (void)hipFree(p);
@@ -294,47 +317,96 @@ static void for_each_conv(s2v_vae* v, const std::function<void(ConvL&)>& fn) {
     fn(v->conv_out);
 }
 
-static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max) {
-    if (v->th >= th && v->tw >= tw && v->fmax[0] >= fz_max) return 0;
+// the live members <-> workspace set k
+static void ws_save(s2v_vae* v, int k) {
+    s2v_vae::WS& w = v->ws[k];
+    w.pads.clear();
+    for_each_conv(v, [&](ConvL& c) { w.pads.push_back(c.pad); });
+    for (int i = 0; i < 3; ++i) w.dense[i] = v->dense[i];
+    w.zq = v->zq; w.yt = v->yt; w.bt = v->bt; w.sums = v->sums; w.gn_part = v->gn_part;
+    w.cur_h = v->cur_h; w.cur_w = v->cur_w;
+}
+static void ws_activate(s2v_vae* v, int k) {
+    if (v->ws.empty() || k == v->ws_active) return;
+    v->ws[v->ws_active].cur_h = v->cur_h; v->ws[v->ws_active].cur_w = v->cur_w;
+    const s2v_vae::WS& w = v->ws[k];
+    size_t i = 0;
+    for_each_conv(v, [&](ConvL& c) { c.pad = w.pads[i++]; });
+    for (int j = 0; j < 3; ++j) v->dense[j] = w.dense[j];
+    v->zq = w.zq; v->yt = w.yt; v->bt = w.bt; v->sums = w.sums; v->gn_part = w.gn_part;
+    v->cur_h = w.cur_h; v->cur_w = w.cur_w;
+    v->ws_active = k;
+}
+
+static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws = 1) {
+    if (v->th >= th && v->tw >= tw && v->fmax[0] >= fz_max && v->ws_req >= nws) return 0;
     S2V_CHECK_HIP(hipDeviceSynchronize());
     for (void* p : v->geo_allocs) (void)hipFree(p);
     v->geo_allocs.clear();
     th = th > v->th ? th : v->th;
     tw = tw > v->tw ? tw : v->tw;
     fz_max = fz_max > v->fmax[0] ? fz_max : v->fmax[0];
+    nws = std::max(nws, v->ws_req);
+    v->ws_req = nws;
     v->th = th; v->tw = tw;
     // frames per level
     int f = fz_max, lvl = 0;
     v->fmax[0] = f;
     for (size_t s = 1; s < v->stages.size(); ++s)
         if (v->stages[s].has_up) { f = up_frames(f, v->stages[s].compress_time); v->fmax[++lvl] = f; }
-    int rc = 0;
-    int64_t dmax = 0;
-    for_each_conv(v, [&](ConvL& c) {
-        const int64_t H = (int64_t)th << c.level, W = (int64_t)tw << c.level;
-        const int F = v->fmax[c.level] + (c.kt == 3 ? 2 : 0);
-        c.pad_bytes = (int64_t)F * (H + 2) * (W + 2) * c.cin * v->esz + 1024;
-        if (!rc) rc = dmalloc(v, &c.pad, c.pad_bytes, true);
-        const int64_t d = (int64_t)v->fmax[c.level] * H * W * (c.cin > c.cout ? c.cin : c.cout) * v->esz;
-        dmax = d > dmax ? d : dmax;
-    });
-    if (rc) return rc;
-    v->dense_bytes = dmax + (int64_t)256 * 1024 * v->esz;  // + one 128-row MFMA tile of slack
-    for (int i = 0; i < 3; ++i) S2V_TRY(dmalloc(v, &v->dense[i], v->dense_bytes, true));
-    S2V_TRY(dmalloc(v, &v->zq, (int64_t)fz_max * th * tw * v->Cz * v->esz + 64, true));
-    {
-        int cmax = 0;
-        for_each_conv(v, [&](ConvL& c) { cmax = c.cin > cmax ? c.cin : cmax; });
-        S2V_TRY(dmalloc(v, &v->yt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
-        S2V_TRY(dmalloc(v, &v->bt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
-        {
-            int lv = 0;
-            for (size_t s = 1; s < v->stages.size(); ++s) if (v->stages[s].has_up) lv++;
-            const int64_t pmax = (int64_t)v->fmax[lv] * ((int64_t)th << lv) * ((int64_t)tw << lv);
-            S2V_TRY(dmalloc(v, &v->gn_part, gn_stats_scratch_bytes(pmax, v->G) + 64, true));
-        }
+    {  // as many sets as 70 % of the free memory holds (never fewer than one)
+        int64_t set_bytes = 0, dmax = 0;
+        for_each_conv(v, [&](ConvL& c) {
+            const int64_t H = (int64_t)th << c.level, W = (int64_t)tw << c.level;
+            set_bytes += (int64_t)(v->fmax[c.level] + (c.kt == 3 ? 2 : 0)) * (H + 2) * (W + 2) * c.cin * v->esz;
+            dmax = std::max(dmax, (int64_t)v->fmax[c.level] * H * W * std::max(c.cin, c.cout) * v->esz);
+        });
+        set_bytes += 3 * dmax;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && set_bytes > 0)
+            nws = (int)std::max<int64_t>(1, std::min<int64_t>(nws, (int64_t)(0.7 * (double)free_b) / set_bytes));
     }
-    v->cur_h = v->cur_w = 0;
+    v->ws.assign(nws, s2v_vae::WS());
+    for (int k = 0; k < nws; ++k) {
+        int rc = 0;
+        int64_t dmax = 0;
+        for_each_conv(v, [&](ConvL& c) {
+            const int64_t H = (int64_t)th << c.level, W = (int64_t)tw << c.level;
+            const int F = v->fmax[c.level] + (c.kt == 3 ? 2 : 0);
+            c.pad_bytes = (int64_t)F * (H + 2) * (W + 2) * c.cin * v->esz + 1024;
+            if (!rc) rc = dmalloc(v, &c.pad, c.pad_bytes, true);
+            const int64_t d = (int64_t)v->fmax[c.level] * H * W * (c.cin > c.cout ? c.cin : c.cout) * v->esz;
+            dmax = d > dmax ? d : dmax;
+        });
+        if (rc) return rc;
+        v->dense_bytes = dmax + (int64_t)256 * 1024 * v->esz;  // + one 128-row MFMA tile of slack
+        for (int i = 0; i < 3; ++i) S2V_TRY(dmalloc(v, &v->dense[i], v->dense_bytes, true));
+        S2V_TRY(dmalloc(v, &v->zq, (int64_t)fz_max * th * tw * v->Cz * v->esz + 64, true));
+        {
+            int cmax = 0;
+            for_each_conv(v, [&](ConvL& c) { cmax = c.cin > cmax ? c.cin : cmax; });
+            S2V_TRY(dmalloc(v, &v->yt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
+            S2V_TRY(dmalloc(v, &v->bt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
+            {
+                int lv = 0;
+                for (size_t s = 1; s < v->stages.size(); ++s) if (v->stages[s].has_up) lv++;
+                const int64_t pmax = (int64_t)v->fmax[lv] * ((int64_t)th << lv) * ((int64_t)tw << lv);
+                S2V_TRY(dmalloc(v, &v->gn_part, gn_stats_scratch_bytes(pmax, v->G) + 64, true));
+            }
+        }
+        S2V_TRY(dmalloc(v, &v->sums, sizeof(double) * 2 * v->G, true));
+        v->cur_h = v->cur_w = 0;
+        ws_save(v, k);
+    }
+    v->ws_active = nws - 1;  // the members hold the last set built
+    ws_activate(v, 0);
+    while ((int)v->side.size() < nws - 1) {
+        hipStream_t sst = nullptr; hipEvent_t e = nullptr;
+        S2V_CHECK_HIP(hipStreamCreateWithFlags(&sst, hipStreamNonBlocking));
+        S2V_CHECK_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        v->side.push_back(sst); v->ev_side.push_back(e);
+    }
+    if (!v->ev_fork) S2V_CHECK_HIP(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
     return 0;
 }
 
@@ -503,15 +575,22 @@ extern "C" int s2v_vae_decode(s2v_vae* v, const void* latents, int32_t F, int32_
     for (auto b : frame_batches(F)) fz_max = std::max(fz_max, b.e - b.s);
     if (!use_tiles(v, h, w, tiling)) {
         S2V_TRY(prepare_tile_capacity(v, h, w, fz_max));
+        ws_activate(v, 0);
         return decode_window(v, (const char*)latents, F, h, w, 0, 0, h, w, (char*)out, Ftot, scaled, st);
     }
     TileGeo t = tile_geo(v);
     S2V_REQUIRE(t.ov_h > 0 && t.ov_w > 0, "s2v_vae_decode: degenerate tile overlap");
-    S2V_TRY(prepare_tile_capacity(v, std::min(t.tl_h, h), std::min(t.tl_w, w), fz_max));
     std::vector<int> is, js;
     for (int i = 0; i < h; i += t.ov_h) is.push_back(i);
     for (int j = 0; j < w; j += t.ov_w) js.push_back(j);
     const size_t nt = is.size() * js.size();
+    // tiles in flight: 49 x 480 x 720 at the real widths measured 928 / 684 / 602 / 605 / 554 / 590 ms with 1 / 2 / 3 / 4 / 6 / 9 sets of
+    // ~20 GB each (profiles/r03_vae_tiles_in_flight.txt); six when the device has the room, fewer otherwise (ws_fit)
+    int nws_cap = 6;
+    if (const char* e = getenv("S2V_VAE_TILES_IN_FLIGHT")) nws_cap = std::max(1, atoi(e));
+    int nws = (int)std::min<size_t>(nt, (size_t)nws_cap);
+    S2V_TRY(prepare_tile_capacity(v, std::min(t.tl_h, h), std::min(t.tl_w, w), fz_max, nws));
+    nws = std::min(nws, (int)v->ws.size());
     const int C = v->cfg.out_channels;
     // per-tile outputs [C][Ftot][8 th][8 tw] (re-allocated only when the tiling changes)
     bool realloc_tiles = v->tiles.size() != nt || v->tiles_F != Ftot;
@@ -530,9 +609,23 @@ extern "C" int s2v_vae_decode(s2v_vae* v, const void* latents, int32_t F, int32_
         }
         v->tiles_F = Ftot;
     }
+    // tile k runs on workspace set k mod nws: set 0 on the caller's stream, the others on side streams forked from it and joined
+    // before the blends (tiles of one set serialise on its stream: they share its buffers)
+    if (nws > 1) S2V_CHECK_HIP(hipEventRecord(v->ev_fork, st));
+    for (int q = 1; q < nws; ++q) S2V_CHECK_HIP(hipStreamWaitEvent(v->side[q - 1], v->ev_fork, 0));
+    // raster order, round-robin over the sets (largest-tile-first onto the least loaded set measured the same at 3-4 sets and 18 % worse
+    // at 6: what overlaps well is a big tile's chip-filling GEMMs with a small tile's latency-bound ones, which raster order pairs up)
     for (size_t k = 0; k < nt; ++k) {
         const int i = is[k / js.size()], j = js[k % js.size()];
-        S2V_TRY(decode_window(v, (const char*)latents, F, h, w, i, j, v->tile_h[k] / sc, v->tile_w[k] / sc, v->tiles[k], Ftot, scaled, st));
+        const int q = (int)(k % nws);
+        ws_activate(v, q);
+        S2V_TRY(decode_window(v, (const char*)latents, F, h, w, i, j, v->tile_h[k] / sc, v->tile_w[k] / sc, v->tiles[k], Ftot, scaled,
+                              q == 0 ? st : v->side[q - 1]));
+    }
+    ws_activate(v, 0);
+    for (int q = 1; q < nws; ++q) {
+        S2V_CHECK_HIP(hipEventRecord(v->ev_side[q - 1], v->side[q - 1]));
+        S2V_CHECK_HIP(hipStreamWaitEvent(st, v->ev_side[q - 1], 0));
     }
     // raster-order in-place blends, then crop + concatenate (:1437-1450)
     int32_t Fo, Ho, Wo;
