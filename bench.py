@@ -154,8 +154,8 @@ def cpu_baseline_vae(s2v, dev, cores):
 
 
 # kernel names as rocprofv3 prints them (template arguments included)
-KERNEL_OF_CLASS = {"attention": "attn_qx_persist_k<2>", "gemm_qkv": "gemm_bf16_pp64<4>", "gemm_ff1_gelu": "gemm_bf16_pp64<1>",
-                   "gemm_out": "gemm_bf16_pp64<2>", "gemm_ff2": "gemm_bf16_pp64<2>"}  # <4>: QKV with the fused q/k norm + rotary epilogue
+KERNEL_OF_CLASS = {"attention": "attn_qx_persist_k<2>", "gemm_qkv": "gemm_g4<4>", "gemm_ff1_gelu": "gemm_g4<1>",
+                   "gemm_out": "gemm_g4<2>", "gemm_ff2": "gemm_g4<2>"}  # <4>: QKV with the fused q/k norm + rotary epilogue
 
 
 def pmc_traffic_bytes(kernel_class):
