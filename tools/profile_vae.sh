@@ -25,7 +25,7 @@ for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
             if r.get("Counter_Name") != ctr: continue
             k = r["Kernel_Name"].split("(")[0][:80]
             agg[k][0] += float(r["Counter_Value"]); agg[k][1] += 1
-    with open(f"{out}/summary/{tag}_vae_{name}.csv", "w") as f:
+    with open(f"{out}/summary/{tag}_vae_{name[4:]}.csv", "w") as f:
         f.write(f"kernel,launches,mean_{ctr}_KB_raw,total_{ctr}_KB_raw\n")
         for k, (s, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:30]:
             f.write(f'"{k}",{n},{s/n:.1f},{s:.1f}\n')
