@@ -121,7 +121,7 @@ def cpu_baseline(s2v, cfg, F, H, W, T, dev):
 
 def cpu_baseline_vae(s2v, dev, cores):
     """the second half of the metric (wall-clock per video) on the host cores: ONE frame batch (2 latent frames -> 8 frames) of a
-    12 x 16 latent window (96 x 128 pixels; torch's CPU conv3d runs at ~65 GFLOP/s on this box, a whole 30 x 45 tile takes two minutes)
+    6 x 8 latent window (48 x 64 pixels; torch's CPU conv3d runs at 10-65 GFLOP/s on these boxes, a whole 30 x 45 tile takes minutes)
     of the real-width decoder through oracle.vae_ref, extrapolated by area to a tile and then to the tiled decode of 13 x 60 x 90 latents
     (9 tiles x [one 3-frame + five 2-frame batches] = 58.5 tile-batches; autoencoder_kl_cogvideox.py:1237-1245, 1400-1406); the same
     window through s2v_vae_decode is the check"""
@@ -133,7 +133,7 @@ def cpu_baseline_vae(s2v, dev, cores):
                 sample_height=vcfg.sample_height, sample_width=vcfg.sample_width, scaling_factor=vcfg.scaling_factor)
     dt = torch.bfloat16
     sd = {k: v.to(dt).float() for k, v in s2v.weights.synthetic_vae_state_dict(vcfg, seed=7).items()}
-    wh, ww = 12, 16
+    wh, ww = 6, 8
     lat = torch.randn(1, 2, 16, wh, ww, generator=torch.Generator().manual_seed(23)).to(dt).float()
     with torch.no_grad():
         t0 = time.time()

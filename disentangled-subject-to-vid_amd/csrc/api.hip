@@ -906,6 +906,13 @@ extern "C" int s2v_op_linear_fp8(const void* A, const void* W, const void* bias,
     return launch_gemm_fp8(g, epilogue, st);
 }
 
+extern "C" int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias, void* out, int32_t B, int32_t temb_dim,
+                               int64_t rows, int32_t dtype, int32_t impl, s2v_stream stream) {
+    S2V_REQUIRE(emb && W && out, "s2v_op_mod_gemv: null argument");
+    S2V_REQUIRE(dtype == S2V_DTYPE_BF16 || dtype == S2V_DTYPE_F32, "s2v_op_mod_gemv: dtype must be bf16 or f32");
+    return launch_mod_gemv(emb, B, temb_dim, W, bias, rows, out, dtype, (hipStream_t)stream, impl == 1);
+}
+
 extern "C" int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok,
                                 int32_t dtype, int32_t impl, s2v_stream stream) {
     S2V_REQUIRE(qkv && out, "s2v_op_attention: null argument");

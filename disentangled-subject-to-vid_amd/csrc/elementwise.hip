@@ -402,11 +402,80 @@ __global__ __launch_bounds__(256) void gemv_rows_k(const T* in, int B, int K, co
         }
     }
 }
+// The same sums in the same order (bit-identical), shaped for the weight stream: K = KC * 64 * (16-byte vector) exactly, so a lane
+// owns KC fixed chunks of every row; it applies f to its slice of the B input vectors ONCE (the one-wave-per-row kernel re-evaluated
+// silu for every row: 16 exp per 16 bytes of weights, which held the step's modulation GEMV at 1.1 TB/s) and then streams GEMV_R rows
+// with all their loads in flight.
+constexpr int GEMV_R = 8;
+template <typename T, bool PRE_SILU, int KC, int BN>
+__global__ __launch_bounds__(256) void gemv_rows_reg_k(const T* in, const T* W, const T* bias, int64_t rows, T* out) {
+    constexpr int VN = Vec16<T>::N, K = KC * 64 * VN;
+    const int lane = threadIdx.x & 63;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * GEMV_R;
+    if (row0 >= rows) return;
+    float x[BN][KC][VN];
+#pragma unroll
+    for (int b = 0; b < BN; ++b)
+#pragma unroll
+        for (int c = 0; c < KC; ++c) {
+            Vec16<T>::ld(in + (size_t)b * K + (c * 64 + lane) * VN, x[b][c]);
+            if (PRE_SILU)
+#pragma unroll
+                for (int e = 0; e < VN; ++e) x[b][c][e] = ET<T>::rnd(silu_f(x[b][c][e]));
+        }
+    const int nr = (int)min((int64_t)GEMV_R, rows - row0);
+    float wv[GEMV_R][KC][VN];
+#pragma unroll
+    for (int r = 0; r < GEMV_R; ++r) {
+        const T* w = W + (row0 + min(r, nr - 1)) * K;
+#pragma unroll
+        for (int c = 0; c < KC; ++c) Vec16<T>::ld(w + (c * 64 + lane) * VN, wv[r][c]);
+    }
+#pragma unroll
+    for (int r = 0; r < GEMV_R; ++r) {
+        float acc[BN];
+#pragma unroll
+        for (int b = 0; b < BN; ++b) {
+            acc[b] = 0.f;
+#pragma unroll
+            for (int c = 0; c < KC; ++c)
+#pragma unroll
+                for (int e = 0; e < VN; ++e) acc[b] = fmaf(x[b][c][e], wv[r][c][e], acc[b]);
+            acc[b] = wave_sum(acc[b]);
+        }
+        if (lane == 0 && r < nr) {
+            const float bv = bias ? ET<T>::ld(bias + row0 + r) : 0.f;
+#pragma unroll
+            for (int b = 0; b < BN; ++b) ET<T>::st(out + (size_t)b * rows + row0 + r, acc[b] + bv);
+        }
+    }
+}
+template <typename T, bool PRE_SILU, int KC>
+static int gemv_rows_reg(const void* in, int B, const void* W, const void* bias, int64_t rows, void* out, hipStream_t st) {
+    dim3 grid((unsigned)((rows + 4 * GEMV_R - 1) / (4 * GEMV_R)));
+#define S2V_GEMV_B(BN)                                                                                                     \
+    case BN:                                                                                                               \
+        hipLaunchKernelGGL((gemv_rows_reg_k<T, PRE_SILU, KC, BN>), grid, dim3(256), 0, st, (const T*)in, (const T*)W,      \
+                           (const T*)bias, rows, (T*)out);                                                                 \
+        break;
+    switch (B) {
+        S2V_GEMV_B(1) S2V_GEMV_B(2) S2V_GEMV_B(3) S2V_GEMV_B(4)
+        default: return s2v_fail(__FILE__, __LINE__, "gemv_rows: batch must be <= 4", -1);
+    }
+#undef S2V_GEMV_B
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <typename T>
 static int gemv_rows(const void* in, int B, int K, const void* W, const void* bias, int64_t rows, void* out,
-                     bool pre_silu, hipStream_t st) {
+                     bool pre_silu, hipStream_t st, bool rowwise = false) {
     S2V_REQUIRE(B <= 4, "gemv_rows: batch must be <= 4");
     S2V_REQUIRE(K % Vec16<T>::N == 0, "gemv_rows: K must be a multiple of the 16-byte vector width");
+    if (pre_silu && rows >= 4096 && !rowwise) {  // the modulation stack (K = time_embed_dim): one or two chunks per lane
+        if (K == 64 * Vec16<T>::N) return gemv_rows_reg<T, true, 1>(in, B, W, bias, rows, out, st);
+        if (K == 128 * Vec16<T>::N) return gemv_rows_reg<T, true, 2>(in, B, W, bias, rows, out, st);
+    }
     dim3 grid((unsigned)((rows + 3) / 4));
     if (pre_silu)
         hipLaunchKernelGGL((gemv_rows_k<T, true>), grid, dim3(256), 0, st, (const T*)in, B, K, (const T*)W,
@@ -441,9 +510,9 @@ int launch_time_embed(const float* t_dev, int B, int D, const void* w1, const vo
 }
 
 int launch_mod_gemv(const void* emb, int B, int temb_dim, const void* W, const void* bias, int64_t rows_total,
-                    void* out, int dtype, hipStream_t st) {
-    return dtype == S2V_BF16 ? gemv_rows<bf16_t>(emb, B, temb_dim, W, bias, rows_total, out, true, st)
-                             : gemv_rows<float>(emb, B, temb_dim, W, bias, rows_total, out, true, st);
+                    void* out, int dtype, hipStream_t st, bool rowwise) {
+    return dtype == S2V_BF16 ? gemv_rows<bf16_t>(emb, B, temb_dim, W, bias, rows_total, out, true, st, rowwise)
+                             : gemv_rows<float>(emb, B, temb_dim, W, bias, rows_total, out, true, st, rowwise);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -124,7 +124,7 @@ int launch_time_embed(const float* t_dev, int B, int D, const void* w1, const vo
                       int temb_dim, void* tmp /*[B,temb]*/, void* emb_out /*[B,temb]*/, int dtype, hipStream_t st);
 // out[j][b][:] = W_j . silu(emb[b]) + bias_j for a batch of stacked linears: W [rows_total, temb], bias [rows_total]
 int launch_mod_gemv(const void* emb, int B, int temb_dim, const void* W, const void* bias, int64_t rows_total,
-                    void* out /*[B][rows_total]*/, int dtype, hipStream_t st);
+                    void* out /*[B][rows_total]*/, int dtype, hipStream_t st, bool rowwise = false);
 
 // latents [Bn, F, C, H, W] -> patches [Bn*F*(H/2)*(W/2), C*4] with feature order (c, py, px);
 // lat_bstride = elements between samples (0 => every sample reads the same latent: the CFG pair)

@@ -278,6 +278,11 @@ S2V_API int s2v_op_linear(const void* A, const void* W, const void* bias, void* 
  * M, N multiples of 256, K a multiple of 128; epilogue 0 = bias, 1 = bias + GELU(tanh). */
 S2V_API int s2v_op_linear_fp8(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
                               int32_t epilogue, void* scratch, int64_t scratch_bytes, s2v_stream stream);
+/* out[b][r] = silu(emb[b]) . W[r] + bias[r] for the stacked AdaLN modulation linears of a step (every
+ * CogVideoXLayerNormZero.linear and norm_out.linear on silu(temb), normalization.py / cogvideox_transformer_3d.py:122-186);
+ * emb [B, temb_dim], W [rows, temb_dim], out [B, rows], B <= 4; impl 0 = the product dispatch, 1 = one wave per row */
+S2V_API int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias, void* out, int32_t B, int32_t temb_dim,
+                            int64_t rows, int32_t dtype, int32_t impl, s2v_stream stream);
 S2V_API int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype,
                      int32_t impl, s2v_stream stream);
 

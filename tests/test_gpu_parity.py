@@ -494,3 +494,31 @@ def test_rotary_tables_without_the_pair_structure_take_the_separate_pass(s2v, dt
           return_dict=False, eval=True, **kw)[0]
     torch.cuda.synchronize()
     assert_close(y, exp, dt_name, "unpaired rotary tables")
+
+
+@pytest.mark.parametrize("B,K,rows", [(2, 512, 6 * 3072 * 4 + 5), (1, 512, 8192), (4, 1024, 4099), (2, 64, 5000)])
+def test_op_mod_gemv_register_form_equals_the_row_form_and_the_fp64_sum(s2v, B, K, rows):
+    """the step's stacked AdaLN linears on silu(temb) (normalization.py CogVideoXLayerNormZero.linear, called from
+    cogvideox_transformer_3d.py:122-186): the product dispatch (a lane keeps its slice of silu(temb) in registers and streams eight rows)
+    must give the bits of the one-wave-per-row kernel, and both the fp64 sum on the bf16-rounded silu within bf16 rounding; the ragged
+    row tail (rows not a multiple of 32) is written exactly once"""
+    L = s2v._lib
+    g = torch.Generator().manual_seed(B * 7 + K)
+    emb = torch.randn(B, K, generator=g).bfloat16()
+    W = (torch.randn(rows, K, generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(rows, generator=g).bfloat16()
+    outs = []
+    emb_d, W_d, bias_d = emb.to(DEV), W.to(DEV), bias.to(DEV)
+    for impl in (0, 1):
+        out = torch.full((B, rows + 8), 7.0, dtype=torch.bfloat16, device=DEV)
+        L.check(L.lib().s2v_op_mod_gemv(L.ptr(emb_d), L.ptr(W_d), L.ptr(bias_d), L.ptr(out), B, K, rows,
+                                        L.DTYPE_BF16, impl, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    flat = outs[0].flatten()
+    assert (flat[B * rows:] == 7.0).all(), "nothing past [B, rows] may be written"
+    got = flat[:B * rows].reshape(B, rows).double()
+    x = torch.nn.functional.silu(emb.float()).bfloat16().double()
+    ref = x @ W.double().T + bias.double()
+    assert (got - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
