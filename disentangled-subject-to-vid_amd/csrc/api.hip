@@ -5,6 +5,7 @@
 #include "kernels.h"
 #include "../../include/s2v_hip.h"
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -55,6 +56,7 @@ struct s2v_ctx {
     bool finalized = false;
     // weights
     int num_cus = 256;
+    int sk_tiles = 0; float* sk_ws = nullptr; unsigned* sk_cnt = nullptr;  // split-K workspace of the geometry (0: none)
     int* attn_queue = nullptr;               // nine counters of the persistent attention launch (zero between launches)
     hipStream_t side = nullptr;              // fork/join stream for the row-tail launches of split GEMMs
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -438,6 +440,9 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     const int64_t opk = carve((int64_t)(c->R + c->V) * 64 * 4);
     const int64_t opos = carve((int64_t)c->V * D * E);
     const int64_t oaq = carve(c->fp8 ? c->Mpad * 4 * D : 0), oaqs = carve(c->fp8 ? c->Mpad * 4 : 0);
+    // split-K partial tiles + arrival counters (linear(): only geometries whose FF2 has at most half as many 256 x 256 tiles as CUs)
+    c->sk_tiles = (c->mfma && ((c->M + 255) / 256) * ((D + 255) / 256) * 2 <= c->num_cus) ? c->num_cus : 0;
+    const int64_t osk = carve((int64_t)c->sk_tiles * 262144), oskc = carve((int64_t)c->sk_tiles * 4);
     c->ws_bytes = off;
     S2V_CHECK_HIP(hipMalloc((void**)&c->ws, c->ws_bytes));
     S2V_CHECK_HIP(hipMemset(c->ws, 0, c->ws_bytes));
@@ -447,6 +452,7 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     c->emb = w + oemb; c->noise_pred = w + onp; c->rope_cos = (float*)(w + ocos); c->rope_sin = (float*)(w + osin);
     c->pos_tab = w + opos; c->rope_pk = (float*)(w + opk); c->rope_paired = false;
     c->aq = w + oaq; c->aq_scale = (float*)(w + oaqs);
+    c->sk_ws = (float*)(w + osk); c->sk_cnt = (unsigned*)(w + oskc);
     return 0;
 }
 
@@ -496,6 +502,16 @@ extern "C" int s2v_set_pos_embed(s2v_ctx* c, const void* table_dev, s2v_stream s
     return 0;
 }
 
+// Few tiles and a long reduction (C1: the FF2 is 80 tiles of 120 K-tiles -- one K loop is 130 us however many CUs idle): split K over S
+// workgroups per tile, S the largest count that still fits one round and leaves an even number >= 16 of K-tiles per workgroup (below
+// that the fp32 partial traffic costs what the shorter loop saves: measured on the out-projection).  1 = do not split.
+static int choose_splitk(int64_t tiles, int K, int64_t ncu) {
+    if (tiles * 2 > ncu) return 1;
+    int S = (int)std::min<int64_t>(ncu / tiles, 4);  // gemm_g4 adds at most four partials
+    while (S > 1 && !(K % (128 * S) == 0 && K / (64 * S) >= 16)) --S;
+    return S;
+}
+
 static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
     GemmArgs g = g0;
     // every GEMM operand of the transformer lives in a workspace buffer with >= 256 rows of slack behind it
@@ -507,6 +523,10 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
         // last row tile is partial and dropping it saves a round, the full row tiles run on the big kernel and the row tail
         // (108 rows at C3) on the 128 x 128 kernel.
         const int64_t tn = (g.N + 255) / 256, tm = (g.M + 255) / 256, ncu = c->num_cus;
+        if (c->sk_tiles > 0 && g.splitk == 0) {
+            const int S = choose_splitk(tm * tn, g.K, ncu);
+            if (S > 1 && (int64_t)S * tm * tn <= c->sk_tiles) { g.splitk = S; g.sk_ws = c->sk_ws; g.sk_cnt = c->sk_cnt; }
+        }
         const int rem = (int)(g.M % 256);
         if (rem > 0 && tm > 1 && g.N >= 256 && (tm * tn + ncu - 1) / ncu > ((tm - 1) * tn + ncu - 1) / ncu) {
             GemmArgs gm = g, gt = g;
@@ -880,6 +900,25 @@ extern "C" int s2v_op_linear(const void* A, const void* W, const void* bias, voi
         S2V_REQUIRE(M % 128 == 0 && N % 128 == 0, "s2v_op_linear: impl 0 needs M and N padded to 128 by the caller");
         g.a_rows_padded = M;  // the 256-row ring kernel is used when M is a multiple of 256
         return launch_gemm_bf16(g, epilogue, (hipStream_t)stream);
+    }
+    if (impl == 2) {  // the engine's split-K form of a few-tile GEMM (linear()), with a workspace of its own: synchronous
+        S2V_REQUIRE(dtype == S2V_DTYPE_BF16 && M % 256 == 0 && N % 256 == 0, "s2v_op_linear: impl 2 is bf16 with M and N multiples of 256");
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        const int64_t tiles = (int64_t)(M / 256) * (N / 256);
+        const int S = choose_splitk(tiles, K, ncu);
+        S2V_REQUIRE(S > 1, "s2v_op_linear: impl 2: this shape does not split (tiles * 2 <= CUs, K / S a multiple of 128 and >= 1024)");
+        char* ws = nullptr;
+        const size_t pb = (size_t)S * tiles * 262144;
+        S2V_CHECK_HIP(hipMalloc((void**)&ws, pb + tiles * 4));
+        g.a_rows_padded = M; g.w_rows_padded = N;
+        g.splitk = S; g.sk_ws = (float*)ws; g.sk_cnt = (unsigned*)(ws + pb);
+        int rc = hipMemsetAsync(ws + pb, 0, tiles * 4, (hipStream_t)stream) == hipSuccess ? 0 : -2;
+        if (rc == 0) rc = launch_gemm_bf16(g, epilogue, (hipStream_t)stream);
+        if (rc == 0) rc = launch_gemm_bf16(g, epilogue, (hipStream_t)stream);  // twice: the counters must be back at zero
+        hipStreamSynchronize((hipStream_t)stream);
+        hipFree(ws);
+        return rc;
     }
     return launch_gemm_simple(g, epilogue, dtype, (hipStream_t)stream);
 }

@@ -48,7 +48,11 @@ __global__ __launch_bounds__(256, 1) void gemm_g4(const GemmArgs a, int tiles_m,
     // that XCD's L2)
     const int nwg = gridDim.x, bid = blockIdx.x;
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int wg_all = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    // split K: workgroups [z * tiles, (z + 1) * tiles) of the order reduce K range z of every tile
+    const int S = a.splitk > 1 ? a.splitk : 1, ntile = tiles_m * tiles_n;
+    const int z = wg_all / ntile, wg = wg_all - z * ntile;
+    const int Ks = a.K / S;
     const int GM = a.gm > 0 ? a.gm : 4;
     const int per_group = GM * tiles_n;
     const int group = wg / per_group;
@@ -82,14 +86,24 @@ __global__ __launch_bounds__(256, 1) void gemm_g4(const GemmArgs a, int tiles_m,
     u32x2 vpf;
     vpf[0] = (unsigned)(2 * (int64_t)((lane & 7) * 32 + srow) * a.lda);
     vpf[1] = (unsigned)(2 * (int64_t)((lane & 7) * 32 + srow) * a.ldw);
-    const unsigned long long ap = (unsigned long long)((const char*)a.A + 2 * (int64_t)m0 * a.lda);
-    const unsigned long long wp = (unsigned long long)((const char*)a.W + 2 * (int64_t)n0 * a.ldw);
+    const unsigned long long ap = (unsigned long long)((const char*)a.A + 2 * ((int64_t)m0 * a.lda + (int64_t)z * Ks));
+    const unsigned long long wp = (unsigned long long)((const char*)a.W + 2 * ((int64_t)n0 * a.ldw + (int64_t)z * Ks));
     u32x4 ptr;
     ptr[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ap);
     ptr[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ap >> 32));
     ptr[2] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)wp);
     ptr[3] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(wp >> 32));
-    u32x2 sin = {lds0 + wave * 1024, (unsigned)((a.K / 64 - 2 - (G4_PF > 2 ? G4_PF : 2)) / 2)};  // pairs of K-tiles in the asm loop
+    u32x2 sin = {lds0 + wave * 1024, (unsigned)((Ks / 64 - 2 - (G4_PF > 2 ? G4_PF : 2)) / 2)};  // pairs of K-tiles in the asm loop
+
+    // split K: slot (tile, z) of the fp32 partials, [wave][64 register quads][lane] x 16 B
+    const int tile = (m0 >> 8) * tiles_n + (n0 >> 8);
+    const unsigned long long ub = (unsigned long long)(a.sk_ws + ((size_t)tile * S * 4 + wave) * 16384), zb = ub + (unsigned long long)z * 262144;
+    const unsigned voff16 = lane * 16;
+    u32x4 sk;
+    sk[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)zb);
+    sk[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(zb >> 32));
+    sk[2] = (unsigned)__builtin_amdgcn_readfirstlane(S);
+    sk[3] = 0;
 
     G4_STAMP(1);
     f32x32 AC[8];  // acc[i][j] (i: 32-column block of W rows, j: 32-row block of A rows) = registers 64 i + 16 j of a[0:255]
@@ -97,10 +111,37 @@ __global__ __launch_bounds__(256, 1) void gemm_g4(const GemmArgs a, int tiles_m,
 #include "gemm_g4_body.inc"
         : "=" G4_ACC0(AC[0]), "=" G4_ACC1(AC[1]), "=" G4_ACC2(AC[2]), "=" G4_ACC3(AC[3]), "=" G4_ACC4(AC[4]), "=" G4_ACC5(AC[5]),
           "=" G4_ACC6(AC[6]), "=" G4_ACC7(AC[7]), "+" G4_PTR(ptr), "+" G4_SIN(sin)
-        : G4_VADDR(vaddr), G4_VOFF(voff), G4_VPF(vpf)
+        : G4_VADDR(vaddr), G4_VOFF(voff), G4_VPF(vpf), G4_SK(sk), G4_VSK(voff16)
         : G4_CLOBBERS);
     G4_STAMP(2);
     __builtin_amdgcn_s_barrier();  // every wave is done with the stages: the epilogue patches alias them
+
+    if (S > 1) {
+        // Hand-over of the fp32 partial tiles (gen_gemm_g4.py gen_sk_store / gen_sk_sum: layout [wave][64 register quads][lane] x 16 B,
+        // slot (tile, z)).  Every access to them is sc1 (device scope: written through, never served from an L2) -- with plain
+        // accesses the hand-over needs __threadfence(), an L2 write-back + invalidate per wave that also evicts the operands of the
+        // workgroups still in their K loops on the same XCD (measured: 145 us against 130 us unsplit at 80 tiles x K 7680).
+        // the partial of this workgroup was stored at the end of the K-loop statement
+        __syncthreads();
+        unsigned* flag = (unsigned*)smem;
+        if (tid == 0) *flag = __hip_atomic_fetch_add(a.sk_cnt + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag != (unsigned)(S - 1)) return;
+        __syncthreads();  // flag is read by everyone before the patches overwrite it
+        if (tid == 0) __hip_atomic_store(a.sk_cnt + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next launch finds zero
+        // the last workgroup to arrive adds the S partials in split order (the sum must not depend on who was last): the others' from
+        // memory, its own from its registers at its place in the order
+        {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ub), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(ub >> 32));
+            const unsigned ns = (unsigned)__builtin_amdgcn_readfirstlane(S), zs = (unsigned)__builtin_amdgcn_readfirstlane(z);
+            asm volatile(
+#include "gemm_g4_sk_sum.inc"
+                : "+" G4_ACC0(AC[0]), "+" G4_ACC1(AC[1]), "+" G4_ACC2(AC[2]), "+" G4_ACC3(AC[3]), "+" G4_ACC4(AC[4]), "+" G4_ACC5(AC[5]),
+                  "+" G4_ACC6(AC[6]), "+" G4_ACC7(AC[7])
+                : [lo] "s"(lo), [hi] "s"(hi), [voff] "v"(voff16), [ns] "s"(ns), [z] "s"(zs)
+                : G4_SK_CLOBBERS);
+        }
+    }
 
     char* patch = smem + wave * 16384;
 #pragma unroll
@@ -143,15 +184,18 @@ static int launch_g4_t(const GemmArgs& a_in, hipStream_t st) {
     const void* fn = (const void*)gemm_g4<EPI>;
     S2V_TRY(ensure_lds_attr(fn, G4_LDS_BYTES));
     void* args[] = {(void*)&a, (void*)&tiles_m, (void*)&tiles_n};
-    S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(tiles_m * tiles_n), dim3(256), args, G4_LDS_BYTES, st));
+    const int S = a.splitk > 1 ? a.splitk : 1;
+    S2V_REQUIRE(S == 1 || (a.sk_ws && a.sk_cnt), "gemm_g4: split K needs the partial workspace and the arrival counters");
+    S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(tiles_m * tiles_n * S), dim3(256), args, G4_LDS_BYTES, st));
     return 0;
 }
 
 // plain bf16 operands, whole 256-row tiles present behind A (a_rows_padded) and W, an even number of K-tiles and enough of them for the
 // prefetch distance, vector epilogue
 bool gemm_g4_ok(const GemmArgs& a, int epi) {
-    const int nT = a.K / 64;
-    return !a.conv && a.K % 128 == 0 && nT >= (G4_PF > 2 ? G4_PF : 2) + 2 && a.lda % 8 == 0 && a.ldw % 8 == 0 && epi_vec_ok(a, epi) && a.m_begin == 0 &&
+    const int S = a.splitk > 1 ? a.splitk : 1;
+    const int nT = a.K / S / 64;
+    return !a.conv && a.K % (128 * S) == 0 && nT >= (G4_PF > 2 ? G4_PF : 2) + 2 && a.lda % 8 == 0 && a.ldw % 8 == 0 && epi_vec_ok(a, epi) && a.m_begin == 0 &&
            a.a_rows_padded >= ((a.M + 255) / 256) * 256;
 }
 int launch_gemm_g4(const GemmArgs& a, int epi, hipStream_t st) {

@@ -177,7 +177,74 @@ def gen():
     emit("s_waitcnt vmcnt(0)")
     emit("s_nop 15")  # the epilogue reads the accumulators next
     emit("s_nop 15")
+    # split K: this workgroup's partial tile goes to its slot (the stores read a[...] here, inside the statement that produced them:
+    # as operands of a second statement the compiler copied all 256 accumulators out and back, with spills)
+    emit(f"s_cmp_lt_u32 s{S_SK + 2}, 2")
+    emit("s_cbranch_scc1 L_g4_end_%=")
+    for ln in gen_sk_store(f"s{S_SK}", f"s{S_SK + 1}", f"v{V_SK}"):
+        emit(ln)
+    emit("L_g4_end_%=:")
     return L
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Split K (gemm_g4.hip, GemmArgs::splitk): the hand-over of the fp32 partial tiles.  Layout of one partial: [wave][64 register quads]
+# [lane] x 16 bytes -- quad q of a wave = accumulator registers a[4q : 4q + 3], 1 KiB per wave and instruction.  Every access is sc1
+# (device scope: written through / never served from an XCD's L2), so no L2 write-back or invalidate is needed around the arrival
+# counter.  Operands: %[lo] / %[hi] = the wave's base address (SGPRs), %[voff] = lane * 16, %[ns] = number of partials (sum only).
+SK_S0, SK_V0, SK_ZSTRIDE = 50, 100, 262144  # scratch SGPR pair, first of 4 x 32 scratch VGPRs, bytes between the partials of a tile
+
+
+S_SK, V_SK = 44, 98  # main statement: s[44:47] = {partial slot address lo, hi, number of splits, -}, v98 = lane * 16
+
+
+def gen_sk_store(lo, hi, voff):
+    out = []
+    for k in range(8):
+        out.append(f"s_add_u32 s{SK_S0}, {lo}, {k * 8192 + 4096}")
+        out.append(f"s_addc_u32 s{SK_S0 + 1}, {hi}, 0")
+        for g in range(8):
+            out.append(f"global_store_dwordx4 {voff}, a[{32 * k + 4 * g}:{32 * k + 4 * g + 3}], s[{SK_S0}:{SK_S0 + 1}] offset:{g * 1024 - 4096} sc1")
+    out.append("s_waitcnt vmcnt(0)")  # the partial tile is in memory before the arrival is counted
+    return out
+
+
+def gen_sk_sum():
+    """a[...] = partial 0 + partial 1 (+ partial 2 (+ partial 3)), in that order whoever runs it; the partial of the running workgroup
+    (%[z]) is taken from its registers instead of memory (same bits, a third less to fetch at three splits)"""
+    out = []
+    for k in range(8):
+        out.append(f"s_add_u32 s{SK_S0}, %[lo], {k * 8192 + 4096}")
+        out.append(f"s_addc_u32 s{SK_S0 + 1}, %[hi], 0")
+        for zz in range(4):
+            if zz >= 2:
+                out.append(f"s_cmp_lt_u32 %[ns], {zz + 1}")
+                out.append(f"s_cbranch_scc1 L_sk_w{k}_%=")
+            if zz:
+                out.append(f"s_add_u32 s{SK_S0}, s{SK_S0}, {SK_ZSTRIDE}")
+                out.append(f"s_addc_u32 s{SK_S0 + 1}, s{SK_S0 + 1}, 0")
+            out.append(f"s_cmp_eq_u32 %[z], {zz}")
+            out.append(f"s_cbranch_scc1 L_sk_o{k}_{zz}_%=")
+            for g in range(8):
+                v = SK_V0 + 32 * zz + 4 * g
+                out.append(f"global_load_dwordx4 v[{v}:{v + 3}], %[voff], s[{SK_S0}:{SK_S0 + 1}] offset:{g * 1024 - 4096} sc1")
+            out.append(f"s_branch L_sk_n{k}_{zz}_%=")
+            out.append(f"L_sk_o{k}_{zz}_%=:")
+            for i in range(32):
+                out.append(f"v_accvgpr_read_b32 v{SK_V0 + 32 * zz + i}, a{32 * k + i}")
+            out.append(f"L_sk_n{k}_{zz}_%=:")
+        out.append(f"L_sk_w{k}_%=:")
+        out.append("s_waitcnt vmcnt(0)")
+        for zz in range(1, 4):
+            if zz >= 2:
+                out.append(f"s_cmp_lt_u32 %[ns], {zz + 1}")
+                out.append(f"s_cbranch_scc1 L_sk_d{k}_%=")
+            for i in range(32):
+                out.append(f"v_add_f32 v{SK_V0 + i}, v{SK_V0 + i}, v{SK_V0 + 32 * zz + i}")
+        out.append(f"L_sk_d{k}_%=:")
+        for i in range(32):
+            out.append(f"v_accvgpr_write_b32 a{32 * k + i}, v{SK_V0 + i}")
+    return out
 
 
 def main():
@@ -185,6 +252,10 @@ def main():
     with open(os.path.join(here, "gemm_g4_body.inc"), "w") as f:
         for ln in gen():
             f.write('"' + ln + '\\n\\t"\n')
+    for name, body in (("gemm_g4_sk_sum.inc", gen_sk_sum()),):
+        with open(os.path.join(here, name), "w") as f:
+            for ln in body:
+                f.write('"' + ln + '\\n\\t"\n')
     clob = [f"v{r}" for r in range(0, 64)] + [f"v{VPFD}", f"v{VPFD + 1}"]
     with open(os.path.join(here, "gemm_g4_regs.h"), "w") as f:
         f.write("// generated by gen_gemm_g4.py: the physical registers the K loop of gemm_g4 owns, and its LDS size\n#pragma once\n")
@@ -193,7 +264,9 @@ def main():
             f.write(f'#define G4_ACC{k} "{{a[{32 * k}:{32 * k + 31}]}}"\n')
         f.write(f'#define G4_VADDR "{{v[{VADDR}:{VADDR + 15}]}}"\n#define G4_VOFF "{{v[{VOFF}:{VOFF + 15}]}}"\n#define G4_VPF "{{v[{VPF}:{VPF + 1}]}}"\n')
         f.write(f'#define G4_PTR "{{s[{S_A}:{S_A + 3}]}}"\n#define G4_SIN "{{s[{S_M0W}:{S_M0W + 1}]}}"\n')
-        f.write("#define G4_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + ', "vcc", "scc", "m0", "memory"\n')
+        f.write(f'#define G4_SK "{{s[{S_SK}:{S_SK + 3}]}}"\n#define G4_VSK "{{v{V_SK}}}"\n')
+        f.write("#define G4_SK_CLOBBERS " + ", ".join(f'"v{r}"' for r in range(SK_V0, SK_V0 + 128)) + f', "s{SK_S0}", "s{SK_S0 + 1}", "scc", "memory"\n')
+        f.write("#define G4_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + f', "s{SK_S0}", "s{SK_S0 + 1}", "vcc", "scc", "m0", "memory"\n')
 
 
 if __name__ == "__main__":

@@ -48,6 +48,11 @@ struct GemmArgs {
     const void* qk_w[2]; const void* qk_b[2];
     const float* qk_cs;
     int qk_D; float qk_eps;
+    // gemm_g4 only, split K (few output tiles, long K: the FF2 of the short-sequence geometries): splitk > 1 workgroups share an output
+    // tile, each reduces K / splitk; sk_ws holds their fp32 partial tiles (tiles * splitk * 256 KiB), sk_cnt one arrival counter per
+    // tile (zero before the launch, zero again after it).  The last workgroup to arrive adds the partials IN SPLIT ORDER (so the sum
+    // does not depend on who was last) and runs the epilogue.
+    int splitk; float* sk_ws; unsigned* sk_cnt;
 };
 // fp8 x fp8 -> bf16 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; the per-row scales above in the epilogue): the
 // 256 x 256 ping-pong schedule of gemm_bf16_pp64 on K-tiles of 128 bytes.  Plain mode only (no conv), K % 128 == 0, N_pad % 256 == 0.

@@ -265,7 +265,9 @@ S2V_API int s2v_t5_set_position_bias(s2v_t5* t5, const void* bias_dev, int32_t B
 S2V_API int s2v_t5_encode(s2v_t5* t5, const int64_t* input_ids_dev, int32_t B, int32_t T, void* out, s2v_stream stream);
 
 /* ---- operator-level entry points (used by the parity tests and micro-benchmarks) ------------------------- */
-/* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic */
+/* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic,
+ * 2 = MFMA bf16 with K split over several workgroups per output tile, as the engine runs GEMMs with few tiles and a long
+ * reduction (M, N multiples of 256; fails if the shape does not qualify; allocates its workspace, synchronous) */
 S2V_API int s2v_op_linear(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
                   int32_t epilogue, int32_t dtype, int32_t impl, s2v_stream stream);
 /* qkv [B*Ntok (+64 rows of slack), 3*H*64] -> out [B*Ntok, H*64]; impl 0 = MFMA flash kernel (needs vt scratch

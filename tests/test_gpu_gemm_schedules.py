@@ -151,3 +151,30 @@ def test_persistent_attention_launch_is_bit_identical_to_one_workgroup_per_q_blo
     finally:
         diag.s2v_set_attn_variant(0)
         L._lib = prev
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(512, 512, 7680, 0), (256, 1024, 4096, 1), (1024, 256, 3072, 0)])
+def test_split_k_few_tile_gemm(s2v, M, N, K, epi):
+    """gemm_g4 with K split over S workgroups per tile (api.hip linear() / choose_splitk: the FF2 of the short-sequence geometries,
+    attention.py:1241-1243 at M = 2500): partial tiles in fp32, the last workgroup to arrive adds them in split order -- so the result
+    is a pure function of the inputs (repeated launches bit-identical, arrival counters back at zero) -- and differs from the
+    one-workgroup sum only by fp32 reassociation (<= 1 bf16 ulp of the largest output), both within bf16 rounding of the fp64 product"""
+    L = s2v._lib
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16().to(DEV)
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().to(DEV)
+    b = torch.randn(N, generator=g).bfloat16().to(DEV)
+    outs = []
+    for impl in (2, 2, 0):
+        C = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, epi, L.DTYPE_BF16, impl, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append(C.float().cpu())
+    assert torch.equal(outs[0], outs[1])
+    ref = A.double().cpu() @ W.double().cpu().T + b.double().cpu()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref.float().bfloat16().double(), approximate="tanh")
+    scale = ref.abs().max().item()
+    assert (outs[0] - outs[2]).abs().max().item() <= 2 ** -7 * scale
+    for o in (outs[0], outs[2]):
+        assert (o.double() - ref).abs().max().item() <= 2 ** -7 * scale
