@@ -1226,6 +1226,9 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
 #ifdef S2V_DIAG
     if (const char* e = getenv("S2V_G4_EPI_MASK")) g4_epi = (atoi(e) >> epi) & 1;  // bisecting aid: g4 for the epilogues of the mask only
 #endif
+    // One round of tiles (<= 256 CUs' worth) leaves the epilogue fully exposed, and the fused q/k-norm + rotary epilogue is the longest:
+    // eight waves run it faster than four (C1 QKV, 230 tiles: 65 us on the ping-pong kernel, 72 us on gemm_g4)
+    if (epi == EPI_BIAS_QKNORM && (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) <= 256) g4_epi = false;
     if (g_gemm_impl == 9 && g4_epi && w_tile_ok(a) && gemm_g4_ok(a, epi)) return launch_gemm_g4(a, epi, st);  // four-wave generated-asm K loop
     if ((g_gemm_impl == 7 || g_gemm_impl == 8 || g_gemm_impl == 9) && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
