@@ -45,8 +45,13 @@ READPOS = os.environ.get("Q4_READPOS", "first")  # fragment read first in its ga
 READS = os.environ.get("Q4_READS", "")
 DMAPOS = os.environ.get("Q4_DMAPOS", "")
 SPLIT = os.environ.get("Q4_SPLIT", "")
+# Row sums: "add" = four v_add_f32 per four scores on the fp32 exp2 results (product).  "dot" = v_dot2c_f32_bf16 acc, <1.0 | 1.0>, pk:
+# ONE instruction adds the two bf16 values of a packed P register (the numbers the P.V MFMA multiplies) to the row sum -- 8 softmax
+# VALU per four scores instead of 10, results correct (harness: 46 checks ok) -- but the dot2 issues slower than the two adds it
+# replaces: 7.95 ms against 7.40 at C3 on the same box (tools/q4_ablate.sh build "dot=Q4_SUM=dot" "add=Q4_SUM=add"), so it stays an option.
+SUM = os.environ.get("Q4_SUM", "add")
 ABLATE = set(filter(None, os.environ.get("Q4_ABLATE", "").split(",")))  # timing experiments only (results are wrong)
-S_KPTR, S_VPTR, S_T, S_END, S_KADV, S_VADV, S_NT, S_KSTR, S_NTOK, S_M0W, S_THR, S_RET, S_X0, S_X1, S_CNT = 36, 38, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52
+S_KPTR, S_VPTR, S_T, S_END, S_KADV, S_VADV, S_NT, S_KSTR, S_NTOK, S_M0W, S_THR, S_RET, S_X0, S_X1, S_CNT, S_ONES = 36, 38, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53
 
 
 def layout(jb):
@@ -103,7 +108,22 @@ def soft_stream(sb, kb, sset):
         dst = pk(g >> 2, kb * 2 + (e0 >> 3)) + ((e0 & 7) >> 1) + c
         return f"v_cvt_pk_bf16_f32 {vr(dst)}, {vr(tmp(g, 2 * c))}, {vr(tmp(g, 2 * c + 1))}"
 
+    def dot(g, c):
+        e0 = (g & 3) * 4
+        src = pk(g >> 2, kb * 2 + (e0 >> 3)) + ((e0 & 7) >> 1) + c
+        acc = vr(ps(sset, g >> 2, c))
+        if kb == 0 and (g & 3) == 0:  # first touch of this accumulator in the tile
+            return f"v_dot2_f32_bf16 {acc}, {vr(src)}, s{S_ONES}, 0"
+        return f"v_dot2c_f32_bf16 {acc}, s{S_ONES}, {vr(src)}"
+
     ng = 4 * JB
+    if SUM == "dot":  # per group of four scores: exp2 x 4 of this group, cvt_pk x 2 + dot2 x 2 of the group before
+        ops = [exp(0, x) for x in range(4)]
+        for g in range(1, ng):
+            ops += [exp(g, 0), exp(g, 1), cvt(g - 1, 0), dot(g - 1, 0), exp(g, 2), exp(g, 3), cvt(g - 1, 1), dot(g - 1, 1)]
+        ops += [cvt(ng - 1, 0), dot(ng - 1, 0), cvt(ng - 1, 1), dot(ng - 1, 1)]
+        assert len(ops) == 32 * JB
+        return ops
     if ORDER == "uniform":  # every gap of five = [exp, add, exp, add, cvt]: two exp2 per gap; adds / cvt belong to the group before
         ops = []
         for g in range(ng + 1):
@@ -258,7 +278,9 @@ def gen():
             return
         L.append(ln)
 
-    def soft_lo(i):  # first softmax op of gap i: five per gap, or (SPLIT = "64") six in gaps without a fragment read and four in those with one
+    def soft_lo(i):  # first softmax op of gap i: five per gap (four with the dot2 row sums), or (SPLIT = "64") six in gaps without a fragment read and four in those with one
+        if SUM == "dot":
+            return 4 * i
         if SPLIT == "64" and JB == 2:
             return 5 * i + (i & 1)
         return 5 * i
@@ -279,6 +301,7 @@ def gen():
     emit(f"s_mov_b32 s{S_T}, 0")
     emit(f"s_mov_b32 s{S_CNT}, 0")               # OUT: slow paths taken by this wave (diagnostics)
     emit(f"s_mov_b32 s{S_THR}, 0x{THR_BITS:08x}")      # 2^64
+    emit(f"s_mov_b32 s{S_ONES}, 0x3f803f80")         # bf16 (1.0, 1.0)
     emit(f"s_mov_b32 s{S_KADV}, s{S_KSTR}")
     emit(f"s_mov_b32 s{S_VADV}, 128")
     emit(f"s_sub_u32 s{S_END}, s{S_NT}, 5")      # phase A ends at nt - 5 ...
@@ -425,7 +448,7 @@ def main():
                 for ln in gen():
                     g.write('"' + ln + '\\n\\t"\n')
             clob = [f"v{r}" for r in list(range(0, VIN)) + list(range(VS, VS + 12))] + [f"a{r}" for r in range(KF, VF + 32)]
-            clob += [f"s{r}" for r in (S_T, S_END, S_KADV, S_VADV, S_THR, S_RET, S_X0, S_X1)]
+            clob += [f"s{r}" for r in (S_T, S_END, S_KADV, S_VADV, S_THR, S_RET, S_X0, S_X1, S_ONES)]
             for nm, cls, base, n in [("VIN", "v", VIN, 8), ("LRUN", "v", LRUN, 2), ("QF", "a", QF, 16 * jb), ("PTR", "s", S_KPTR, 4),
                                      ("SIN", "s", S_NT, 4)] + [(f"OT{j}", "a", OT + 32 * j, 32) for j in range(jb)]:
                 f.write(f'#define {name}_{nm} "{{{cls}[{base}:{base + n - 1}]}}"\n')
