@@ -502,16 +502,6 @@ extern "C" int s2v_set_pos_embed(s2v_ctx* c, const void* table_dev, s2v_stream s
     return 0;
 }
 
-// Few tiles and a long reduction (C1: the FF2 is 80 tiles of 120 K-tiles -- one K loop is 130 us however many CUs idle): split K over S
-// workgroups per tile, S the largest count that still fits one round and leaves an even number >= 16 of K-tiles per workgroup (below
-// that the fp32 partial traffic costs what the shorter loop saves: measured on the out-projection).  1 = do not split.
-static int choose_splitk(int64_t tiles, int K, int64_t ncu) {
-    if (tiles * 2 > ncu) return 1;
-    int S = (int)std::min<int64_t>(ncu / tiles, 4);  // gemm_g4 adds at most four partials
-    while (S > 1 && !(K % (128 * S) == 0 && K / (64 * S) >= 16)) --S;
-    return S;
-}
-
 static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
     GemmArgs g = g0;
     // every GEMM operand of the transformer lives in a workspace buffer with >= 256 rows of slack behind it
@@ -524,7 +514,7 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
         // (108 rows at C3) on the 128 x 128 kernel.
         const int64_t tn = (g.N + 255) / 256, tm = (g.M + 255) / 256, ncu = c->num_cus;
         if (c->sk_tiles > 0 && g.splitk == 0) {
-            const int S = choose_splitk(tm * tn, g.K, ncu);
+            const int S = gemm_choose_splitk(tm * tn, g.K, ncu);
             if (S > 1 && (int64_t)S * tm * tn <= c->sk_tiles) { g.splitk = S; g.sk_ws = c->sk_ws; g.sk_cnt = c->sk_cnt; }
         }
         const int rem = (int)(g.M % 256);
@@ -906,7 +896,7 @@ extern "C" int s2v_op_linear(const void* A, const void* W, const void* bias, voi
         int dev = 0, ncu = 256;
         if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
         const int64_t tiles = (int64_t)(M / 256) * (N / 256);
-        const int S = choose_splitk(tiles, K, ncu);
+        const int S = gemm_choose_splitk(tiles, K, ncu);
         S2V_REQUIRE(S > 1, "s2v_op_linear: impl 2: this shape does not split (tiles * 2 <= CUs, K / S a multiple of 128 and >= 1024)");
         char* ws = nullptr;
         const size_t pb = (size_t)S * tiles * 262144;

@@ -50,6 +50,34 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// 16-byte vector of T
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void ld(const float* p, float* v) {
+        f32x4 t = *(const f32x4*)p;
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void st(float* p, const float* v) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
+};
+template <> struct Vec16<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* v) {
+        u32x4 t = *(const u32x4*)p;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(t[i] << 16);
+            v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* v) {
+        u32x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+        *(u32x4*)p = t;
+    }
+};
+
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     // 0.5*x*(1+tanh(sqrt(2/pi)*(x+0.044715 x^3)))  -- torch F.gelu(approximate="tanh")
     const float k0 = 0.7978845608028654f, k1 = 0.044715f;

@@ -7,34 +7,6 @@
 #include "common.h"
 #include "kernels.h"
 
-// 16-byte vector of T
-template <typename T> struct Vec16;
-template <> struct Vec16<float> {
-    static constexpr int N = 4;
-    static __device__ __forceinline__ void ld(const float* p, float* v) {
-        f32x4 t = *(const f32x4*)p;
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
-    static __device__ __forceinline__ void st(float* p, const float* v) { *(f32x4*)p = (f32x4){v[0], v[1], v[2], v[3]}; }
-};
-template <> struct Vec16<bf16_t> {
-    static constexpr int N = 8;
-    static __device__ __forceinline__ void ld(const bf16_t* p, float* v) {
-        u32x4 t = *(const u32x4*)p;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[2 * i] = __uint_as_float(t[i] << 16);
-            v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
-        }
-    }
-    static __device__ __forceinline__ void st(bf16_t* p, const float* v) {
-        u32x4 t;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) t[i] = pack2bf(v[2 * i], v[2 * i + 1]);
-        *(u32x4*)p = t;
-    }
-};
-
 // ---------------------------------------------------------------------------------------------------
 // Row LayerNorm helpers: one wave per row, row cached in registers (D <= 4096, D % (16/sizeof(T)) == 0)
 // NR = rounds of 64 lanes x 16 bytes that cover the row (compile time: 6 for D = 3072 in bf16).  Every load is UNCONDITIONAL on a

@@ -198,6 +198,12 @@ bool gemm_g4_ok(const GemmArgs& a, int epi) {
     return !a.conv && a.K % (128 * S) == 0 && nT >= (G4_PF > 2 ? G4_PF : 2) + 2 && a.lda % 8 == 0 && a.ldw % 8 == 0 && epi_vec_ok(a, epi) && a.m_begin == 0 &&
            a.a_rows_padded >= ((a.M + 255) / 256) * 256;
 }
+int gemm_choose_splitk(int64_t tiles, int K, int64_t ncu) {
+    if (tiles * 2 > ncu) return 1;
+    int S = (int)(ncu / tiles < 4 ? ncu / tiles : 4);  // the sum adds at most four partials
+    while (S > 1 && !(K % (128 * S) == 0 && K / (64 * S) >= 16)) --S;
+    return S;
+}
 int launch_gemm_g4(const GemmArgs& a, int epi, hipStream_t st) {
     switch (epi) {
         case EPI_BIAS: return launch_g4_t<EPI_BIAS>(a, st);

@@ -71,6 +71,11 @@ int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st);  
 // gemm_g4.hip: 256 x 256 tiles, four waves, generated-asm K loop (plain bf16 operands; gemm_g4_ok says whether a call qualifies)
 bool gemm_g4_ok(const GemmArgs& a, int epi);
 int launch_gemm_g4(const GemmArgs& a, int epi, hipStream_t st);
+// Few tiles and a long reduction (C1: the FF2 is 80 tiles of 120 K-tiles -- one K loop is 130 us however many CUs idle; the T5 encoder
+// at M = 452: 32-96 tiles): split K over S workgroups per tile (GemmArgs::splitk), S the largest count <= 4 that still fits one round
+// of `ncu` CUs and leaves an even number >= 16 of K-tiles per workgroup (below that the fp32 partial traffic costs what the shorter
+// loop saves: measured on the C1 out-projection).  1 = do not split.  Workspace: S * tiles * 256 KiB of partials + tiles counters (zero).
+int gemm_choose_splitk(int64_t tiles, int K, int64_t ncu);
 // generic strided fp32 GEMM used at load time (LoRA merge): C[m,n] += alpha * sum_k A[m*sam+k*sak]*B[n*sbn+k*sbk]
 int launch_gemm_strided_f32(const float* A, int64_t sam, int64_t sak, const float* B, int64_t sbn, int64_t sbk,
                             float* C, int64_t ldc, int M, int N, int K, float alpha, hipStream_t st);

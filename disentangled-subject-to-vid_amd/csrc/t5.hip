@@ -34,14 +34,39 @@ __global__ __launch_bounds__(256) void t5_rms_norm_k(const T* x, const T* w, int
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const T* xr = x + (size_t)m * d;
+    T* o = out + (size_t)m * d;
+    constexpr int VN = Vec16<T>::N;
     float ss = 0.f;
+    if (d % (64 * VN) == 0 && d <= 64 * VN * 8) {  // the row in registers, 16-byte accesses (d_model 4096 in bf16: 8 rounds)
+        float v[8][VN];
+        const int nr = d / (64 * VN);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nr) Vec16<T>::ld(xr + (i * 64 + lane) * VN, v[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nr)
+#pragma unroll
+                for (int e = 0; e < VN; ++e) ss += v[i][e] * v[i][e];
+        ss = wave_sum(ss);
+        const float r = 1.0f / sqrtf(ss / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            if (i < nr) {
+                float wv[VN], y[VN];
+                Vec16<T>::ld(w + (i * 64 + lane) * VN, wv);
+#pragma unroll
+                for (int e = 0; e < VN; ++e) y[e] = ET<T>::rnd(wv[e] * ET<T>::rnd(v[i][e] * r));
+                Vec16<T>::st(o + (i * 64 + lane) * VN, y);
+            }
+        return;
+    }
     for (int c = lane; c < d; c += 64) {
         const float v = ET<T>::ld(xr + c);
         ss += v * v;
     }
     ss = wave_sum(ss);
     const float r = 1.0f / sqrtf(ss / (float)d + eps);
-    T* o = out + (size_t)m * d;
     for (int c = lane; c < d; c += 64) ET<T>::st(o + c, ET<T>::rnd(ET<T>::ld(w + c) * ET<T>::rnd(ET<T>::ld(xr + c) * r)));
 }
 
@@ -130,6 +155,112 @@ __global__ __launch_bounds__(256) void t5_attn_k(const T* qkv, const T* bias, in
     if (active) ET<T>::st(out + (size_t)(b * Tn + q) * D + h * 64 + lane, o);
 }
 
+// The same arithmetic (same rounding points, same summation order: bit-identical to t5_attn_k) with the head's K and V staged ONCE per
+// workgroup in LDS as fp32 (K rows padded to 65 words: lane = key reads are conflict-free) and four queries per wave sharing every K
+// read: t5_attn_k fetched each key row from global memory three times per query with 2-byte strided loads -- 451 us per layer at
+// T5-XXL, 2 x 226 tokens, 54 % of the encode.  Tn <= T5_ATTN_MAX_T (LDS: Tn * 129 words + the queries).
+constexpr int T5_ATTN_MAX_T = 280, T5_ATTN_WAVES = 16, T5_ATTN_QB = 4 * T5_ATTN_WAVES, T5_ATTN_NC = (T5_ATTN_MAX_T + 63) / 64;
+template <typename T>
+__global__ __launch_bounds__(64 * T5_ATTN_WAVES) void t5_attn_lds_k(const T* qkv, const T* bias, int B, int H, int Tn, T* out) {
+    extern __shared__ float t5s[];
+    float* Ks = t5s;                         // [Tn][65]
+    float* Vs = Ks + (size_t)Tn * 65;        // [Tn][64]
+    float* Qs = Vs + (size_t)Tn * 64;        // [waves][4 queries][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int D = H * 64, ld = 3 * D;
+    const T* base = qkv + (size_t)b * Tn * ld;
+    {   // staging: 16-byte chunks, every load of a thread in flight before the first LDS store (a load-store loop took one memory
+        // round trip per element pair: 110 us per workgroup)
+        constexpr int VN = Vec16<T>::N, CPR = 64 / VN;                         // chunks per 64-element row
+        constexpr int NTH = 64 * T5_ATTN_WAVES, NCH = (T5_ATTN_MAX_T * CPR + NTH - 1) / NTH;  // chunks per thread and operand
+        const int total = Tn * CPR;
+        float kv_[2][NCH][VN];
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = min((int)threadIdx.x + i * NTH, total - 1), kv = c / CPR, d = (c % CPR) * VN;
+            Vec16<T>::ld(base + (size_t)kv * ld + D + h * 64 + d, kv_[0][i]);
+            Vec16<T>::ld(base + (size_t)kv * ld + 2 * D + h * 64 + d, kv_[1][i]);
+        }
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int c = threadIdx.x + i * NTH, kv = c / CPR, d = (c % CPR) * VN;
+            if (c < total)
+#pragma unroll
+                for (int e = 0; e < VN; ++e) {
+                    Ks[kv * 65 + d + e] = kv_[0][i][e];
+                    Vs[kv * 64 + d + e] = kv_[1][i][e];
+                }
+        }
+    }
+    __syncthreads();
+    float* qs = Qs + wave * 256;
+    // sixteen waves (four per SIMD: the loops below are LDS-latency bound with one), four queries each
+    const int q0 = blockIdx.x * T5_ATTN_QB + wave * 4;
+    if (q0 < Tn) {
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) qs[qi * 64 + lane] = ET<T>::ld(base + (size_t)min(q0 + qi, Tn - 1) * ld + h * 64 + lane);
+        // (a wave reads back only what it wrote: no barrier)
+        float acc[4][T5_ATTN_NC];
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+            for (int c = 0; c < T5_ATTN_NC; ++c) acc[qi][c] = 0.f;
+        int krow[T5_ATTN_NC];
+#pragma unroll
+        for (int c = 0; c < T5_ATTN_NC; ++c) krow[c] = min(c * 64 + lane, Tn - 1) * 65;
+#pragma unroll 4
+        for (int d = 0; d < 64; ++d) {
+            float kd[T5_ATTN_NC];
+#pragma unroll
+            for (int c = 0; c < T5_ATTN_NC; ++c) kd[c] = Ks[krow[c] + d];
+#pragma unroll
+            for (int qi = 0; qi < 4; ++qi) {
+                const float qv = qs[qi * 64 + d];
+#pragma unroll
+                for (int c = 0; c < T5_ATTN_NC; ++c) acc[qi][c] = fmaf(qv, kd[c], acc[qi][c]);
+            }
+        }
+        float pw[4][T5_ATTN_NC];  // normalised, rounded weights of the four queries
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi) {
+            const int q = min(q0 + qi, Tn - 1);
+            const T* brow = bias + ((size_t)h * Tn + q) * Tn;
+            float sc[T5_ATTN_NC], m = -INFINITY;
+#pragma unroll
+            for (int c = 0; c < T5_ATTN_NC; ++c) {
+                const int kv = c * 64 + lane;
+                sc[c] = kv < Tn ? ET<T>::rnd(ET<T>::rnd(acc[qi][c]) + ET<T>::ld(brow + min(kv, Tn - 1))) : -INFINITY;
+                m = fmaxf(m, sc[c]);
+            }
+            m = wave_max(m);
+            float l = 0.f;
+#pragma unroll
+            for (int c = 0; c < T5_ATTN_NC; ++c)
+                if (c * 64 < Tn) l += wave_sum(c * 64 + lane < Tn ? expf(sc[c] - m) : 0.f);
+            const float inv = 1.0f / l;
+#pragma unroll
+            for (int c = 0; c < T5_ATTN_NC; ++c) pw[qi][c] = c * 64 + lane < Tn ? ET<T>::rnd(expf(sc[c] - m) * inv) : 0.f;
+        }
+        // o[qi][lane = d] = sum over keys in order: one V read feeds the four queries, the weight of key j comes by v_readlane
+        // (__shfl is a ds_bpermute per key and query: 110 us of LDS traffic per workgroup)
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < T5_ATTN_NC; ++c) {
+            if (c * 64 >= Tn) break;
+            const int nv = min(64, Tn - c * 64);
+            for (int j = 0; j < nv; ++j) {
+                const float v = Vs[(c * 64 + j) * 64 + lane];
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi) o[qi] = fmaf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pw[qi][c]), j)), v, o[qi]);
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi)
+            if (q0 + qi < Tn) ET<T>::st(out + (size_t)(b * Tn + q0 + qi) * D + h * 64 + lane, o[qi]);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 struct T5Layer { char *ln0, *wqkv, *wo, *ln1, *wi, *wff; };
 struct T5Slot { char* dst; int64_t rows, cols; bool loaded; };
@@ -146,6 +277,8 @@ struct s2v_t5 {
     int B = 0, T = 0;
     int64_t Mpad = 0;
     char *X = nullptr, *Xn = nullptr, *QKV = nullptr, *AO = nullptr, *FF = nullptr, *G = nullptr, *bias = nullptr;
+    char* sk = nullptr;  // split-K partial tiles (num_cus x 256 KiB) followed by num_cus arrival counters
+    int num_cus = 256;
     std::vector<void*> ws_allocs;
     // every weight lives in ONE arena (s2v_t5_weight_arena: the replica broadcast); sized by a first pass of the plan
     char* arena = nullptr;
@@ -313,6 +446,14 @@ static int t5_workspace(s2v_t5* t, int B, int T) {
     S2V_TRY(t5_alloc(t, &t->FF, t->Mpad * 2 * F * E, true));
     S2V_TRY(t5_alloc(t, &t->G, t->Mpad * F * E, true));
     S2V_TRY(t5_alloc(t, &t->bias, (int64_t)t->cfg.num_heads * T * T * E, true));
+    t->sk = nullptr;
+    if (t->mfma) {  // a prompt is a few hundred rows: every GEMM is 32-160 tiles, most of them split K (gemm_choose_splitk)
+        int dev = 0, ncu = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && ncu > 0)
+            t->num_cus = ncu;
+        S2V_TRY(t5_alloc(t, &t->sk, (int64_t)t->num_cus * (262144 + 4), true));
+        S2V_CHECK_HIP(hipMemset(t->sk + (int64_t)t->num_cus * 262144, 0, (size_t)t->num_cus * 4));
+    }
     t->B = B; t->T = T;
     return 0;
 }
@@ -335,7 +476,14 @@ static int t5_linear(s2v_t5* t, const void* A, int lda, const void* W, void* C, 
     g.R = R; g.ldr = N;
     g.a_rows_padded = (int)rup_(M, 256);
     g.w_rows_padded = (int)rup_(N, 256);
-    if (t->mfma && K % 64 == 0) return launch_gemm_bf16(g, epi, st);
+    if (t->mfma && K % 64 == 0) {
+        const int64_t tiles = (int64_t)((M + 255) / 256) * ((N + 255) / 256);
+        const int S = t->sk ? gemm_choose_splitk(tiles, K, t->num_cus) : 1;
+        if (S > 1 && S * tiles <= t->num_cus) {
+            g.splitk = S; g.sk_ws = (float*)t->sk; g.sk_cnt = (unsigned*)(t->sk + (int64_t)t->num_cus * 262144);
+        }
+        return launch_gemm_bf16(g, epi, st);
+    }
     return launch_gemm_simple(g, epi, t->dtype, st);
 }
 
@@ -369,7 +517,14 @@ extern "C" int s2v_t5_encode(s2v_t5* t, const int64_t* input_ids_dev, int32_t B,
         }
         S2V_CHECK_HIP(hipGetLastError());
         S2V_TRY(t5_linear(t, t->Xn, d, L.wqkv, t->QKV, M, 3 * in, d, EPI_BIAS, nullptr, st));
-        if (bf) hipLaunchKernelGGL(t5_attn_k<bf16_t>, attn_grid, dim3(256), 0, st, (const bf16_t*)t->QKV, (const bf16_t*)t->bias, B, H, T, (bf16_t*)t->AO);
+        if (T <= T5_ATTN_MAX_T) {
+            const dim3 g((T + T5_ATTN_QB - 1) / T5_ATTN_QB, H, B);
+            const size_t lds = ((size_t)T * 129 + 256 * T5_ATTN_WAVES) * sizeof(float);
+            const void* fn = bf ? (const void*)t5_attn_lds_k<bf16_t> : (const void*)t5_attn_lds_k<float>;
+            S2V_TRY(ensure_lds_attr(fn, (int)lds));
+            if (bf) hipLaunchKernelGGL(t5_attn_lds_k<bf16_t>, g, dim3(64 * T5_ATTN_WAVES), lds, st, (const bf16_t*)t->QKV, (const bf16_t*)t->bias, B, H, T, (bf16_t*)t->AO);
+            else hipLaunchKernelGGL(t5_attn_lds_k<float>, g, dim3(64 * T5_ATTN_WAVES), lds, st, (const float*)t->QKV, (const float*)t->bias, B, H, T, (float*)t->AO);
+        } else if (bf) hipLaunchKernelGGL(t5_attn_k<bf16_t>, attn_grid, dim3(256), 0, st, (const bf16_t*)t->QKV, (const bf16_t*)t->bias, B, H, T, (bf16_t*)t->AO);
         else hipLaunchKernelGGL(t5_attn_k<float>, attn_grid, dim3(256), 0, st, (const float*)t->QKV, (const float*)t->bias, B, H, T, (float*)t->AO);
         S2V_CHECK_HIP(hipGetLastError());
         S2V_TRY(t5_linear(t, t->AO, in, L.wo, t->X, M, d, in, EPI_BIAS_ADD, t->X, st));  // x = x + o(...)

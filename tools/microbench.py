@@ -103,3 +103,17 @@ def bench_vae():
 
 if "vae" in sys.argv[1:]:
     bench_vae()
+
+if "t5" in sys.argv[1:]:
+    # T5-v1.1-XXL encode of the CFG pair's prompts (2 x 226 tokens): per-kernel times come from `rocprofv3 --kernel-trace --stats`
+    tcfg = s2v.T5Config()
+    t5 = s2v.HipT5EncoderModel(tcfg, torch.bfloat16, DEV)
+    t5.load_state_dict(s2v.weights.synthetic_t5_state_dict(tcfg, seed=10, device=DEV, dtype=torch.bfloat16, gain=0.5))
+    ids = torch.randint(1, tcfg.vocab_size, (2, 226), device=DEV)
+    t5(ids)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        t0 = time.perf_counter()
+        emb = t5(ids)[0]
+        torch.cuda.synchronize()
+        print(f"t5 xxl encode 2 x 226 tokens: {(time.perf_counter() - t0) * 1e3:.2f} ms", flush=True)
