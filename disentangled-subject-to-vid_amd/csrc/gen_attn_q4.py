@@ -49,6 +49,9 @@ SPLIT = os.environ.get("Q4_SPLIT", "")
 # ONE instruction adds the two bf16 values of a packed P register (the numbers the P.V MFMA multiplies) to the row sum -- 8 softmax
 # VALU per four scores instead of 10, results correct (harness: 46 checks ok) -- but the dot2 issues slower than the two adds it
 # replaces: 7.95 ms against 7.40 at C3 on the same box (tools/q4_ablate.sh build "dot=Q4_SUM=dot" "add=Q4_SUM=add"), so it stays an option.
+# "pk" = v_pk_add_f32 on the accumulator pair (two adds per instruction, fp32 as now): 8.15 ms against 7.43.  Both packed forms cost more
+# issue time than the two plain VALU they replace (round 2 measured 21.5 cycles per v_pk_*_f32 beside an MFMA stream): on this part the
+# softmax stream cannot be shortened by wider VALU instructions.
 SUM = os.environ.get("Q4_SUM", "add")
 ABLATE = set(filter(None, os.environ.get("Q4_ABLATE", "").split(",")))  # timing experiments only (results are wrong)
 S_KPTR, S_VPTR, S_T, S_END, S_KADV, S_VADV, S_NT, S_KSTR, S_NTOK, S_M0W, S_THR, S_RET, S_X0, S_X1, S_CNT, S_ONES = 36, 38, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53
@@ -116,7 +119,20 @@ def soft_stream(sb, kb, sset):
             return f"v_dot2_f32_bf16 {acc}, {vr(src)}, s{S_ONES}, 0"
         return f"v_dot2c_f32_bf16 {acc}, s{S_ONES}, {vr(src)}"
 
+    def pkadd(g, h):  # two row-sum adds in one v_pk_add_f32: accumulators ps[.][j][0:1] += exp2 results tmp[g][2h : 2h + 1]
+        acc = vr(ps(sset, g >> 2, 0), 2)
+        if kb == 0 and (g & 3) == 0 and h == 0:
+            return f"v_pk_add_f32 {acc}, {vr(tmp(g, 0), 2)}, 0"
+        return f"v_pk_add_f32 {acc}, {acc}, {vr(tmp(g, 2 * h), 2)}"
+
     ng = 4 * JB
+    if SUM == "pk":
+        ops = [exp(0, x) for x in range(4)]
+        for g in range(1, ng):
+            ops += [exp(g, 0), exp(g, 1), pkadd(g - 1, 0), cvt(g - 1, 0), exp(g, 2), exp(g, 3), pkadd(g - 1, 1), cvt(g - 1, 1)]
+        ops += [pkadd(ng - 1, 0), cvt(ng - 1, 0), pkadd(ng - 1, 1), cvt(ng - 1, 1)]
+        assert len(ops) == 32 * JB
+        return ops
     if SUM == "dot":  # per group of four scores: exp2 x 4 of this group, cvt_pk x 2 + dot2 x 2 of the group before
         ops = [exp(0, x) for x in range(4)]
         for g in range(1, ng):
@@ -279,7 +295,7 @@ def gen():
         L.append(ln)
 
     def soft_lo(i):  # first softmax op of gap i: five per gap (four with the dot2 row sums), or (SPLIT = "64") six in gaps without a fragment read and four in those with one
-        if SUM == "dot":
+        if SUM in ("dot", "pk"):
             return 4 * i
         if SPLIT == "64" and JB == 2:
             return 5 * i + (i & 1)
