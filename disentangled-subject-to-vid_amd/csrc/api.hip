@@ -53,6 +53,7 @@ struct s2v_ctx {
     bool fp8 = false;            // cfg.weight_format == 1
     char* aq = nullptr;          // workspace: e4m3 activations [Mpad][4D] of the GEMM being fed
     float* aq_scale = nullptr;   // workspace: their per-token scales [Mpad]
+    unsigned char *hq = nullptr, *hs = nullptr;  // workspace (fp8): GELU(FF1) as MX e4m3 [Mpad][4D] + block scales [Mpad][4D / 32]
     bool finalized = false;
     // weights
     int num_cus = 256;
@@ -440,6 +441,8 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     const int64_t opk = carve((int64_t)(c->R + c->V) * 64 * 4);
     const int64_t opos = carve((int64_t)c->V * D * E);
     const int64_t oaq = carve(c->fp8 ? c->Mpad * 4 * D : 0), oaqs = carve(c->fp8 ? c->Mpad * 4 : 0);
+    // fp8: the FF1 epilogue leaves GELU(h) as MX e4m3 (bytes + one E8M0 scale per 32 columns), the FF2 reads it in place
+    const int64_t ohq = carve(c->fp8 ? c->Mpad * 4 * D : 0), ohs = carve(c->fp8 ? c->Mpad * 4 * D / 32 : 0);
     // split-K partial tiles + arrival counters (linear(): only geometries whose FF2 has at most half as many 256 x 256 tiles as CUs)
     c->sk_tiles = (c->mfma && ((c->M + 255) / 256) * ((D + 255) / 256) * 2 <= c->num_cus) ? c->num_cus : 0;
     const int64_t osk = carve((int64_t)c->sk_tiles * 262144), oskc = carve((int64_t)c->sk_tiles * 4);
@@ -452,6 +455,7 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     c->emb = w + oemb; c->noise_pred = w + onp; c->rope_cos = (float*)(w + ocos); c->rope_sin = (float*)(w + osin);
     c->pos_tab = w + opos; c->rope_pk = (float*)(w + opk); c->rope_paired = false;
     c->aq = w + oaq; c->aq_scale = (float*)(w + oaqs);
+    c->hq = (unsigned char*)(w + ohq); c->hs = (unsigned char*)(w + ohs);
     c->sk_ws = (float*)(w + osk); c->sk_cnt = (unsigned*)(w + oskc);
     return 0;
 }
@@ -538,8 +542,15 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
 
 // weight_format 1: quantise the activation rows (per token, dynamic) and run the fp8 GEMM against the e4m3 weight copy
 // prequant: the producer (ln_modulate_k) already left the e4m3 image and the row scales of A in c->aq / c->aq_scale
+// g0.mx_a_s set: A is already an MX image (g0.A bytes, block scales g0.mx_a_s) left by the producing GEMM's epilogue
 static int linear_fp8(s2v_ctx* c, const GemmArgs& g0, int epi, const char* wq, const float* wscale, hipStream_t st, bool prequant = false) {
     GemmArgs g = g0;
+    if (g.mx_a_s) {
+        g.lda = g.K; g.W = wq; g.ldw = g.K; g.a_scale = nullptr; g.w_scale = wscale;
+        g.a_rows_padded = (int)rup(g.M, 256);
+        g.w_rows_padded = (int)rup(g.N, 256);
+        return launch_gemm_fp8(g, epi, st);
+    }
     if (!prequant) S2V_TRY(launch_quant_rows_fp8(g.A, g.lda, g.M, g.K, c->aq, c->aq_scale, st));
     g.A = c->aq; g.lda = g.K; g.W = wq; g.ldw = g.K;
     g.a_scale = c->aq_scale; g.w_scale = wscale;
@@ -576,6 +587,8 @@ extern "C" int s2v_set_conditioning(s2v_ctx* c, const void* text_dev, const void
 
 // ---- one transformer block on the packed residual buffer X ------------------------------------------------
 #ifdef S2V_DIAG
+static int g_fp8_mx = 1;
+extern "C" __attribute__((visibility("default"))) int s2v_set_fp8_mx(int on) { g_fp8_mx = on; return 0; }
 static int g_fused_q8 = 1;
 extern "C" __attribute__((visibility("default"))) int s2v_set_fused_q8(int on) { g_fused_q8 = on; return 0; }
 static int g_fused_qk = 1;
@@ -663,12 +676,18 @@ static int run_block(s2v_ctx* c, int l, const char* mod_base /* [B][mod_stride] 
             GemmArgs f{};
             f.A = c->Xn; f.lda = D; f.W = w.w1; f.ldw = D; f.bias = w.b1; f.C = c->Hb; f.ldc = 4 * D;
             f.M = (int)c->M; f.N = 4 * D; f.K = D;
+            bool mx = c->fp8 && (4 * D) % 128 == 0;
+#ifdef S2V_DIAG
+            mx = mx && g_fp8_mx;
+#endif
+            if (mx) { f.mx_out_q = c->hq; f.mx_out_s = c->hs; }
             {
                 ProfScope ps(c, PK_FF1, st);
                 if (c->fp8) S2V_TRY(linear_fp8(c, f, EPI_BIAS_GELU, w.q_1, w.s_1, st, prequant));
                 else S2V_TRY(linear(c, f, EPI_BIAS_GELU, st));
             }
             g.A = c->Hb; g.lda = 4 * D; g.W = w.w2; g.ldw = 4 * D; g.bias = w.b2; g.K = 4 * D;
+            if (mx) { g.A = c->hq; g.mx_a_s = c->hs; }
             ProfScope ps(c, PK_FF2, st);
             if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS_GATE_RES, w.q_2, w.s_2, st));
             else S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
@@ -933,6 +952,49 @@ extern "C" int s2v_op_linear_fp8(const void* A, const void* W, const void* bias,
     g.A = aq; g.lda = K; g.W = wq; g.ldw = K; g.bias = bias; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
     g.a_rows_padded = M; g.w_rows_padded = N; g.a_scale = as; g.w_scale = ws;
     return launch_gemm_fp8(g, epilogue, st);
+}
+
+// FeedForward (attention.py:1237-1243) on the fp8 matrix cores as the fp8 engine runs it: x, W1, W2 quantised per row (e4m3, amax / 448);
+// h = GELU(x W1^T + b1) either (mx = 1) left by the FF1 epilogue as MX e4m3 -- one power-of-two scale per 32 columns -- and read in
+// place by the FF2, or (mx = 0) written in bf16 and quantised per row by a separate pass; out = h W2^T + b2, bf16.  Allocates its
+// scratch and synchronises: a test / micro-benchmark entry point.
+extern "C" int s2v_op_ff_fp8(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* out, int32_t M, int32_t D,
+                             int32_t F, int32_t mx, s2v_stream stream) {
+    S2V_REQUIRE(x && w1 && w2 && out, "s2v_op_ff_fp8: null argument");
+    S2V_REQUIRE(M % 256 == 0 && D % 256 == 0 && F % 256 == 0, "s2v_op_ff_fp8: M, D, F must be multiples of 256");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t bytes = (size_t)M * D + (size_t)F * D + (size_t)D * F + 4 * ((size_t)2 * M + F + D) + (size_t)M * F * 3 + (size_t)M * F / 32 + 4096;
+    char* p = nullptr;
+    S2V_CHECK_HIP(hipMalloc((void**)&p, bytes));
+    char* xq = p; char* w1q = xq + (size_t)M * D; char* w2q = w1q + (size_t)F * D;
+    float* xs = (float*)(w2q + (size_t)D * F); float* hs_row = xs + M; float* w1s = hs_row + M; float* w2s = w1s + F;
+    char* hb = (char*)(w2s + D);                 // bf16 h (mx = 0)
+    char* hq = hb + (size_t)M * F * 2;           // e4m3 h
+    unsigned char* hsc = (unsigned char*)hq + (size_t)M * F;  // MX block scales
+    int rc = 0;
+    auto run = [&]() -> int {
+        S2V_TRY(launch_quant_rows_fp8(x, D, M, D, xq, xs, st));
+        S2V_TRY(launch_quant_rows_fp8(w1, D, F, D, w1q, w1s, st));
+        S2V_TRY(launch_quant_rows_fp8(w2, F, D, F, w2q, w2s, st));
+        GemmArgs f{};
+        f.A = xq; f.lda = D; f.W = w1q; f.ldw = D; f.bias = b1; f.C = hb; f.ldc = F; f.M = M; f.N = F; f.K = D;
+        f.a_rows_padded = M; f.w_rows_padded = F; f.a_scale = xs; f.w_scale = w1s;
+        if (mx) { f.mx_out_q = (unsigned char*)hq; f.mx_out_s = hsc; }
+        S2V_TRY(launch_gemm_fp8(f, EPI_BIAS_GELU, st));
+        GemmArgs g{};
+        g.A = hq; g.lda = F; g.W = w2q; g.ldw = F; g.bias = b2; g.C = out; g.ldc = D; g.M = M; g.N = D; g.K = F;
+        g.a_rows_padded = M; g.w_rows_padded = D; g.w_scale = w2s;
+        if (mx) g.mx_a_s = hsc;
+        else {
+            S2V_TRY(launch_quant_rows_fp8(hb, F, M, F, hq, hs_row, st));
+            g.a_scale = hs_row;
+        }
+        return launch_gemm_fp8(g, EPI_BIAS, st);
+    };
+    rc = run();
+    hipStreamSynchronize(st);
+    hipFree(p);
+    return rc;
 }
 
 extern "C" int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias, void* out, int32_t B, int32_t temb_dim,

@@ -114,6 +114,14 @@ __device__ __forceinline__ void glds16_saddr_m0(const char* sbase, unsigned voff
                  : "memory", "m0");
 }
 
+// one dword per lane: LDS address = M0 + 4 * lane (the MX block scales of 64 rows)
+__device__ __forceinline__ void glds4_saddr_m0(const char* sbase, unsigned voff, unsigned m0val) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %0"
+                 :
+                 : "s"(sbase), "v"(voff), "s"(m0val)
+                 : "memory", "m0");
+}
+
 // the same with compile-time displacements: M0 = m0base + m0add (one SALU), global address + off (instruction immediate, 13-bit
 // signed).  m0add / off must fold to constants after inlining and unrolling ("i" constraints)
 __device__ __forceinline__ void glds16_saddr_m0_imm(const char* sbase, unsigned voff, unsigned m0base, int m0add, int off) {

@@ -542,6 +542,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
         offW[i] = (unsigned)(ES * ((int64_t)(srow + i * 32) * a.ldw + scol));
     }
     const int nT = a.K / BKE;
+    const bool mx = FP8 && a.mx_a_s != nullptr;                 // block-scaled A (GemmArgs::mx_a_s)
+    const unsigned offS = (unsigned)((w4 * 64 + lane) * (a.K >> 5));  // scale row of lane: rows w4 * 64 + lane of the tile
     const int ldst = (g * 128 + w4 * 8) * 128;  // byte offset of the wave's piece 0 inside an operand image
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base_u32(smem));  // LDS destinations as integers: no null-check SALU per piece
     auto dma_a = [&](int t) {
@@ -553,6 +555,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             glds16_saddr_m0(tb, offA[i], base + i * 4096);
+        if (mx && !g) {  // the K-tile's four block scales of the tile's 256 rows: one dword per row, 64 rows per wave of group 0
+            const char* sb = (const char*)a.mx_a_s + (size_t)m0 * (a.K >> 5) + tc * 4;
+            glds4_saddr_m0(sb, offS, lds0 + 131072 + (t & 1) * 1024 + w4 * 256);
+        }
     };
     auto dma_w = [&](int t) {
         if (ABL == 1 && t > 0) return;
@@ -580,10 +586,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
     if (g) __builtin_amdgcn_s_barrier();  // group 1 idles through I_0
 
     bf16x8 wf[2][2], af[2][4];
+    int sb_[4] = {127, 127, 127, 127};  // E8M0 scales of the lane's A blocks: byte 0 for half-step 0, byte 2 for half-step 1
     auto reads = [&](int t, int s) {
         if (ABL == 6 && t > 0) return;
         const char* tA = smem + (t & 1) * 65536;
         const char* tW = tA + 32768;
+        if (FP8 && mx && s == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                sb_[j] = (int)(*(const unsigned*)(smem + 131072 + (t & 1) * 1024 + (wm * 128 + j * 32 + fr) * 4) >> (8 * hi));
+        }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -609,7 +621,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat16(wf[0][i], wf[1][i]), cat16(af[0][j], af[1][j]), acc[i][j], 0, 0, 0, 127, 0, 127);
+                    acc[i][j] = tile_end ? __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat16(wf[0][i], wf[1][i]), cat16(af[0][j], af[1][j]), acc[i][j], 0, 0, 0, 127, 2, sb_[j])
+                                         : __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(cat16(wf[0][i], wf[1][i]), cat16(af[0][j], af[1][j]), acc[i][j], 0, 0, 0, 127, 0, sb_[j]);
         } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -1158,13 +1171,14 @@ static constexpr int g_gemm_impl = 9;  // 9: gemm_g4 where it qualifies, gemm_bf
 template <int EPI>
 static int launch_fp8_t(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
-    S2V_TRY(ensure_lds_attr((const void*)gemm_bf16_pp64<EPI, 0, true>, 131072));
-    hipLaunchKernelGGL((gemm_bf16_pp64<EPI, 0, true>), dim3(tiles_m * tiles_n), dim3(512), 131072, st, a, tiles_m, tiles_n);
+    S2V_TRY(ensure_lds_attr((const void*)gemm_bf16_pp64<EPI, 0, true>, 131072 + 2048));  // + two stages of A block scales (MX)
+    hipLaunchKernelGGL((gemm_bf16_pp64<EPI, 0, true>), dim3(tiles_m * tiles_n), dim3(512), 131072 + 2048, st, a, tiles_m, tiles_n);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
 int launch_gemm_fp8(const GemmArgs& a, int epi, hipStream_t st) {
-    S2V_REQUIRE(!a.conv && a.a_scale && a.w_scale, "gemm_fp8: plain mode with both scale vectors only");
+    S2V_REQUIRE(!a.conv && (a.a_scale || a.mx_a_s) && a.w_scale, "gemm_fp8: plain mode with the weight scales and row or block scales of A only");
+    S2V_REQUIRE(!a.mx_out_q || (epi == EPI_BIAS_GELU && a.mx_out_s && a.N % 64 == 0), "gemm_fp8: MX output is the GELU epilogue's, N a multiple of 64");
     S2V_REQUIRE(a.K % 128 == 0 && a.lda % 16 == 0 && a.ldw % 16 == 0, "gemm_fp8: K must be a multiple of 128, rows 16-byte aligned");
     S2V_REQUIRE(a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM && a.w_rows_padded >= ((a.N + WBN - 1) / WBN) * WBN,
                 "gemm_fp8: operands must be padded to whole 256-row tiles");

@@ -134,7 +134,7 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
     // SC (fp8 operands): acc * a_scale[row] * w_scale[column] first -- the dequantisation of the per-token / per-channel scales
     float sa[MB];
 #pragma unroll
-    for (int j = 0; j < MB; ++j) sa[j] = SC ? a.a_scale[min(mw + j * 32 + fr, a.M - 1)] : 1.f;
+    for (int j = 0; j < MB; ++j) sa[j] = (SC && a.a_scale) ? a.a_scale[min(mw + j * 32 + fr, a.M - 1)] : 1.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -231,7 +231,31 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
                     o[e] = pack2bf(__uint_as_float(v[u][e] << 16) + __uint_as_float(xo[u][e] << 16),
                                    __uint_as_float(v[u][e] & 0xffff0000u) + __uint_as_float(xo[u][e] & 0xffff0000u));
             }
-            if (mrow[u] < a.M && n_ok) {
+            if (EPI == EPI_BIAS_GELU && a.mx_out_q) {
+                // MX output (GemmArgs::mx_out_q): the lane's 8 values are a quarter of a 32-column block (lanes c16 & ~3 .. + 3 of
+                // the row); block scale = smallest power of two s with amax / s <= 448, elements = rne_e4m3(x / s)
+                float x[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(o[e] << 16); x[2 * e + 1] = __uint_as_float(o[e] & 0xffff0000u); }
+                float am = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(x[e]));
+                am = fmaxf(am, __shfl_xor(am, 1, 64));
+                am = fmaxf(am, __shfl_xor(am, 2, 64));
+                unsigned eb = (__float_as_uint(am * (1.0f / 448.0f)) + 0x7fffffu) >> 23;  // biased exponent, rounded up unless am / 448 is a power of two
+                eb = min(max(eb, 1u), 254u);
+                const float inv = __uint_as_float((254u - eb) << 23);                     // 2^(127 - eb): exact
+                int w0 = 0, w1 = 0;
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0] * inv, x[1] * inv, w0, false);
+                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2] * inv, x[3] * inv, w0, true);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[4] * inv, x[5] * inv, w1, false);
+                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6] * inv, x[7] * inv, w1, true);
+                const unsigned e2 = eb | ((unsigned)__shfl_xor((int)eb, 4, 64) << 8);      // lane c16 = 0: blocks 0 and 1 of the 64 columns
+                if (mrow[u] < a.M && n_ok) {
+                    *(u32x2*)(a.mx_out_q + (size_t)mrow[u] * a.N + n) = u32x2{(unsigned)w0, (unsigned)w1};
+                    if (c16 == 0) *(unsigned short*)(a.mx_out_s + (size_t)mrow[u] * (a.N >> 5) + (n >> 5)) = (unsigned short)e2;
+                }
+            } else if (mrow[u] < a.M && n_ok) {
                 if (EPI == EPI_BIAS_GATE_RES) *(u32x4*)((bf16_t*)a.X + (size_t)mrow[u] * a.ldx + n) = o;
                 else *(u32x4*)((bf16_t*)a.C + (size_t)mrow[u] * a.ldc + n) = o;
             }

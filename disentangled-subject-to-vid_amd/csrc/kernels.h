@@ -53,6 +53,13 @@ struct GemmArgs {
     // tile (zero before the launch, zero again after it).  The last workgroup to arrive adds the partials IN SPLIT ORDER (so the sum
     // does not depend on who was last) and runs the epilogue.
     int splitk; float* sk_ws; unsigned* sk_cnt;
+    // fp8 GEMMs only, MX (block-scaled) activations: v_mfma_scale_f32_32x32x64_f8f6f4 takes one E8M0 scale per lane = per (row, 32
+    // consecutive K elements), so a producer can quantise its output tile in place -- no row amax across workgroups.
+    //   mx_out_q / mx_out_s (EPI_BIAS_GELU): the epilogue writes e4m3 bytes [M][N] and scale bytes [M][N / 32] (2^(s - 127), the
+    //   smallest power of two with amax / scale <= 448) INSTEAD of the bf16 C;
+    //   mx_a_s: A is such an image, its block scales [M_pad][K / 32]; a_scale may then be null (= 1).
+    unsigned char* mx_out_q; unsigned char* mx_out_s;
+    const unsigned char* mx_a_s;
 };
 // fp8 x fp8 -> bf16 GEMM on v_mfma_scale_f32_32x32x64_f8f6f4 (unit block scales; the per-row scales above in the epilogue): the
 // 256 x 256 ping-pong schedule of gemm_bf16_pp64 on K-tiles of 128 bytes.  Plain mode only (no conv), K % 128 == 0, N_pad % 256 == 0.

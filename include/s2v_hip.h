@@ -280,6 +280,13 @@ S2V_API int s2v_op_linear(const void* A, const void* W, const void* bias, void* 
  * M, N multiples of 256, K a multiple of 128; epilogue 0 = bias, 1 = bias + GELU(tanh). */
 S2V_API int s2v_op_linear_fp8(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
                               int32_t epilogue, void* scratch, int64_t scratch_bytes, s2v_stream stream);
+/* FeedForward (attention.py:1237-1243: Linear D -> F, GELU(tanh), Linear F -> D) on the fp8 matrix cores as the fp8 engine runs it:
+ * x [M, D], W1 [F, D], W2 [D, F] bf16, quantised per row to e4m3; mx = 1: GELU(h) leaves the first GEMM's epilogue as MX e4m3 (one
+ * power-of-two scale per 32 columns, the block scales v_mfma_scale_f32_32x32x64_f8f6f4 takes per lane) and the second GEMM reads it
+ * in place; mx = 0: bf16 h + a per-row quantisation pass.  M, D, F multiples of 256; allocates its scratch, synchronous.  No
+ * reference arithmetic exists for fp8 (parity unpinned): tests/test_gpu_fp8.py states the contract against a torch emulation. */
+S2V_API int s2v_op_ff_fp8(const void* x, const void* w1, const void* b1, const void* w2, const void* b2, void* out, int32_t M,
+                          int32_t D, int32_t F, int32_t mx, s2v_stream stream);
 /* out[b][r] = silu(emb[b]) . W[r] + bias[r] for the stacked AdaLN modulation linears of a step (every
  * CogVideoXLayerNormZero.linear and norm_out.linear on silu(temb), normalization.py / cogvideox_transformer_3d.py:122-186);
  * emb [B, temb_dim], W [rows, temb_dim], out [B, rows], B <= 4; impl 0 = the product dispatch, 1 = one wave per row */

@@ -168,3 +168,53 @@ def test_fp8_quantisation_fused_into_layernorm_is_bit_identical_to_the_separate_
     finally:
         diag.s2v_set_fused_q8(1)
         L._lib = prev
+
+
+def quant_mx(h):
+    """MX e4m3 as the FF1 epilogue produces it (gemm_epi.h): blocks of 32 columns, scale = the smallest power of two s with
+    amax / s <= 448 (the E8M0 byte is the biased exponent of amax / 448 rounded up), elements = rne_e4m3(x / s)"""
+    M, F = h.shape
+    b = h.float().view(M, F // 32, 32)
+    amax = b.abs().amax(dim=2, keepdim=True)
+    t = (amax * (1.0 / 448.0)).contiguous().view(torch.int32)
+    eb = ((t + 0x7FFFFF) >> 23).clamp(1, 254)
+    s = ((eb << 23).view(torch.float32))
+    q = (b * (((254 - eb) << 23).view(torch.float32))).to(torch.float8_e4m3fn)
+    return (q.float() * s).view(M, F)
+
+
+@pytest.mark.parametrize("M,D,F", [(256, 256, 1024), (512, 768, 3072)])
+def test_op_ff_fp8_mx_hand_over_matches_emulation(s2v, M, D, F):
+    """the fp8 FeedForward (attention.py:1237-1243) with GELU(h) handed from the FF1 epilogue to the FF2 as MX e4m3 -- block scales taken
+    per lane by v_mfma_scale_f32_32x32x64_f8f6f4 -- against a torch emulation of the same quantisation (rel-L2 <= 6e-3: bf16 roundings
+    of h can flip an e4m3 rounding), against the per-row-quantised hand-over (mx = 0) and against the un-quantised bf16 arithmetic"""
+    L = s2v._lib
+    g = torch.Generator().manual_seed(M + D + F)
+    x = (torch.randn(M, D, generator=g) * (0.5 + torch.rand(M, 1, generator=g))).bfloat16().to(DEV)
+    w1 = (torch.randn(F, D, generator=g) / D ** 0.5).bfloat16().to(DEV)
+    b1 = (torch.randn(F, generator=g) * 0.1).bfloat16().to(DEV)
+    w2 = (torch.randn(D, F, generator=g) / F ** 0.5).bfloat16().to(DEV)
+    b2 = (torch.randn(D, generator=g) * 0.1).bfloat16().to(DEV)
+    outs = {}
+    for mx in (1, 0):
+        out = torch.full((M, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        L.check(L.lib().s2v_op_ff_fp8(L.ptr(x), L.ptr(w1), L.ptr(b1), L.ptr(w2), L.ptr(b2), L.ptr(out), M, D, F, mx, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs[mx] = out.float()
+        assert torch.isfinite(outs[mx]).all()
+    qx, sx = quant_rows(x)
+    q1, s1 = quant_rows(w1)
+    q2, s2 = quant_rows(w2)
+    h = torch.nn.functional.gelu(((qx.float() @ q1.float().T) * sx * s1.T + b1.float()).bfloat16().float(), approximate="tanh").bfloat16().float()
+    emu_mx = (quant_mx(h) @ q2.float().T) * s2.T + b2.float()
+    qh, sh = quant_rows(h.bfloat16())
+    emu_row = (qh.float() @ q2.float().T) * sh * s2.T + b2.float()
+    full = torch.nn.functional.gelu((x.float() @ w1.float().T + b1.float()).bfloat16().float(), approximate="tanh").bfloat16().float() @ w2.float().T + b2.float()
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm()).item()
+
+    assert rel(outs[1], emu_mx) <= 6e-3, rel(outs[1], emu_mx)
+    assert rel(outs[0], emu_row) <= 6e-3, rel(outs[0], emu_row)
+    assert rel(outs[1], full) <= 5e-2 and rel(outs[0], full) <= 5e-2
+    assert rel(outs[1], full) <= 1.1 * rel(outs[0], full) + 1e-3, "block scales must not be worse than one scale per row"
