@@ -494,9 +494,12 @@ extern "C" __attribute__((visibility("default"))) int s2v_debug_read(long long* 
 //        each read's lgkmcnt(0) sits after the next barrier, and one more barrier precedes the DMA issue above.
 //   RAW  tile T+1 is first read in I_4T+4 (A-lo, W-lo, W-hi) and I_4T+5 (A-hi): the waits above sit in I_4T+3 / I_4T+4.
 // FP8: the same schedule byte for byte on e4m3 operands -- a K-tile is 128 elements = the same 128-byte rows, a half-step (64 bytes
-// of K) is ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 block (64 cycles, twice the bf16 rate) whose 32-byte operand is the
-// two 16-byte fragments a lane reads for its K half (chunks s*4 + hi*2 + {0, 1}); block scales are unit (E8M0 127), the
-// per-token / per-channel scales are applied by the epilogue.
+// of K) is ONE v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 block (64 cycles, twice the bf16 rate).  The instruction's LOGICAL K order
+// (tools/probes/mfma_mx.hip): block b (32 elements, one E8M0 scale) = bytes 16 b .. 16 b + 15 of the operand registers of BOTH lane
+// halves, its scale is taken from lanes 32 b + row.  With the bf16 chunk order -- a lane's two 16-byte fragments are chunks
+// s*4 + kk*2 + hi, kk = 0, 1 -- the logical blocks of half-step s are therefore the memory-contiguous 32-element blocks 2 s and
+// 2 s + 1 of the K-tile, and lane (row, hi) supplies the scale of block 2 s + hi.  Per-token / per-channel scales are applied by the
+// epilogue; the block scales are unit unless A is an MX image (GemmArgs::mx_a_s).
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 typedef int i32x8v __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ i32x8v cat16(bf16x8 lo, bf16x8 hi) {
@@ -586,7 +589,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
     if (g) __builtin_amdgcn_s_barrier();  // group 1 idles through I_0
 
     bf16x8 wf[2][2], af[2][4];
-    int sb_[4] = {127, 127, 127, 127};  // E8M0 scales of the lane's A blocks: byte 0 for half-step 0, byte 2 for half-step 1
+    int sb_[4] = {0x007f007f, 0x007f007f, 0x007f007f, 0x007f007f};  // E8M0 scales of the lane's A blocks: byte 0 for half-step 0, byte 2 for half-step 1 (unit unless MX)
     auto reads = [&](int t, int s) {
         if (ABL == 6 && t > 0) return;
         const char* tA = smem + (t & 1) * 65536;
@@ -599,9 +602,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i) wf[kk][i] = lds_frag(tW, wn * 64 + i * 32 + fr, FP8 ? s * 4 + hi * 2 + kk : s * 4 + kk * 2 + hi);
+            for (int i = 0; i < 2; ++i) wf[kk][i] = lds_frag(tW, wn * 64 + i * 32 + fr, s * 4 + kk * 2 + hi);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[kk][j] = lds_frag(tA, wm * 128 + j * 32 + fr, FP8 ? s * 4 + hi * 2 + kk : s * 4 + kk * 2 + hi);
+            for (int j = 0; j < 4; ++j) af[kk][j] = lds_frag(tA, wm * 128 + j * 32 + fr, s * 4 + kk * 2 + hi);
         }
     };
     // (ABL >= 4): per-wave stall accounting with s_memtime (diagnostics; totals of block 100 go to g_pp_dbg[8][6])

@@ -234,25 +234,29 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
             if (EPI == EPI_BIAS_GELU && a.mx_out_q) {
                 // MX output (GemmArgs::mx_out_q): the lane's 8 values are a quarter of a 32-column block (lanes c16 & ~3 .. + 3 of
                 // the row); block scale = smallest power of two s with amax / s <= 448, elements = rne_e4m3(x / s)
-                float x[8];
+                // |x| of non-negative bf16 order like their bit patterns: the amax of the 8 values is a packed 16-bit integer max, the
+                // quad's by two DPP exchanges; the conversion divides by the block scale itself (v_cvt_scalef32_pk_fp8_bf16)
+                typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+                u16x2_t pm = __builtin_bit_cast(u16x2_t, o[0] & 0x7fff7fffu);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(o[e] << 16); x[2 * e + 1] = __uint_as_float(o[e] & 0xffff0000u); }
-                float am = 0.f;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(x[e]));
-                am = fmaxf(am, __shfl_xor(am, 1, 64));
-                am = fmaxf(am, __shfl_xor(am, 2, 64));
-                unsigned eb = (__float_as_uint(am * (1.0f / 448.0f)) + 0x7fffffu) >> 23;  // biased exponent, rounded up unless am / 448 is a power of two
+                for (int e = 1; e < 4; ++e) pm = __builtin_elementwise_max(pm, __builtin_bit_cast(u16x2_t, o[e] & 0x7fff7fffu));
+                int amb = (int)max((unsigned)pm[0], (unsigned)pm[1]) << 16;                               // bits of amax as fp32
+                amb = max(amb, __builtin_amdgcn_update_dpp(0, amb, 0xB1, 0xf, 0xf, true));                  // lane ^ 1
+                amb = max(amb, __builtin_amdgcn_update_dpp(0, amb, 0x4E, 0xf, 0xf, true));                  // lane ^ 2
+                unsigned eb = (__float_as_uint(__int_as_float(amb) * (1.0f / 448.0f)) + 0x7fffffu) >> 23;  // biased exponent, rounded up unless am / 448 is a power of two
                 eb = min(max(eb, 1u), 254u);
-                const float inv = __uint_as_float((254u - eb) << 23);                     // 2^(127 - eb): exact
-                int w0 = 0, w1 = 0;
-                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0] * inv, x[1] * inv, w0, false);
-                w0 = __builtin_amdgcn_cvt_pk_fp8_f32(x[2] * inv, x[3] * inv, w0, true);
-                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[4] * inv, x[5] * inv, w1, false);
-                w1 = __builtin_amdgcn_cvt_pk_fp8_f32(x[6] * inv, x[7] * inv, w1, true);
-                const unsigned e2 = eb | ((unsigned)__shfl_xor((int)eb, 4, 64) << 8);      // lane c16 = 0: blocks 0 and 1 of the 64 columns
+                const float bscale = __uint_as_float(eb << 23);                                             // 2^(eb - 127)
+                // v_cvt_scalef32_pk_fp8_bf16 d, s, scale = rne_e4m3(s / scale) on a packed bf16 pair (tools/probes/mx_quant.hip: bit-identical
+                // to unpack + multiply + v_cvt_pk_fp8_f32).  Inline asm: the builtin form was mis-compiled by this hipcc (ROCm 7.2:
+                // every call of a group read the first call's source register).
+                unsigned w0 = 0, w1 = 0;
+                asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(w0) : "v"(o[0]), "v"(bscale));
+                asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(w0) : "v"(o[1]), "v"(bscale));
+                asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(w1) : "v"(o[2]), "v"(bscale));
+                asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(w1) : "v"(o[3]), "v"(bscale));
+                const unsigned e2 = eb | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)eb, 0x104, 0xf, 0xf, true) << 8);  // lane c16 = 0: + lane 4's block
                 if (mrow[u] < a.M && n_ok) {
-                    *(u32x2*)(a.mx_out_q + (size_t)mrow[u] * a.N + n) = u32x2{(unsigned)w0, (unsigned)w1};
+                    *(u32x2*)(a.mx_out_q + (size_t)mrow[u] * a.N + n) = u32x2{w0, w1};
                     if (c16 == 0) *(unsigned short*)(a.mx_out_s + (size_t)mrow[u] * (a.N >> 5) + (n >> 5)) = (unsigned short)e2;
                 }
             } else if (mrow[u] < a.M && n_ok) {

@@ -216,5 +216,5 @@ def test_op_ff_fp8_mx_hand_over_matches_emulation(s2v, M, D, F):
 
     assert rel(outs[1], emu_mx) <= 6e-3, rel(outs[1], emu_mx)
     assert rel(outs[0], emu_row) <= 6e-3, rel(outs[0], emu_row)
-    assert rel(outs[1], full) <= 5e-2 and rel(outs[0], full) <= 5e-2
+    assert rel(outs[1], full) <= 7e-2 and rel(outs[0], full) <= 7e-2   # two chained e4m3 GEMMs: 4e-2 each (test above) in quadrature
     assert rel(outs[1], full) <= 1.1 * rel(outs[0], full) + 1e-3, "block scales must not be worse than one scale per row"
