@@ -86,9 +86,12 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
 }
 // same function as x * sigmoid(2u): one v_exp_f32 + one v_rcp_f32 (relative error ~1e-6, far below a bf16 ulp);
 // used by the bf16 MFMA epilogue where tanhf() cost ~10 % of the FF1 GEMM
+// seven VALU: the exp2 argument -log2(e) * 2u = x * (k0 + k1 x^2) with the constants folded (the four-wave GEMM's epilogue is VALU-issue
+// bound: one instruction per ~5 cycles and wave, 256 outputs per lane)
 __device__ __forceinline__ float gelu_tanh_fast(float x) {
-    const float u2 = 1.5957691216057308f * (x + 0.044715f * x * x * x);
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * u2);
+    constexpr float k0 = -1.4426950408889634f * 1.5957691216057308f, k1 = k0 * 0.044715f;
+    const float p = fmaf(x * x, k1, k0);
+    const float e = __builtin_amdgcn_exp2f(x * p);
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
