@@ -95,6 +95,9 @@ __device__ __forceinline__ float gelu_tanh_fast(float x) {
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// x * sigmoid(x) on the hardware exp2 / rcp (relative error ~2e-7): for values that are rounded to bf16 next
+__device__ __forceinline__ float silu_fast(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+template <typename T> __device__ __forceinline__ float silu_t(float x) { return sizeof(T) == 2 ? silu_fast(x) : silu_f(x); }
 
 // LDS-DMA of 16 B per lane in the saddr + 32-bit voffset form: global address = sbase (wave-uniform, SGPR pair) + voff
 // (per-lane byte offset), LDS address = M0 + 16 * lane.  hipcc picks the 64-bit vaddr form inside loops; this pins the

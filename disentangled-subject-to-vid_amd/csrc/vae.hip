@@ -158,7 +158,8 @@ __global__ __launch_bounds__(256) void gn_stats_k(const T* x, int64_t P, int C, 
     for (int e = 0; e < VN; ++e) { a[e] = 0.f; q[e] = 0.f; }
     const int64_t p0 = (int64_t)blockIdx.x * GN_PIX_PER_BLOCK;
     const int64_t p1 = min(p0 + GN_PIX_PER_BLOCK, P);
-    for (int64_t p = p0 + pl; p < p1; p += ppi) {
+#pragma unroll 4
+    for (int64_t p = p0 + pl; p < p1; p += ppi) {  // four loads in flight, sums in the same order
         float v[VN];
         V16<T>::ld(x + p * C + vi * VN, v);
 #pragma unroll
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void snorm_apply_k(const SNormArgs a) {
             const float n = ET<T>::rnd((v[e] - mean[g]) * rstd[g] * g_w[e] + g_b[e]);
             float r = n;  // plain nn.GroupNorm (encoder resnets, yt == nullptr)
             if (a.yt != nullptr) r = ET<T>::rnd(ET<T>::rnd(n * cy[e]) + cb[e]);
-            if (a.silu) r = ET<T>::rnd(silu_f(r));
+            if (a.silu) r = ET<T>::rnd(silu_t<T>(r));
             o[e] = r;
         }
         V16<T>::st(out + ((((int64_t)(f + a.f_off)) * Hp + yy + 1) * Wp + xx + 1) * C + c0, o);
@@ -307,32 +308,35 @@ __global__ __launch_bounds__(256) void snorm_apply_rows_k(const SNormArgs a) {
         rs[e] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + (double)a.eps));
     }
     const int Hp = a.H + 2, Wp = a.W + 2;
-    const T* x = (const T*)a.x;
-    T* out = (T*)a.out;
+    const T* __restrict__ x = (const T*)a.x;
+    T* __restrict__ out = (T*)a.out;  // never aliases x or the tables: the loads of the next pixels may pass the stores
+    const T* __restrict__ yt = (const T*)a.yt;
+    const T* __restrict__ bt = (const T*)a.bt;
     const int rows = a.F * a.H;
     for (int r = blockIdx.x; r < rows; r += gridDim.x) {
         const int f = r / a.H, yy = r - f * a.H;
         const int fz = zq_frame(f, a.F, a.Fz);
         const int yz = (int)(((int64_t)yy * a.hz) / a.H);
-        const T* xr = x + (int64_t)r * a.W * C + c0;
-        T* orow = out + ((((int64_t)(f + a.f_off)) * Hp + yy + 1) * Wp + 1) * C + c0;
+        const T* __restrict__ xr = x + (int64_t)r * a.W * C + c0;
+        T* __restrict__ orow = out + ((((int64_t)(f + a.f_off)) * Hp + yy + 1) * Wp + 1) * C + c0;
         const int64_t zrow = ((int64_t)fz * a.hz + yz) * a.wz;
+#pragma unroll 2
         for (int xx = pl; xx < a.W; xx += ppi) {
             float v[VN], cy[VN], cb[VN];
             V16<T>::ld(xr + (int64_t)xx * C, v);
-            if (a.yt != nullptr) {
+            if (yt != nullptr) {
                 const int xz = (int)(((unsigned)xx * (unsigned)a.wz) / (unsigned)a.W);
                 const int64_t pz = (zrow + xz) * C + c0;
-                V16<T>::ld((const T*)a.yt + pz, cy);
-                V16<T>::ld((const T*)a.bt + pz, cb);
+                V16<T>::ld(yt + pz, cy);
+                V16<T>::ld(bt + pz, cb);
             }
             float o[VN];
 #pragma unroll
             for (int e = 0; e < VN; ++e) {
                 const float n = ET<T>::rnd((v[e] - mu[e]) * rs[e] * g_w[e] + g_b[e]);
                 float rr = n;
-                if (a.yt != nullptr) rr = ET<T>::rnd(ET<T>::rnd(n * cy[e]) + cb[e]);
-                if (a.silu) rr = ET<T>::rnd(silu_f(rr));
+                if (yt != nullptr) rr = ET<T>::rnd(ET<T>::rnd(n * cy[e]) + cb[e]);
+                if (a.silu) rr = ET<T>::rnd(silu_t<T>(rr));
                 o[e] = rr;
             }
             V16<T>::st(orow + (int64_t)xx * C, o);
