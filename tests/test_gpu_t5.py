@@ -55,6 +55,30 @@ def test_t5_mfma_width_bf16_vs_oracle(s2v, simple):
     assert rel <= 3e-2, rel
 
 
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_t5_prompt_lengths_either_side_of_the_lds_attention_limit(s2v, dt):
+    """t5.hip keeps a head's K / V in LDS up to 280 tokens (t5_attn_lds_k: 2 x 226 is the pipeline's case) and falls back to the
+    one-wave-per-query kernel beyond; both restate T5Attention.forward (transformers modeling_t5: scores + position_bias, fp32
+    softmax) with the same rounding points -- T = 280 (last LDS size, ragged 64-key chunk) and T = 300 (fallback) against the oracle"""
+    cfgd = dict(vocab_size=300, d_model=128, d_kv=64, num_heads=2, d_ff=256, num_layers=2, relative_attention_num_buckets=32,
+                relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
+    cfg = s2v.T5Config(**cfgd)
+    sd = {k: v.to(dt) for k, v in s2v.weights.synthetic_t5_state_dict(cfg, seed=71).items()}
+    m = s2v.HipT5EncoderModel(cfg, dt, DEV)
+    m.load_state_dict(sd)
+    for T in (280, 300, 65):
+        ids = torch.randint(0, 300, (2, T), generator=torch.Generator().manual_seed(T))
+        y = m(ids.to(DEV))[0].float().cpu()
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            exp = t5_ref.encoder_forward(sd, cfgd, ids).float()
+        assert torch.isfinite(y).all()
+        if dt == torch.float32:
+            assert (y - exp).abs().max().item() <= 1e-3, T
+        else:
+            assert ((y - exp).norm() / exp.norm()).item() <= 3e-2, T
+
+
 def test_t5_errors(s2v):
     cfg = s2v.T5Config(**TINY)
     m = s2v.HipT5EncoderModel(cfg, torch.float32, DEV)
