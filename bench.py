@@ -334,6 +334,7 @@ def main():
     if rank == 0 and not args.no_vae:
         # wall-clock per video = 50 denoise steps + VAE decode (BASELINE.json metric, second half); decode is timed once
         # outside the step timing, untiled (288 GB part) and tiled (what src/inference.py:204-207 enables)
+        torch.cuda.empty_cache()  # the tiled decode sizes its workspace sets (tiles in flight) by the free HBM: hand back torch's cached blocks
         vcfg = s2v.VAEConfig(scaling_factor=cfg.vae_scaling_factor)
         vae = s2v.HipAutoencoderKLCogVideoX(vcfg, dt, dev)
         vae.load_state_dict(s2v.weights.synthetic_vae_state_dict(vcfg, seed=7, device=dev))
