@@ -347,6 +347,7 @@ def main():
             frames = vae.decode_latents(latents)
             torch.cuda.synchronize()
             dec["tiled" if tiling else "untiled"] = time.perf_counter() - t1
+        vae_sets, vae_set_bytes = vae.workspace_info()
         # reference-image encode (src/video_generate.py:26-38), reported beside the metric, not inside it
         vae.load_state_dict(s2v.weights.synthetic_vae_encoder_state_dict(vcfg, seed=8, device=dev, dtype=dt))
         img = (torch.rand(1, 3, 1, H * 8, W * 8, generator=torch.Generator().manual_seed(9)) * 2 - 1).to(dev, dt)
@@ -380,6 +381,7 @@ def main():
                  "ref_image_encode_untiled_s": round(enc["untiled"], 4), "ref_image_encode_tiled_s": round(enc["tiled"], 4),
                  "ref_latent_finite": bool(torch.isfinite(ref_lat.float()).all().item()),
                  "vae_decode_untiled_s": round(dec["untiled"], 3), "vae_decode_tiled_s": round(dec["tiled"], 3),
+                 "vae_tiles_in_flight": vae_sets, "vae_workspace_set_gb": round(vae_set_bytes / 1e9, 1),
                  "s_per_video_untiled": round(50 * step_s + dec["untiled"], 2),
                  "s_per_video_tiled": round(50 * step_s + dec["tiled"], 2),
                  "frames": list(frames.shape), "frames_finite": bool(torch.isfinite(frames.float()).all().item())}

@@ -67,6 +67,7 @@ struct s2v_vae {
     };
     std::vector<WS> ws;
     int ws_active = 0, ws_req = 0;  // ws_req: sets asked for when ws was built (memory may have granted fewer)
+    int64_t set_bytes = 0;          // bytes of one set at the current capacity
     std::vector<hipStream_t> side;  // one per workspace set beyond the first
     std::vector<hipEvent_t> ev_side;
     hipEvent_t ev_fork = nullptr;
@@ -362,6 +363,7 @@ static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws
             dmax = std::max(dmax, (int64_t)v->fmax[c.level] * H * W * std::max(c.cin, c.cout) * v->esz);
         });
         set_bytes += 3 * dmax;
+        v->set_bytes = set_bytes;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && set_bytes > 0)
             nws = (int)std::max<int64_t>(1, std::min<int64_t>(nws, (int64_t)(0.7 * (double)free_b) / set_bytes));
@@ -527,6 +529,13 @@ static TileGeo tile_geo(s2v_vae* v) {  // :1102-1114, 1400-1406 incl. the int() 
 static bool use_tiles(s2v_vae* v, int h, int w, int tiling) {
     TileGeo t = tile_geo(v);
     return tiling && (w > t.tl_w || h > t.tl_h);
+}
+
+extern "C" int s2v_vae_workspace_info(s2v_vae* v, int32_t* sets, int64_t* bytes_per_set) {
+    S2V_REQUIRE(v && sets && bytes_per_set, "s2v_vae_workspace_info: null argument");
+    *sets = (int32_t)v->ws.size();
+    *bytes_per_set = v->set_bytes;
+    return 0;
 }
 
 extern "C" int s2v_vae_out_shape(s2v_vae* v, int32_t F, int32_t h, int32_t w, int32_t tiling, int32_t* Fo, int32_t* Ho,

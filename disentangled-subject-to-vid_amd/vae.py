@@ -30,6 +30,7 @@ _lib.register_sigs({
     "s2v_vae_weight_arena": [_P, ctypes.POINTER(_P), ctypes.POINTER(_I64)],
     "s2v_vae_mark_weights_loaded": [_P],
     "s2v_vae_out_shape": [_P, _I32, _I32, _I32, _I32, ctypes.POINTER(_I32), ctypes.POINTER(_I32), ctypes.POINTER(_I32)],
+    "s2v_vae_workspace_info": [_P, ctypes.POINTER(_I32), ctypes.POINTER(_I64)],
     "s2v_vae_decode": [_P, _P, _I32, _I32, _I32, _I32, _I32, _P, _P],
     "s2v_vae_postprocess": [_P, _I32, _I32, _I32, _I32, _P, _I32, _P],
     "s2v_vae_postprocess_u8": [_P, _I32, _I32, _I32, _I32, _P, _I32, _P],
@@ -209,6 +210,13 @@ class HipAutoencoderKLCogVideoX:
         if not return_dict:
             return (post,)
         return SimpleNamespace(latent_dist=post)
+
+    def workspace_info(self):
+        """(workspace sets = tiles in flight, bytes per set) of the decoder's current capacity: the tiled decode takes as many
+        sets as 70 % of the free HBM holds, at most six"""
+        n, b = _I32(), _I64()
+        _lib.check(_lib.lib().s2v_vae_workspace_info(self._h, ctypes.byref(n), ctypes.byref(b)))
+        return n.value, b.value
 
     def _out_shape(self, F, h, w):
         fo, ho, wo = _I32(), _I32(), _I32()
