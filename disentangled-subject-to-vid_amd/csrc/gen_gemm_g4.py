@@ -26,6 +26,13 @@ What the measurements said (tools/stall_g4.py, tools/g4_ablate.sh; cycles per K-
   * an L2 prefetch (G4_PF > 0: PF K-tiles ahead each wave touches the 128 cache lines of its own future pieces with two
     global_load_dword, one lane per line, result discarded): 2470-3070 -- a load with 64 distinct lines per instruction occupies the
     CU's address path longer than the latency it was meant to hide.
+  * register-staged operands (G4_STAGE=reg: global_load_dwordx4 of K-tile t+2 into one of two 64-VGPR sets, ds_write_b128 of K-tile t+1
+    behind a counted vmcnt -- 1-1.5 K-tiles of lead instead of 0.75-1; results bit-identical): 3020-3440 with the 16 loads and the 16
+    writes dense in one step each, 2340-2480 with both spread one per two MFMAs (G4_REGV=2) against 2154-2453 for this schedule on the
+    same box.  Writes alone cost 215 cycles per K-tile (13 per ds_write_b128: the LDS-DMA writes LDS without holding the wave), and
+    with the writes removed the loop still waits for the loads (FF2: 2790): operands that miss the XCD's L2 take longer than one K-tile
+    to arrive, a third register set does not fit (292 VGPRs), so more lead needs a third LDS stage, which 160 KiB only has for one
+    operand.
 So the schedule below stands: 3-4 % faster than gemm_bf16_pp64 on the four C3 shapes (profiles/r03_gemm_g4.txt); what is left above the
 floor is the latency of operands that come from beyond the XCD's L2, which two stages cannot cover.
 
@@ -47,6 +54,8 @@ import os
 ACC, FRAG, VADDR, VOFF, VPF, VPFD = 0, 0, 64, 80, 96, 98
 S_A, S_W, S_M0W, S_CNT = 36, 38, 40, 41
 ABLATE = set(filter(None, os.environ.get("G4_ABLATE", "").split(",")))
+STAGE = os.environ.get("G4_STAGE", "dma")  # "dma": LDS-DMA pieces one K-tile ahead; "reg": global_load -> VGPR two K-tiles ahead, ds_write (below)
+VREG, VWR = 100, 228                       # "reg": two sets of 16 pieces x 4 VGPRs (v[100:227]); ds_write addresses of stage 0 / 1 (v228, v229)
 PF = int(os.environ.get("G4_PF", "0"))  # K-tiles between the L2 prefetch of a tile and its staging (0: none -- the default, see above); even
 
 
@@ -111,6 +120,108 @@ def ktile(emit, g, first=False, dma_w=True, dma_a=True, last=False, prefetch=Fal
         if s == 3 and dma_a:
             emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
             emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
+
+
+REGV = int(os.environ.get("G4_REGV", "0"))  # "reg" placement: 0 = loads dense in step 0, writes dense in step 2; 1 = loads one per two MFMAs over steps 0-1; 2 = + writes over steps 1-2
+
+
+def ktile_reg(emit, g, first=False, loads=True, writes=True, last=False):
+    """register-staged K-tile t (stage g = t & 1): the operands of K-tile t+2 are requested in step 0 (steps 0-1) into register set g
+    (free since its ds_write in K-tile t-1), the operands of K-tile t+1 (register set g^1, requested one K-tile ago) are written to
+    stage g^1 in step 2 (steps 1-2) behind a counted vmcnt: a load has 1-1.5 K-tiles to arrive where an LDS-DMA piece had 0.75-1."""
+    wsteps = (1, 2) if REGV >= 2 else (2,)
+    for s in range(4):
+        cur, nxt = s & 1, (s & 1) ^ 1
+        if s == 3 and not last:
+            emit("s_waitcnt lgkmcnt(0)")
+            emit("s_barrier")
+        elif s == wsteps[0] and writes:
+            newer = 0 if not loads else (16 if REGV == 0 else 8 * s)  # loads of K-tile t+2 already issued in this tile
+            emit(f"s_waitcnt vmcnt({newer}) lgkmcnt(0)")
+        else:
+            emit("s_waitcnt lgkmcnt(0)")
+        for k in range(16):
+            i, j = k >> 2, k & 3
+            acc = ar(ACC + 64 * i + 16 * j, 16)
+            c = "0" if (first and s == 0) else acc
+            emit(f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(wf(cur, i), 4)}, {vr(af(cur, j), 4)}, {c}")
+            if k < 8 and not (last and s == 3):
+                gs, ss = (g, s + 1) if s < 3 else (g ^ 1, 0)
+                if k < 4:
+                    emit(f"ds_read_b128 {vr(wf(nxt, k), 4)}, {vr(vaddr(True, gs, ss))} offset:{k * 4096}")
+                else:
+                    emit(f"ds_read_b128 {vr(af(nxt, k - 4), 4)}, {vr(vaddr(False, gs, ss))} offset:{(k - 4) * 4096}")
+            pl = k if (REGV == 0 and s == 0) else (s * 8 + (k >> 1) if (REGV >= 1 and s < 2 and (k & 1)) else -1)
+            if loads and pl >= 0:     # piece pl of K-tile t+2 (A pieces 0-7, W pieces 0-7) -> register set g
+                src = f"{vr(VOFF + pl)}, s[{S_A}:{S_A + 1}]" if pl < 8 else f"{vr(VOFF + pl)}, s[{S_W}:{S_W + 1}]"
+                emit(f"global_load_dwordx4 {vr(VREG + 64 * g + 4 * pl, 4)}, {src}")
+            pw = k if (REGV < 2 and s == 2) else ((s - 1) * 8 + (k >> 1) if (REGV >= 2 and s in (1, 2) and not (k & 1)) else -1)
+            if writes and pw >= 0:    # piece pw of K-tile t+1: register set g^1 -> stage g^1
+                off = pw * 4096 if pw < 8 else 32768 + (pw - 8) * 4096
+                emit(f"ds_write_b128 {vr(VWR + (g ^ 1))}, {vr(VREG + 64 * (g ^ 1) + 4 * pw, 4)} offset:{off}")
+        if loads and s == (0 if REGV == 0 else 1):
+            for sp in (S_A, S_W):
+                emit(f"s_add_u32 s{sp}, s{sp}, 128")
+                emit(f"s_addc_u32 s{sp + 1}, s{sp + 1}, 0")
+
+
+def gen_reg():
+    L = []
+
+    def emit(ln):
+        op = ln.split()[0]
+        if "nodma" in ABLATE and op in ("global_load_dwordx4", "ds_write_b128"):
+            return
+        if ("noload" in ABLATE and op == "global_load_dwordx4") or ("nowrite" in ABLATE and op == "ds_write_b128"):
+            return
+        if "noread" in ABLATE and op == "ds_read_b128":
+            return
+        if "nobar" in ABLATE and op == "s_barrier":
+            return
+        L.append(ln)
+
+    emit("; ---- gemm_g4 K loop, register-staged operands (generated by gen_gemm_g4.py; do not edit)")
+    emit(f"v_add_u32 {vr(VWR)}, s{S_M0W}, {vr(V_SK)}")          # LDS address of the lane's 16 bytes of the wave's piece 0 of A, stage 0
+    emit(f"v_add_u32 {vr(VWR + 1)}, 0x10000, {vr(VWR)}")        # ... stage 1
+    for t in range(2):                                          # K-tiles 0 and 1 -> register sets 0 and 1
+        for k in range(16):
+            src = f"{vr(VOFF + k)}, s[{S_A}:{S_A + 1}]" if k < 8 else f"{vr(VOFF + k)}, s[{S_W}:{S_W + 1}]"
+            emit(f"global_load_dwordx4 {vr(VREG + 64 * t + 4 * k, 4)}, {src}")
+        for sp in (S_A, S_W):
+            emit(f"s_add_u32 s{sp}, s{sp}, 128")
+            emit(f"s_addc_u32 s{sp + 1}, s{sp + 1}, 0")
+    emit("s_waitcnt vmcnt(16)")
+    for k in range(16):
+        off = k * 4096 if k < 8 else 32768 + (k - 8) * 4096
+        emit(f"ds_write_b128 {vr(VWR)}, {vr(VREG + 4 * k, 4)} offset:{off}")
+    emit("s_waitcnt lgkmcnt(0)")
+    emit("s_barrier")
+    for n in range(8):  # fragments of step 0 of K-tile 0
+        if n < 4:
+            emit(f"ds_read_b128 {vr(wf(0, n), 4)}, {vr(vaddr(True, 0, 0))} offset:{n * 4096}")
+        else:
+            emit(f"ds_read_b128 {vr(af(0, n - 4), 4)}, {vr(vaddr(False, 0, 0))} offset:{(n - 4) * 4096}")
+    # K-tile 0, s41 pairs [odd, even] (t = 1 .. nT-4), then t = nT-3 (the last that requests operands), nT-2 (still writes nT-1), nT-1
+    ktile_reg(emit, 0, first=True)
+    emit("L_g4_loop_%=:")
+    emit(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    emit("s_cbranch_scc1 L_g4_nopf_%=")
+    ktile_reg(emit, 1)
+    ktile_reg(emit, 0)
+    emit(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    emit("s_branch L_g4_loop_%=")
+    emit("L_g4_nopf_%=:")
+    ktile_reg(emit, 1)
+    ktile_reg(emit, 0, loads=False)
+    ktile_reg(emit, 1, loads=False, writes=False, last=True)
+    emit("s_nop 15")  # the epilogue reads the accumulators next
+    emit("s_nop 15")
+    emit(f"s_cmp_lt_u32 s{S_SK + 2}, 2")
+    emit("s_cbranch_scc1 L_g4_end_%=")
+    for ln in gen_sk_store(f"s{S_SK}", f"s{S_SK + 1}", f"v{V_SK}"):
+        emit(ln)
+    emit("L_g4_end_%=:")
+    return L
 
 
 def gen():
@@ -250,13 +361,13 @@ def gen_sk_sum():
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "gemm_g4_body.inc"), "w") as f:
-        for ln in gen():
+        for ln in (gen_reg() if STAGE == "reg" else gen()):
             f.write('"' + ln + '\\n\\t"\n')
     for name, body in (("gemm_g4_sk_sum.inc", gen_sk_sum()),):
         with open(os.path.join(here, name), "w") as f:
             for ln in body:
                 f.write('"' + ln + '\\n\\t"\n')
-    clob = [f"v{r}" for r in range(0, 64)] + [f"v{VPFD}", f"v{VPFD + 1}"]
+    clob = [f"v{r}" for r in range(0, 64)] + ([f"v{r}" for r in range(VREG, VWR + 2)] if STAGE == "reg" else [f"v{VPFD}", f"v{VPFD + 1}"])
     with open(os.path.join(here, "gemm_g4_regs.h"), "w") as f:
         f.write("// generated by gen_gemm_g4.py: the physical registers the K loop of gemm_g4 owns, and its LDS size\n#pragma once\n")
         f.write(f"#define G4_PF {PF}\n#define G4_LDS_BYTES 131072\n")
