@@ -594,6 +594,14 @@ extern "C" __attribute__((visibility("default"))) int s2v_set_fused_q8(int on) {
 static int g_fused_qk = 1;
 extern "C" __attribute__((visibility("default"))) int s2v_set_fused_qk(int on) { g_fused_qk = on; return 0; }
 #endif
+// mx_out (fp8 engine, MFMA path): the attention kernel leaves its output as MX e4m3 in c->aq / c->hs for the out-projection instead of bf16 in Xn
+static bool attn_mx_out(const s2v_ctx* c) {
+    bool mx = c->fp8 && c->mfma && c->D % 128 == 0;
+#ifdef S2V_DIAG
+    mx = mx && g_fp8_mx;
+#endif
+    return mx;
+}
 static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = false) {
     // Xn -> QKV -> (qk-norm, rope, V^T) -> attention -> Xn (reused as the attention output buffer)
     const LayerW& w = c->layers[l];
@@ -636,6 +644,7 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     a.qkv = c->QKV; a.ld_qkv = 3 * D; a.vt = c->VT; a.ntok_pad = c->ntok_pad; a.out = c->Xn; a.ld_out = D;
     a.B = c->B; a.H = c->cfg.num_heads; a.Ntok = c->Ntok; a.scale = 0.125f;
     a.queue = c->attn_queue; a.num_cus = c->num_cus;  // launches of one context are ordered on its stream: one queue suffices
+    if (attn_mx_out(c)) { a.mx_q = (unsigned char*)c->aq; a.mx_s = c->hs; }
     ProfScope ps(c, PK_ATTN, st);
     if (c->mfma) S2V_TRY(launch_attn_bf16(a, st));
     else S2V_TRY(launch_attn_simple(a, c->dtype, st));
@@ -669,6 +678,7 @@ static int run_block(s2v_ctx* c, int l, const char* mod_base /* [B][mod_stride] 
         if (half == 0) {
             S2V_TRY(run_attention(c, l, st, prequant));
             g.A = c->Xn; g.lda = D; g.W = w.wo; g.ldw = D; g.bias = w.bo; g.K = D;
+            if (attn_mx_out(c)) { g.A = c->aq; g.mx_a_s = c->hs; }
             ProfScope ps(c, PK_OUT, st);
             if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS_GATE_RES, w.q_o, w.s_o, st));
             else S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
@@ -793,6 +803,7 @@ extern "C" int s2v_attn_forward(s2v_ctx* c, int32_t layer, const void* hidden, c
     const LayerW& w = c->layers[layer];
     GemmArgs g{};
     g.A = c->Xn; g.lda = D; g.W = w.wo; g.ldw = D; g.bias = w.bo; g.C = c->Hb; g.ldc = D; g.M = (int)c->M; g.N = D; g.K = D;
+    if (attn_mx_out(c)) { g.A = c->aq; g.mx_a_s = c->hs; }
     if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS, w.q_o, w.s_o, st));  // the same operands run_block feeds its out-projection
     else S2V_TRY(linear(c, g, EPI_BIAS, st));
     for (int b = 0; b < B; ++b) {

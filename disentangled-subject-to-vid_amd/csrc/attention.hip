@@ -546,6 +546,7 @@ int launch_attn_bf16(const AttnArgs& a_in, hipStream_t st) {
     if (v == 3 || v == 6 || v == 8 || v == 10 || v == 1 || v == 2) a.queue = nullptr;
     if (v == 8 || v == 9) return launch_attn_q8(a, v == 9, st);
     if (v == 1 || v == 2 || v == 5 || v == 10 || v == 11) {
+        S2V_REQUIRE(a.mx_q == nullptr, "attn_bf16: the MX output of the fp8 engine is attn_q4 / attn_q8's (reference variants write bf16 only)");
         const dim3 g8(total), b8(512);
         const void* fn = (v == 1) ? (const void*)attn_pp_k<true> : (const void*)attn_pp_k<false>;
         size_t lds = 65536;

@@ -167,13 +167,50 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
             og[g].x = pack2bf(OT[j][16 * db + rq * 4 + 0] * inv, OT[j][16 * db + rq * 4 + 1] * inv);
             og[g].y = pack2bf(OT[j][16 * db + rq * 4 + 2] * inv, OT[j][16 * db + rq * 4 + 3] * inv);
         }
-        bf16_t* o = (bf16_t*)a.out + (size_t)(b * a.Ntok + min(q_row[j], a.Ntok - 1)) * a.ld_out + h * 64 + hi * 8;
+        u32x4 vv[4];  // the lane's 8-column groups: columns 16 u + 8 hi .. + 7 of the head, u = 0 .. 3
 #pragma unroll
         for (int g = 0; g < 8; g += 2) {
             const auto rx = __builtin_amdgcn_permlane32_swap(og[g].x, og[g + 1].x, false, false);
             const auto ry = __builtin_amdgcn_permlane32_swap(og[g].y, og[g + 1].y, false, false);
-            u32x4 v = {rx[0], ry[0], rx[1], ry[1]};
-            if (q_row[j] < a.Ntok) *(u32x4*)(o + 8 * g) = v;
+            vv[g >> 1] = u32x4{rx[0], ry[0], rx[1], ry[1]};
+        }
+        const size_t orow = (size_t)(b * a.Ntok + min(q_row[j], a.Ntok - 1));
+        if (a.mx_q == nullptr) {
+            bf16_t* o = (bf16_t*)a.out + orow * a.ld_out + h * 64 + hi * 8;
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (q_row[j] < a.Ntok) *(u32x4*)(o + 16 * u) = vv[u];
+        } else {
+            // fp8 engine: the out-projection's A operand as MX e4m3 (GemmArgs::mx_a_s) -- a head is two 32-column blocks, each held by
+            // the row's two lanes (16 values each): block amax by v_pk_max_u16 + one cross-half exchange, scale = the smallest power
+            // of two with amax / scale <= 448, conversion by v_cvt_scalef32_pk_fp8_bf16 (as the FF1 epilogue, gemm_epi.h)
+            typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+            unsigned ebs = 0;
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                u16x2_t pm = {0, 0};
+#pragma unroll
+                for (int u = 2 * blk; u < 2 * blk + 2; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pm = __builtin_elementwise_max(pm, __builtin_bit_cast(u16x2_t, vv[u][e] & 0x7fff7fffu));
+                unsigned amb = max((unsigned)pm[0], (unsigned)pm[1]) << 16;
+                const auto sw = __builtin_amdgcn_permlane32_swap(amb, amb, false, false);
+                amb = max(sw[0], sw[1]);
+                unsigned eb = (__float_as_uint(__uint_as_float(amb) * (1.0f / 448.0f)) + 0x7fffffu) >> 23;
+                eb = min(max(eb, 1u), 254u);
+                ebs |= eb << (8 * blk);
+                const float bscale = __uint_as_float(eb << 23);
+#pragma unroll
+                for (int u = 2 * blk; u < 2 * blk + 2; ++u) {
+                    unsigned w0 = 0, w1 = 0;
+                    asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(w0) : "v"(vv[u][0]), "v"(bscale));
+                    asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(w0) : "v"(vv[u][1]), "v"(bscale));
+                    asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2" : "+v"(w1) : "v"(vv[u][2]), "v"(bscale));
+                    asm volatile("v_cvt_scalef32_pk_fp8_bf16 %0, %1, %2 op_sel:[0,0,1]" : "+v"(w1) : "v"(vv[u][3]), "v"(bscale));
+                    if (q_row[j] < a.Ntok) *(u32x2*)(a.mx_q + orow * a.ld_out + h * 64 + 16 * u + hi * 8) = u32x2{w0, w1};
+                }
+            }
+            if (hi == 0 && q_row[j] < a.Ntok) *(unsigned short*)(a.mx_s + orow * (a.ld_out >> 5) + h * 2) = (unsigned short)ebs;
         }
     }
 }

@@ -100,6 +100,9 @@ struct AttnArgs {
     // bf16 path, optional: nine zero-initialised ints owned by the caller (one set per concurrently running launch) and the CU count
     // -> the persistent, work-pulling launch (attention.hip: attn_pp_persist_k); null -> one workgroup per q-block
     int* queue; int num_cus;
+    // fp8 engine, attn_q4 only: write the output as MX e4m3 [B*Ntok][ld_out] bytes + block scales [B*Ntok][ld_out / 32] INSTEAD of the
+    // bf16 `out` (the out-projection reads it through GemmArgs::mx_a_s)
+    unsigned char* mx_q; unsigned char* mx_s;
 };
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st);
 int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st);

@@ -218,3 +218,44 @@ def test_op_ff_fp8_mx_hand_over_matches_emulation(s2v, M, D, F):
     assert rel(outs[0], emu_row) <= 6e-3, rel(outs[0], emu_row)
     assert rel(outs[1], full) <= 7e-2 and rel(outs[0], full) <= 7e-2   # two chained e4m3 GEMMs: 4e-2 each (test above) in quadrature
     assert rel(outs[1], full) <= 1.1 * rel(outs[0], full) + 1e-3, "block scales must not be worse than one scale per row"
+
+
+def test_fp8_mx_hand_overs_against_the_row_quantised_engine(s2v):
+    """the two MX hand-overs of the fp8 engine -- attention output -> out-projection (attention_q4.hip epilogue) and GELU(FF1) -> FF2
+    (gemm_epi.h) -- against the same engine with the per-row quantisation passes (diagnostics switch s2v_set_fp8_mx): both within the
+    fp8 tolerance of the bf16 engine, the block-scaled one not worse, the two close to each other; ragged token count (rows past Ntok
+    must not be written, the last 256-row item is partial)"""
+    import copy
+
+    L = s2v._lib
+    diag = L.diag_lib()
+    prev = L._lib
+    L.lib()
+    try:
+        L._lib = diag
+        cfg = s2v.tiny(use_rope=True, heads=4, layers=2, text_dim=128, temb=64)
+        cfg.max_text_seq_length = 7
+        sd = s2v.weights.synthetic_state_dict(cfg, seed=5, parity=True)
+        g = torch.Generator().manual_seed(19)
+        lat = torch.randn(1, 3, 16, 18, 22, generator=g).bfloat16()
+        text = torch.randn(2, 7, 128, generator=g).bfloat16()
+        ref = (torch.randn(1, 1, 16, 18, 22, generator=g) * 0.7).bfloat16()
+        y16 = _run_engine(s2v, copy.copy(cfg), sd, lat, text, ref, 300.0)[1].float()
+        cfg8 = copy.copy(cfg)
+        cfg8.weight_format = "fp8"
+        outs = {}
+        for mx in (1, 0):
+            diag.s2v_set_fp8_mx(mx)
+            outs[mx] = _run_engine(s2v, copy.copy(cfg8), sd, lat, text, ref, 300.0)[1].float()
+            assert torch.isfinite(outs[mx]).all()
+
+        def rel(a, b):
+            return ((a - b).norm() / b.norm()).item()
+
+        assert not torch.equal(outs[0], outs[1]), "the switch must change the arithmetic"
+        assert rel(outs[1], y16) <= 5e-2 and rel(outs[0], y16) <= 5e-2
+        assert rel(outs[1], y16) <= 1.15 * rel(outs[0], y16) + 1e-3
+        assert rel(outs[1], outs[0]) <= 5e-2
+    finally:
+        diag.s2v_set_fp8_mx(1)
+        L._lib = prev
