@@ -521,6 +521,11 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
             const int S = gemm_choose_splitk(tm * tn, g.K, ncu);
             if (S > 1 && (int64_t)S * tm * tn <= c->sk_tiles) { g.splitk = S; g.sk_ws = c->sk_ws; g.sk_cnt = c->sk_cnt; }
         }
+        // Few tiles (C1: M = 2500): half a round of 256 x 256 tiles or less and no split K (the out-projection: 80 tiles of 30 K-tiles)
+        // -> 256 x 128 tiles put twice the workgroups on the part: 36 us against 59 (tools/microbench.py gemm_c1, profiles/r03_c1_*).
+        // Measured and dropped: peeling the sparse second round of the FF1 (300 tiles on 256 CUs) off as 128 x 128 tiles -- 62 + 35 us
+        // against 100 for the two rounds on the same stream, slower (117) as a fork on the side stream.
+        if (g.splitk == 0 && epi != EPI_BIAS_QKNORM && g.tile == 0 && tm * tn * 2 <= ncu) g.tile = 1;
         const int rem = (int)(g.M % 256);
         if (rem > 0 && tm > 1 && g.N >= 256 && (tm * tn + ncu - 1) / ncu > ((tm - 1) * tn + ncu - 1) / ncu) {
             GemmArgs gm = g, gt = g;

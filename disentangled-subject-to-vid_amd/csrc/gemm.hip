@@ -1246,8 +1246,9 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     // One round of tiles (<= 256 CUs' worth) leaves the epilogue fully exposed, and the fused q/k-norm + rotary epilogue is the longest:
     // eight waves run it faster than four (C1 QKV, 230 tiles: 65 us on the ping-pong kernel, 72 us on gemm_g4)
     if (epi == EPI_BIAS_QKNORM && (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) <= 256) g4_epi = false;
-    if (g_gemm_impl == 9 && g4_epi && w_tile_ok(a) && gemm_g4_ok(a, epi)) return launch_gemm_g4(a, epi, st);  // four-wave generated-asm K loop
-    if ((g_gemm_impl == 7 || g_gemm_impl == 8 || g_gemm_impl == 9) && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
+    const bool big_tiles = a.tile == 0 || a.conv || epi == EPI_BIAS_QKNORM;  // GemmArgs::tile: the caller asks for smaller tiles
+    if (g_gemm_impl == 9 && big_tiles && g4_epi && w_tile_ok(a) && gemm_g4_ok(a, epi)) return launch_gemm_g4(a, epi, st);  // four-wave generated-asm K loop
+    if ((g_gemm_impl == 7 || g_gemm_impl == 8 || g_gemm_impl == 9) && big_tiles && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
             case EPI_BIAS: return launch_pp64_t<EPI_BIAS>(a, st);
@@ -1270,7 +1271,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
         }
     }
 #endif
-    if ((g_gemm_impl == 2 || g_gemm_impl >= 4) && (a.conv || a.a_rows_padded >= ((a.M + RBM - 1) / RBM) * RBM)) {
+    if ((g_gemm_impl == 2 || g_gemm_impl >= 4) && (a.tile != 2 || a.conv) && epi != EPI_BIAS_QKNORM && (a.conv || a.a_rows_padded >= ((a.M + RBM - 1) / RBM) * RBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
             case EPI_BIAS: return launch_stag_t<EPI_BIAS>(a, st);

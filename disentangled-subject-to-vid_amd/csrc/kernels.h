@@ -34,6 +34,8 @@ struct GemmArgs {
     int conv, cin, Hp, Wp, oH, oW, kt;
     int cstride;        // conv mode: spatial stride of the output grid (0 or 1 = dense; 2 = CogVideoXDownsample3D, downsampling.py:322-353)
     int gm;             // 256-row kernel: row tiles per group of the tile order (0: chosen by the launcher)
+    int tile;           // plain bf16 GEMMs: 0 = the launcher's choice (256 x 256 tiles where the shape fits them); 1 = 256 x 128 tiles, 2 = 128 x 128
+                        // (few-tile GEMMs: more, smaller workgroups fill the CUs that a single partial round of 256 x 256 tiles leaves idle)
     int ablate;         // diagnostics only
     int a_rows_padded;  // plain mode: rows physically present behind A (>= M); the 256-row kernel needs ceil256(M)
     int m_begin;        // first output row of this launch (row-tail launches of a split GEMM; 128-row kernel only)

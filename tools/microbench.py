@@ -55,6 +55,26 @@ def bench_gemm():
         del A, W, C
 
 
+def bench_gemm_c1():
+    """the four linears of a C1 block (2B, 9 x 256 x 256: M = 2500 rows, padded to 2560 here) on each tiling: which one fills 256 CUs best"""
+    M = 2560
+    for name, N, K, epi in (("qkv", 5760, 1920, 0), ("out", 1920, 1920, 0), ("ff1+gelu", 7680, 1920, 1), ("ff2", 1920, 7680, 0)):
+        A = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
+        W = (torch.randn(N, K, device=DEV) * 0.02).bfloat16()
+        b = torch.zeros(N, device=DEV, dtype=torch.bfloat16)
+        C = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        f = lambda: L.check(L.diag_lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, epi, 1, 0, L.stream_ptr()))
+        for impl in (0, 2, 7, 9):
+            if impl in (7, 9) and N % 256:
+                continue
+            L.diag_lib().s2v_set_gemm_impl(impl)
+            f()
+            torch.cuda.synchronize()
+            ms = timeit(f, iters=50, warm=10)
+            print(f"gemm_c1[{LABELS[impl]}] {name:9s} M={M} N={N} K={K}: {ms*1e3:8.1f} us  {2*M*N*K/ms/1e9:8.1f} TFLOP/s", flush=True)
+        L.diag_lib().s2v_set_gemm_impl(9)
+
+
 def bench_attn():
     for (B, H, N) in ((2, 48, 19126), (2, 30, 19126), (2, 30, 1250)):
         D = H * 64
@@ -74,6 +94,8 @@ def bench_attn():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["gemm", "attn"]
     print(torch.cuda.get_device_name(0), flush=True)
+    if "gemm_c1" in what:
+        bench_gemm_c1()
     if "gemm" in what:
         bench_gemm()
     if "attn" in what:
