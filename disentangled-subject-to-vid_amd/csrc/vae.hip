@@ -93,6 +93,32 @@ int launch_dense_to_padded(const void* in, int F, int H, int W, int C, void* out
     return 0;
 }
 
+// the zero ring of a padded operand [F][Hp][Wp][C] (the implicit-GEMM convolution's padding = 1): a new window size moves the ring into
+// what was interior, and only the ring has to be cleared -- every interior cell is rewritten by the operand's producer before a
+// convolution reads it.  (Clearing whole buffers on every change of the tile size cost the tiled decode 35-40 ms of memsets.)
+// Units of two bytes (U per cell) so that any channel count of either dtype is covered.
+__global__ void zero_border_k(unsigned short* pad, int F, int Hp, int Wp, int U) {
+    const int ring = 2 * Wp + 2 * (Hp - 2);
+    const int64_t total = (int64_t)F * ring * U;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int u = (int)(i % U);
+        const int r = (int)((i / U) % ring);
+        const int f = (int)(i / ((int64_t)U * ring));
+        int y, x;
+        if (r < Wp) { y = 0; x = r; }
+        else if (r < 2 * Wp) { y = Hp - 1; x = r - Wp; }
+        else { const int k = r - 2 * Wp; y = 1 + (k >> 1); x = (k & 1) ? Wp - 1 : 0; }
+        pad[(((int64_t)f * Hp + y) * Wp + x) * U + u] = 0;
+    }
+}
+int launch_zero_border(void* pad, int F, int H, int W, int C, int esz, hipStream_t st) {
+    const int Hp = H + 2, Wp = W + 2, U = C * esz / 2;
+    const int64_t total = (int64_t)F * (2 * Wp + 2 * (Hp - 2)) * U;
+    hipLaunchKernelGGL(zero_border_k, dim3(grid_for(total)), dim3(256), 0, st, (unsigned short*)pad, F, Hp, Wp, U);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // window (y0, x0, th, tw) of an image [C][F][H][W] -> zero-bordered channels-last operand [f_off + F][th+2][tw+2][C]
 template <typename T>
 __global__ void image_to_padded_k(const T* img, int C, int F, int H, int W, int y0, int x0, int th, int tw, T* out, int f_off) {

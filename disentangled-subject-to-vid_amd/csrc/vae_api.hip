@@ -412,13 +412,19 @@ static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws
     return 0;
 }
 
-static int set_layout(s2v_vae* v, int h, int w, hipStream_t st) {
+// A new window size: the zero ring of every padded operand moves.  Decoder (ring_only): only the ring of the new size is cleared
+// (launch_zero_border: interiors are rewritten by their producers before they are read; the buffers were zeroed when they were
+// allocated) -- with nine tiles of four sizes dealt to six workspace sets the whole-buffer memsets (20 GB per set) were 35-40 ms of a
+// 555 ms tiled decode.  The encoder's one-frame buffers are small and keep the plain memset.
+static int set_layout(s2v_vae* v, int h, int w, hipStream_t st, bool ring_only = false) {
     if (v->cur_h == h && v->cur_w == w) return 0;
     int rc = 0;
     for_each_conv(v, [&](ConvL& c) {
-        if (!rc && hipMemsetAsync(c.pad, 0, (size_t)c.pad_bytes, st) != hipSuccess) rc = -2;
+        if (rc) return;
+        if (ring_only) rc = launch_zero_border(c.pad, v->fmax[c.level] + (c.kt == 3 ? 2 : 0), h << c.level, w << c.level, c.cin, v->esz, st);
+        else if (hipMemsetAsync(c.pad, 0, (size_t)c.pad_bytes, st) != hipSuccess) rc = -2;
     });
-    if (rc) return vfail("memset failed");
+    if (rc) return vfail("clearing the operand borders failed");
     v->cur_h = h; v->cur_w = w;
     return 0;
 }
@@ -555,7 +561,7 @@ extern "C" int s2v_vae_out_shape(s2v_vae* v, int32_t F, int32_t h, int32_t w, in
 
 static int decode_window(s2v_vae* v, const char* lat, int F, int h, int w, int y0, int x0, int th, int tw, char* dst,
                          int Ftot, int scaled, hipStream_t st) {
-    S2V_TRY(set_layout(v, th, tw, st));
+    S2V_TRY(set_layout(v, th, tw, st, true));
     const float inv_sf = scaled ? (float)(1.0 / (double)v->cfg.scaling_factor) : 1.0f;
     int f0 = 0;
     bool first = true;

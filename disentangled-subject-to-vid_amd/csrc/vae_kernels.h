@@ -19,6 +19,7 @@ int launch_latent_to_zq(const void* lat, int F, int C, int h, int w, float inv_s
 int launch_image_to_padded(const void* img, int C, int F, int H, int W, int y0, int x0, int th, int tw, void* out, int f_off,
                            int dtype, hipStream_t st);
 int launch_gaussian_sample(const void* mom, const void* noise, int64_t n, void* out, int dtype, hipStream_t st);
+int launch_zero_border(void* pad, int F, int H, int W, int C, int esz, hipStream_t st);  // zero ring of a padded operand [F][H+2][W+2][C]
 int launch_dense_to_padded(const void* in, int F, int H, int W, int C, void* out, int f_off, int dtype, hipStream_t st);
 int64_t gn_stats_scratch_bytes(int64_t P, int G);
 int launch_gn_stats(const void* x, int64_t P, int C, int G, double* sums, double* part_scratch, int dtype, hipStream_t st);
