@@ -70,8 +70,8 @@ __global__ __launch_bounds__(256, 1) void gemm_g4(const GemmArgs a, int tiles_m,
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const unsigned inrow = (unsigned)(((s * 2 + hi) ^ ((fr >> 1) & 7)) << 4);
-            vaddr[4 * g + s] = lds0 + g * 65536 + (wm * 128 + fr) * 128 + inrow;
-            vaddr[8 + 4 * g + s] = lds0 + g * 65536 + 32768 + (wn * 128 + fr) * 128 + inrow;
+            vaddr[4 * g + s] = lds0 + g * G4_A_STRIDE + (wm * 128 + fr) * 128 + inrow;
+            vaddr[8 + 4 * g + s] = lds0 + G4_W_BASE + g * G4_W_STRIDE + (wn * 128 + fr) * 128 + inrow;
         }
     // staging: piece p (0..7) of an operand image = rows p * 32 + wave * 8 + (lane >> 3), 8 chunks of 16 B, chunk XOR on the SOURCE
     // address (the XOR term does not depend on p); global address = K-tile base (SGPR pair) + per-lane 32-bit offset
@@ -110,8 +110,8 @@ __global__ __launch_bounds__(256, 1) void gemm_g4(const GemmArgs a, int tiles_m,
     asm volatile(
 #include "gemm_g4_body.inc"
         : "=" G4_ACC0(AC[0]), "=" G4_ACC1(AC[1]), "=" G4_ACC2(AC[2]), "=" G4_ACC3(AC[3]), "=" G4_ACC4(AC[4]), "=" G4_ACC5(AC[5]),
-          "=" G4_ACC6(AC[6]), "=" G4_ACC7(AC[7]), "+" G4_PTR(ptr), "+" G4_SIN(sin)
-        : G4_VADDR(vaddr), G4_VOFF(voff), G4_VPF(vpf), G4_SK(sk), G4_VSK(voff16)
+          "=" G4_ACC6(AC[6]), "=" G4_ACC7(AC[7]), "+" G4_PTR(ptr), "+" G4_SIN(sin), "+" G4_VADDR(vaddr)
+        : G4_VOFF(voff), G4_VPF(vpf), G4_SK(sk), G4_VSK(voff16)
         : G4_CLOBBERS);
     G4_STAMP(2);
     __builtin_amdgcn_s_barrier();  // every wave is done with the stages: the epilogue patches alias them

@@ -56,6 +56,17 @@ S_A, S_W, S_M0W, S_CNT = 36, 38, 40, 41
 ABLATE = set(filter(None, os.environ.get("G4_ABLATE", "").split(",")))
 STAGE = os.environ.get("G4_STAGE", "dma")  # "dma": LDS-DMA pieces one K-tile ahead; "reg": global_load -> VGPR two K-tiles ahead, ds_write (below)
 VREG, VWR = 100, 228                       # "reg": two sets of 16 pieces x 4 VGPRs (v[100:227]); ds_write addresses of stage 0 / 1 (v228, v229)
+# G4_W3 = 1: THREE stages for the W operand (LDS: [A0 | A1 | W0 | W1 | W2] x 32 KiB = the whole 160 KiB).  The W pieces of K-tile t+2 are issued
+# in step 0 of K-tile t (stage (t+2) % 3, last read in step 2 of K-tile t-1) -- 1.75-2 K-tiles of lead where two stages give W 0.75-1 (A has
+# 1.25: its pieces follow the barrier of step 3).  The code stays unrolled by two (A parity); the W stage is run-time state: s42 / s43 = LDS
+# offset of the W stage K-tile t+1 reads / K-tile t's DMA writes, and the four W fragment addresses of K-tile t+1 (register set (t+1) & 1)
+# are rebuilt in step 1 of K-tile t from the stage-0 addresses (v[100:103]).  The step-3 wait becomes vmcnt(8): the W pieces issued in
+# this K-tile may stay in flight.  Built, bit-identical to the two-stage loop, and measured LEVEL with it on the same box (profiles/r03_gemm_g4_w3.txt:
+# QKV 2152 vs 2155 cycles per K-tile, out 2282 vs 2286, FF1 2188 vs 2203, FF2 2459 vs 2459): the W lead is not what the loop waits for.
+# Kept as an option (default off: the body is byte-identical to the round's product loop).
+W3 = os.environ.get("G4_W3", "0") == "1"
+S_WNEXT, S_WDMA, S_WM0, WBASE = 42, 43, 48, 100
+A_STRIDE, W_BASE, W_STRIDE = (32768, 65536, 32768) if W3 else (65536, 32768, 65536)
 PF = int(os.environ.get("G4_PF", "0"))  # K-tiles between the L2 prefetch of a tile and its staging (0: none -- the default, see above); even
 
 
@@ -83,10 +94,12 @@ def ktile(emit, g, first=False, dma_w=True, dma_a=True, last=False, prefetch=Fal
     for s in range(4):
         cur, nxt = s & 1, (s & 1) ^ 1
         if s == 3 and not last:
-            emit(f"s_waitcnt vmcnt({2 if (prefetch and PF) else 0}) lgkmcnt(0)")
+            emit(f"s_waitcnt vmcnt({8 if (W3 and dma_w) else 2 if (prefetch and PF) else 0}) lgkmcnt(0)")
             emit("s_barrier")
         else:
             emit("s_waitcnt lgkmcnt(0)")
+        if W3 and s == 0 and dma_w:
+            emit(f"s_add_u32 s{S_WM0}, s{S_M0W}, s{S_WDMA}")
         for k in range(16):
             i, j = k >> 2, k & 3
             acc = ar(ACC + 64 * i + 16 * j, 16)
@@ -99,14 +112,19 @@ def ktile(emit, g, first=False, dma_w=True, dma_a=True, last=False, prefetch=Fal
                 else:
                     emit(f"ds_read_b128 {vr(af(nxt, k - 4), 4)}, {vr(vaddr(False, gs, ss))} offset:{(k - 4) * 4096}")
             p = k >> 1
-            if s == 0 and dma_w:  # W piece p of K-tile t+1 -> stage g^1
+            if s == 0 and dma_w:  # W piece p of K-tile t+1 -> stage g^1 (W3: of K-tile t+2 -> stage (t+2) % 3)
                 if k & 1 == 0:
-                    emit(f"s_add_u32 m0, s{S_M0W}, {(g ^ 1) * 65536 + 32768 + p * 4096}")
+                    if W3:
+                        emit(f"s_add_u32 m0, s{S_WM0}, {W_BASE + p * 4096}")
+                    else:
+                        emit(f"s_add_u32 m0, s{S_M0W}, {(g ^ 1) * 65536 + 32768 + p * 4096}")
                 else:
                     emit(f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]")
+            if W3 and s == 1 and not last and k >= 12:  # W fragment addresses of K-tile t+1 (set g^1, idle since step 3 of K-tile t-1)
+                emit(f"v_add_u32 {vr(vaddr(True, g ^ 1, k - 12))}, s{S_WNEXT}, {vr(WBASE + k - 12)}")
             if s == 3 and dma_a:  # A piece p of K-tile t+2 -> stage g
                 if k & 1 == 0:
-                    emit(f"s_add_u32 m0, s{S_M0W}, {g * 65536 + p * 4096}")
+                    emit(f"s_add_u32 m0, s{S_M0W}, {g * A_STRIDE + p * 4096}")
                 else:
                     emit(f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]")
             if s == 1 and prefetch and PF:  # the A pointer is at K-tile t+2, the W pointer (advanced in step 0) too
@@ -117,6 +135,11 @@ def ktile(emit, g, first=False, dma_w=True, dma_a=True, last=False, prefetch=Fal
         if s == 0 and dma_w:
             emit(f"s_add_u32 s{S_W}, s{S_W}, 128")
             emit(f"s_addc_u32 s{S_W + 1}, s{S_W + 1}, 0")
+        if W3 and s == 1 and not last:  # rotate the W stages: K-tile t+2 reads what this K-tile's DMA wrote
+            emit(f"s_mov_b32 s{S_WNEXT}, s{S_WDMA}")
+            emit(f"s_add_u32 s{S_WDMA}, s{S_WDMA}, {W_STRIDE}")
+            emit(f"s_cmp_ge_u32 s{S_WDMA}, {3 * W_STRIDE}")
+            emit(f"s_cselect_b32 s{S_WDMA}, 0, s{S_WDMA}")
         if s == 3 and dma_a:
             emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
             emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
@@ -244,7 +267,7 @@ def gen():
         emit("s_nop 0")
         emit(f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]")
     for p in range(8):
-        emit(f"s_add_u32 m0, s{S_M0W}, {32768 + p * 4096}")
+        emit(f"s_add_u32 m0, s{S_M0W}, {W_BASE + p * 4096}")
         emit("s_nop 0")
         emit(f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]")
     emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
@@ -252,15 +275,27 @@ def gen():
     emit(f"s_add_u32 s{S_W}, s{S_W}, 128")
     emit(f"s_addc_u32 s{S_W + 1}, s{S_W + 1}, 0")
     for p in range(8):
-        emit(f"s_add_u32 m0, s{S_M0W}, {65536 + p * 4096}")
+        emit(f"s_add_u32 m0, s{S_M0W}, {A_STRIDE + p * 4096}")
         emit("s_nop 0")
         emit(f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]")
     emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
     emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
+    if W3:  # K-tile 1's W half too (stage 1); K-tile 2's follows in step 0 of K-tile 0 (stage 2)
+        assert PF == 0
+        for p in range(8):
+            emit(f"s_add_u32 m0, s{S_M0W}, {W_BASE + W_STRIDE + p * 4096}")
+            emit("s_nop 0")
+            emit(f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]")
+        emit(f"s_add_u32 s{S_W}, s{S_W}, 128")
+        emit(f"s_addc_u32 s{S_W + 1}, s{S_W + 1}, 0")
+        emit(f"s_mov_b32 s{S_WNEXT}, {W_STRIDE}")
+        emit(f"s_mov_b32 s{S_WDMA}, {2 * W_STRIDE}")
+        for x in range(4):
+            emit(f"v_mov_b32 {vr(WBASE + x)}, {vr(vaddr(True, 0, x))}")
     for k in range(2, PF):  # the lines of K-tiles 2 .. PF-1 (pointer + (k - 2) * 128: the A pointer is at K-tile 2, the W pointer at 1)
         emit(f"global_load_dword {vr(VPFD)}, {vr(VPF)}, s[{S_A}:{S_A + 1}] offset:{(k - 2) * 128}")
         emit(f"global_load_dword {vr(VPFD + 1)}, {vr(VPF + 1)}, s[{S_W}:{S_W + 1}] offset:{(k - 1) * 128}")
-    emit(f"s_waitcnt vmcnt({8 + 2 * max(0, PF - 2)})")  # K-tile 0 landed; the A half of K-tile 1 (and the prefetches) stay in flight
+    emit(f"s_waitcnt vmcnt({16 if W3 else 8 + 2 * max(0, PF - 2)})")  # K-tile 0 landed; the A half of K-tile 1 (and the prefetches) stay in flight (W3: all of K-tile 1)
     emit("s_barrier")
     for n in range(8):  # fragments of step 0 of K-tile 0
         if n < 4:
@@ -283,7 +318,7 @@ def gen():
         ktile(emit, 1)
         ktile(emit, 0)
     ktile(emit, 1)                            # K-tile nT-3: the last one that stages both halves
-    ktile(emit, 0, dma_a=False)               # K-tile nT-2: still stages the W half of K-tile nT-1
+    ktile(emit, 0, dma_a=False, dma_w=not W3) # K-tile nT-2: still stages the W half of K-tile nT-1 (W3: that went out with K-tile nT-3)
     ktile(emit, 1, dma_w=False, dma_a=False, last=True)
     emit("s_waitcnt vmcnt(0)")
     emit("s_nop 15")  # the epilogue reads the accumulators next
@@ -368,9 +403,12 @@ def main():
             for ln in body:
                 f.write('"' + ln + '\\n\\t"\n')
     clob = [f"v{r}" for r in range(0, 64)] + ([f"v{r}" for r in range(VREG, VWR + 2)] if STAGE == "reg" else [f"v{VPFD}", f"v{VPFD + 1}"])
+    if W3:
+        clob += [f"v{WBASE + x}" for x in range(4)] + [f"s{S_WNEXT}", f"s{S_WDMA}", f"s{S_WM0}"]
     with open(os.path.join(here, "gemm_g4_regs.h"), "w") as f:
         f.write("// generated by gen_gemm_g4.py: the physical registers the K loop of gemm_g4 owns, and its LDS size\n#pragma once\n")
-        f.write(f"#define G4_PF {PF}\n#define G4_LDS_BYTES 131072\n")
+        f.write(f"#define G4_PF {PF}\n#define G4_LDS_BYTES {163840 if W3 else 131072}\n")
+        f.write(f"#define G4_A_STRIDE {A_STRIDE}\n#define G4_W_BASE {W_BASE}\n#define G4_W_STRIDE {W_STRIDE}  // LDS map of the operand stages: A stage g at g * A_STRIDE, W stage h at W_BASE + h * W_STRIDE\n")
         for k in range(8):
             f.write(f'#define G4_ACC{k} "{{a[{32 * k}:{32 * k + 31}]}}"\n')
         f.write(f'#define G4_VADDR "{{v[{VADDR}:{VADDR + 15}]}}"\n#define G4_VOFF "{{v[{VOFF}:{VOFF + 15}]}}"\n#define G4_VPF "{{v[{VPF}:{VPF + 1}]}}"\n')

@@ -446,9 +446,12 @@ static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int e
     g.w_rows_padded = (int)rup64(c.cout, 256);
     if (v->mfma && c.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, epi, st));  // cout = 3 (conv_out) runs one padded 128-column tile
     else S2V_TRY(launch_gemm_simple(g, epi, v->dtype, st));
-    if (c.kt == 3) {
-        S2V_CHECK_HIP(hipMemcpyAsync(c.pad, c.pad + (int64_t)F * fb, fb, hipMemcpyDeviceToDevice, st));
-        S2V_CHECK_HIP(hipMemcpyAsync(c.pad + fb, c.pad + (int64_t)(F + 1) * fb, fb, hipMemcpyDeviceToDevice, st));
+    if (c.kt == 3) {  // conv cache: the last two frames of the operand become frames 0, 1 of the next batch (adjacent on both sides: one copy unless they overlap)
+        if (F >= 2) S2V_CHECK_HIP(hipMemcpyAsync(c.pad, c.pad + (int64_t)F * fb, 2 * fb, hipMemcpyDeviceToDevice, st));
+        else {
+            S2V_CHECK_HIP(hipMemcpyAsync(c.pad, c.pad + (int64_t)F * fb, fb, hipMemcpyDeviceToDevice, st));
+            S2V_CHECK_HIP(hipMemcpyAsync(c.pad + fb, c.pad + (int64_t)(F + 1) * fb, fb, hipMemcpyDeviceToDevice, st));
+        }
     }
     return 0;
 }
