@@ -116,11 +116,12 @@ def bench_vae():
         torch.cuda.synchronize()
         t0 = time.time()
         y = vae.decode_latents(lat)
+        t_enq = time.time() - t0  # host time to enqueue the decode (launch-bound if close to the total)
         torch.cuda.synchronize()
         dt = time.time() - t0
         fl = 441.04e12 if tiling else 315.03e12
         print(f"vae decode 13x60x90 -> {tuple(y.shape)} tiling={tiling}: {dt*1e3:8.1f} ms  {fl/dt/1e12:7.1f} TFLOP/s  "
-              f"finite={bool(torch.isfinite(y.float()).all())} mem={torch.cuda.mem_get_info()[0]/2**30:.0f} GiB free", flush=True)
+              f"enqueue={t_enq*1e3:.0f} ms finite={bool(torch.isfinite(y.float()).all())} mem={torch.cuda.mem_get_info()[0]/2**30:.0f} GiB free", flush=True)
 
 
 if "vae" in sys.argv[1:]:
