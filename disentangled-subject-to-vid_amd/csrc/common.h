@@ -54,6 +54,9 @@ __device__ __forceinline__ float wave_max(float v) {
 template <typename T> struct Vec16;
 template <> struct Vec16<float> {
     static constexpr int N = 4;
+    typedef f32x4 raw_t;  // the 16 bytes as loaded; dec() turns them into N floats (loads issued early, decoded at their use)
+    static __device__ __forceinline__ raw_t ldraw(const float* p) { return *(const f32x4*)p; }
+    static __device__ __forceinline__ void dec(const raw_t& t, float* v) { v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
     static __device__ __forceinline__ void ld(const float* p, float* v) {
         f32x4 t = *(const f32x4*)p;
         v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
@@ -62,6 +65,15 @@ template <> struct Vec16<float> {
 };
 template <> struct Vec16<bf16_t> {
     static constexpr int N = 8;
+    typedef u32x4 raw_t;
+    static __device__ __forceinline__ raw_t ldraw(const bf16_t* p) { return *(const u32x4*)p; }
+    static __device__ __forceinline__ void dec(const raw_t& t, float* v) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(t[i] << 16);
+            v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+        }
+    }
     static __device__ __forceinline__ void ld(const bf16_t* p, float* v) {
         u32x4 t = *(const u32x4*)p;
 #pragma unroll
