@@ -24,7 +24,17 @@
 #define KV_TILE 64
 #define Q_BLOCK 128
 #define ATT_TILE_BYTES (64 * 64 * 2)  // 8 KiB
+#ifndef ATTN_PP_MAX_TOKENS
+#define ATTN_PP_MAX_TOKENS 4608  // launch_attn_bf16: sequences up to this length run attn_pp, longer ones attn_q4 (profiles/r03_attn_short_sequences.txt:
+                                 // attn_pp 9 % ahead at 4000 tokens, attn_q4 2 % ahead at 6000, 6 % at 19126)
+#endif
 
+// v_max3_f32 written out so that the max tree keeps the order it is given (the scores are never NaN: no canonicalisation)
+__device__ __forceinline__ float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 #ifdef S2V_DIAG  // ---- A/B reference kernels (diagnostics library only) ----
 template <int NT>
 __device__ __forceinline__ void stage64(const bf16_t* __restrict__ g, size_t ld, char* lds, int tid) {
@@ -49,12 +59,6 @@ __device__ __forceinline__ void stage_kv(const bf16_t* __restrict__ kg, size_t l
                                          char* lds, int tid) {
     stage64<NW * 64>(kg, ldk, lds, tid);
     stage64<NW * 64>(vg, ldv, lds + ATT_TILE_BYTES, tid);
-}
-// v_max3_f32 written out so that the max tree keeps the order it is given (the scores are never NaN: no canonicalisation)
-__device__ __forceinline__ float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
 }
 __device__ __forceinline__ bf16x8 frag64(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + row * 128 + ((cl ^ ((row >> 1) & 7)) << 4));
@@ -236,10 +240,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
 // MFMAs (+3 %) or in S (+4 %), dedicated loader waves (three waves per SIMD force 168 registers and drop the fragment
 // prefetch: +2 %), bounded scores with no maximum at all and the row sums on the matrix pipe (20 MFMA per tile: -1.5 %, not
 // worth its precondition).
+#endif  // S2V_DIAG (attn_pp below is product code again: the short-sequence kernel, see launch_attn_bf16)
 __device__ long long g_attn_dbg[64];  // ACCT: per-wave s_memtime totals of block 100
 __device__ long long g_attn_blk[2 * 8192];  // ACCT: s_memrealtime at entry / exit of every workgroup (timeline of a launch)
+#ifdef S2V_DIAG
 extern "C" __attribute__((visibility("default"))) int s2v_attn_debug_read_blocks(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_blk), sizeof(long long) * 2 * 8192) == hipSuccess ? 0 : -1; }
 extern "C" __attribute__((visibility("default"))) int s2v_attn_debug_read(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_attn_dbg), sizeof(long long) * 64) == hipSuccess ? 0 : -1; }
+#endif
 // one work item = the 256 query rows (wg % nqb) of (sample, head) wg / nqb; all eight waves enter and leave it together
 template <bool ACCT>
 __device__ __forceinline__ void attn_pp_item(const AttnArgs& a, int nqb, int wg, char* smem) {
@@ -519,9 +526,6 @@ __global__ __launch_bounds__(512, 2) void attn_pp_persist_k(const AttnArgs a, in
     }
 }
 
-
-#endif  // S2V_DIAG
-
 #ifdef S2V_DIAG
 int g_attn_variant = 0;  // see launch_attn_bf16
 extern "C" __attribute__((visibility("default"))) int s2v_set_attn_variant(int v) { g_attn_variant = v; return 0; }
@@ -539,12 +543,14 @@ int launch_attn_bf16(const AttnArgs& a_in, hipStream_t st) {
     const int total = nqb8 * a.B * a.H;
 #ifdef S2V_DIAG
     // variants: 0 = product (attn_q4; persistent when the caller brought a queue), 3 = product, one workgroup per item,
-    //   4 = product, persistent on the harness queue, 6 / 7 = attn_q4 per item / persistent, 8 / 9 = attn_q8 (the same stream, eight
+    //   4 = product, persistent on the harness queue (0 / 3 / 4: attn_pp up to ATTN_PP_MAX_TOKENS, attn_q4 beyond), 6 / 7 = attn_q4 per item /
+    //   persistent at any length, 8 / 9 = attn_q8 (the same stream, eight
     //   waves x 32 rows), 10 / 11 = attn_pp (round-2 kernel) per item / persistent, 1 / 5 = attn_pp with stall accounting, 2 = round-1 kernel
     const int v = g_attn_variant;
     if ((v == 4 || v == 5 || v == 7 || v == 9 || v == 11) && !a.queue) { a.queue = g_attn_queue; a.num_cus = g_attn_ncu; }
     if (v == 3 || v == 6 || v == 8 || v == 10 || v == 1 || v == 2) a.queue = nullptr;
     if (v == 8 || v == 9) return launch_attn_q8(a, v == 9, st);
+    if (v == 6 || v == 7) return launch_attn_q4(a, v == 7 && a.queue != nullptr, st);  // attn_q4 whatever the sequence length
     if (v == 1 || v == 2 || v == 5 || v == 10 || v == 11) {
         S2V_REQUIRE(a.mx_q == nullptr, "attn_bf16: the MX output of the fp8 engine is attn_q4 / attn_q8's (reference variants write bf16 only)");
         const dim3 g8(total), b8(512);
@@ -567,6 +573,23 @@ int launch_attn_bf16(const AttnArgs& a_in, hipStream_t st) {
 #endif
     // persistent (work-pulling) launch when the caller owns a queue and there is more than two rounds of work; else one workgroup per item
     const bool persist = a.queue != nullptr && total > 2 * a.num_cus && a.num_cus >= 8;
+    // Short sequences run the eight-wave ping-pong kernel (attn_pp, round 2's product kernel): attn_q4's one-statement body pays a long
+    // prologue (first-tile maxima, fragment pipeline fill) and walks its last five KV tiles through the rare-path handler, which is
+    // nothing at 299 tiles (C3: attn_q4 5-6 % ahead) and a quarter of the iterations at 20 (C1: 47.5 -> 37 us per layer, DESIGN section 3;
+    // tools/attn_small_probe.py).  Same deferred-maximum rule (2^64), results within bf16 rounding of attn_q4's, not bit-identical.
+    if (a.mx_q == nullptr && a.Ntok <= ATTN_PP_MAX_TOKENS) {
+        const void* fn = persist ? (const void*)attn_pp_persist_k<false> : (const void*)attn_pp_k<false>;
+        S2V_TRY(ensure_lds_attr(fn, 65536));
+        if (persist) {
+            int* queue = a.queue;
+            void* args[] = {(void*)&a, (void*)&nqb8, (void*)&total, (void*)&queue};
+            S2V_CHECK_HIP(hipLaunchKernel(fn, dim3((a.num_cus / 8) * 8), dim3(512), args, 65536, st));
+        } else {
+            void* args[] = {(void*)&a, (void*)&nqb8};
+            S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(total), dim3(512), args, 65536, st));
+        }
+        return 0;
+    }
     return launch_attn_q4(a, persist, st);
 }
 

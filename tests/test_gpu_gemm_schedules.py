@@ -153,6 +153,40 @@ def test_persistent_attention_launch_is_bit_identical_to_one_workgroup_per_q_blo
         L._lib = prev
 
 
+@pytest.mark.parametrize("B,H,N", [(2, 30, 1250), (1, 3, 130), (2, 2, 700), (1, 1, 64), (1, 2, 4608), (1, 2, 4700)])
+def test_attention_kernel_choice_by_sequence_length(s2v, B, H, N):
+    """launch_attn_bf16 runs the eight-wave ping-pong kernel (attn_pp) up to 4608 tokens and the four-wave attn_q4 beyond (attention.hip;
+    both replace F.scaled_dot_product_attention, attention_processor.py:2083-2087).  Both kernels are held against fp64 SDPA on the same
+    bf16 inputs at every length -- the product no longer reaches attn_q4's short-sequence paths (all tiles in its last-five-tiles phase),
+    the diagnostics switch does -- and against each other within bf16 rounding."""
+    L = s2v._lib
+    diag = L.diag_lib()
+    D = H * 64
+    g = torch.Generator(device=DEV).manual_seed(N)
+    qkv = torch.randn(B * N + 64, 3 * D, generator=g, device=DEV).bfloat16()
+    qkv[5, D : D + 64] *= 6.0  # a spiked key row
+    vt = torch.zeros(B * H * 64 * ((N + 63) // 64 * 64), dtype=torch.bfloat16, device=DEV)
+    outs = {}
+    try:
+        for variant in (6, 10, 0):  # attn_q4, attn_pp, the product's choice
+            diag.s2v_set_attn_variant(variant)
+            out = torch.full((B * N, D), float("nan"), device=DEV, dtype=torch.bfloat16)
+            L.check(diag.s2v_op_attention(L.ptr(qkv), L.ptr(vt), L.ptr(out), B, H, N, 1, 0, L.stream_ptr()))
+            torch.cuda.synchronize()
+            outs[variant] = out
+    finally:
+        diag.s2v_set_attn_variant(0)
+    assert torch.equal(outs[0], outs[10] if N <= 4608 else outs[6]), "the product did not pick the kernel its rule names"
+    q, k, v = (qkv[: B * N, i * D : (i + 1) * D].reshape(B, N, H, 64).transpose(1, 2).double().cpu() for i in range(3))
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * N, D)
+    scale = max(1.0, ref.abs().max().item())
+    for variant in (6, 10):
+        got = outs[variant].double().cpu()
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() <= 2e-2 * scale, (variant, (got - ref).abs().max().item())  # test_op_attention's tolerance
+    assert (outs[6].double() - outs[10].double()).abs().max().item() <= 1.6e-2 * scale
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(512, 512, 7680, 0), (256, 1024, 4096, 1), (1024, 256, 3072, 0)])
 def test_split_k_few_tile_gemm(s2v, M, N, K, epi):
     """gemm_g4 with K split over S workgroups per tile (api.hip linear() / choose_splitk: the FF2 of the short-sequence geometries,
