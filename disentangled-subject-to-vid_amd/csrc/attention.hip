@@ -575,7 +575,7 @@ int launch_attn_bf16(const AttnArgs& a_in, hipStream_t st) {
     const bool persist = a.queue != nullptr && total > 2 * a.num_cus && a.num_cus >= 8;
     // Short sequences run the eight-wave ping-pong kernel (attn_pp, round 2's product kernel): attn_q4's one-statement body pays a long
     // prologue (first-tile maxima, fragment pipeline fill) and walks its last five KV tiles through the rare-path handler, which is
-    // nothing at 299 tiles (C3: attn_q4 5-6 % ahead) and a quarter of the iterations at 20 (C1: 47.5 -> 37 us per layer, DESIGN section 3;
+    // nothing at 299 tiles (C3: attn_q4 5-6 % ahead) and a quarter of the iterations at 20 (C1 step 12.01 -> 11.27 ms on one box, DESIGN section 3;
     // tools/attn_small_probe.py).  Same deferred-maximum rule (2^64), results within bf16 rounding of attn_q4's, not bit-identical.
     if (a.mx_q == nullptr && a.Ntok <= ATTN_PP_MAX_TOKENS) {
         const void* fn = persist ? (const void*)attn_pp_persist_k<false> : (const void*)attn_pp_k<false>;
