@@ -1246,6 +1246,10 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     // One round of tiles (<= 256 CUs' worth) leaves the epilogue fully exposed, and the fused q/k-norm + rotary epilogue is the longest:
     // eight waves run it faster than four (C1 QKV, 230 tiles: 65 us on the ping-pong kernel, 72 us on gemm_g4)
     if (epi == EPI_BIAS_QKNORM && (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) <= 256) g4_epi = false;
+    // the bias + GELU epilogue is the next longest: up to two rounds of tiles with a short reduction (C1 FF1: 300 tiles of 30 K-tiles) also run
+    // faster on eight waves -- same-box A/B of the C1 step, 11.50 -> 11.12 ms (tools/c1_attn_kernel_probe.py, S2V_G4_EPI_MASK); same epilogue
+    // code, bit-identical results
+    if (epi == EPI_BIAS_GELU && a.splitk <= 1 && a.K <= 2048 && (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) <= 512) g4_epi = false;
     const bool big_tiles = a.tile == 0 || a.conv || epi == EPI_BIAS_QKNORM;  // GemmArgs::tile: the caller asks for smaller tiles
     if (g_gemm_impl == 9 && big_tiles && g4_epi && w_tile_ok(a) && gemm_g4_ok(a, epi)) return launch_gemm_g4(a, epi, st);  // four-wave generated-asm K loop
     if ((g_gemm_impl == 7 || g_gemm_impl == 8 || g_gemm_impl == 9) && big_tiles && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {

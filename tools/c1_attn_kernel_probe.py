@@ -34,3 +34,16 @@ for variant in (6, 0, 6, 0):
     torch.cuda.synchronize()
     print(f"attention variant {variant} ({'attn_q4' if variant == 6 else 'product: attn_pp'}): {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step (eager)", flush=True)
 diag.s2v_set_attn_variant(0)
+# the FF1 (bias + GELU epilogue, 300 tiles of 30 K-tiles) on gemm_g4 (mask 31) against the eight-wave gemm_bf16_pp64 (mask 29: g4 for every epilogue but GELU)
+for mask in ("31", "29", "31", "29"):
+    os.environ["S2V_G4_EPI_MASK"] = mask
+    lat = lat0.clone()
+    for i in range(5):
+        eng.denoise_step(lat, float(sch.timesteps[i]), coefs[i], use_graph=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 40
+    for i in range(n):
+        eng.denoise_step(lat, float(sch.timesteps[(5 + i) % 50]), coefs[(5 + i) % 50], use_graph=False)
+    torch.cuda.synchronize()
+    print(f"S2V_G4_EPI_MASK={mask}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step (eager)", flush=True)
