@@ -1,8 +1,13 @@
 """Benchmark of the denoise hot path on MI355X.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N --steps K --warmup W          (no wrapper: spawns its own N ranks, one per GPU, backend nccl = RCCL)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W             (the driver's form: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env)
+
+--gpus N is a CLAIM the run has to earn: with no torchrun environment the script launches N rank processes itself and refuses
+(non-zero exit) when fewer than N GPUs are visible; with a torchrun environment WORLD_SIZE must equal N.  `value` is computed from
+what the ranks report (sum of their timed steps / max elapsed over ranks), never from the flag.
 
 One "step" = one iteration of the denoise loop of src/custom_cogvideox_pipe.py:241-296 on one video: the B=2 (CFG pair)
 transformer forward + fp32 CFG + DDIM scheduler step + round to bf16, all inside libs2v_hip.so, inputs resident in
@@ -182,18 +187,28 @@ KERNEL_OF_CLASS = {"attention": "attn_qx_persist_k<2>", "gemm_qkv": "gemm_g4<4>"
                    "gemm_out": "gemm_g4<2>", "gemm_ff2": "gemm_g4<2>"}  # <4>: QKV with the fused q/k norm + rotary epilogue
 
 
-def pmc_traffic_bytes(kernel_class):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_pmc_*.csv:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  FETCH_SIZE is doubled: on gfx950 it reports
-    half the bytes of a wide coalesced stream (MI355X_MICROARCH.md, HBM section).  None when no profile is present."""
+# which committed rocprofv3 PMC passes belong to which workload (profiles/README.md): rNN_ = the default workload,
+# rNNfp8_ = the fp8 engine at the same geometry, rNN_c1_ = the C1 geometry; the other workloads have no PMC pass
+PMC_PREFIX = {"cogvideox-5b-49x480x720": r"r\d+_pmc", "cogvideox-5b-fp8-49x480x720": r"r\d+fp8_pmc", "cogvideox-2b-9x256x256": r"r\d+_c1_pmc"}
+
+
+def pmc_traffic_bytes(kernel_class, workload):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes OF THIS WORKLOAD (separate
+    --pmc FETCH_SIZE / WRITE_SIZE runs of this same command).  FETCH_SIZE is doubled: on gfx950 it reports half the bytes of a
+    wide coalesced stream (MI355X_MICROARCH.md, HBM section).  Returns (bytes or None, [file names])."""
     import csv
-    import glob
+    import re
 
     name = KERNEL_OF_CLASS.get(kernel_class)
-    fetch = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_fetch.csv")))
-    write = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_write.csv")))
-    if not name or not fetch or not write:
-        return None
+    pat = PMC_PREFIX.get(workload)
+    if not name or not pat:
+        return None, []
+    pdir = os.path.join(ROOT, "profiles")
+    have = sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []
+    fetch = [f for f in have if re.fullmatch(pat + "_fetch\\.csv", f)]
+    write = [f for f in have if re.fullmatch(pat + "_write\\.csv", f)]
+    if not fetch or not write:
+        return None, []
 
     def mean_kb(path):
         tot = cnt = 0.0
@@ -204,13 +219,64 @@ def pmc_traffic_bytes(kernel_class):
                 cnt += float(row[1])
         return tot / cnt if cnt else None
 
-    f, w = mean_kb(fetch[-1]), mean_kb(write[-1])
+    f, w = mean_kb(os.path.join(pdir, fetch[-1])), mean_kb(os.path.join(pdir, write[-1]))
     if f is None or w is None:
-        return None
-    return int((2.0 * f + w) * 1024)
+        return None, [fetch[-1], write[-1]]
+    return int((2.0 * f + w) * 1024), [fetch[-1], write[-1]]
 
 
-def main():
+def free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` with no torchrun environment: launch the N rank processes here, one per GPU (LOCAL_RANK = RANK = i),
+    rendezvous on 127.0.0.1, backend nccl (= RCCL).  Refuses when fewer than N GPUs are visible -- S2V_BENCH_ONE_DEVICE=1 (all ranks
+    on cuda:0; RCCL rejects two ranks on one device, so it needs S2V_BENCH_BACKEND=gloo) is a functional check of the rank logic on
+    a one-GPU box and its line reports the devices actually used.  Returns the exit code (non-zero if any rank failed)."""
+    import subprocess
+
+    one_dev = os.environ.get("S2V_BENCH_ONE_DEVICE", "0") == "1"
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev < 1:
+        raise SystemExit(f"bench.py --gpus {n}: no GPU visible (torch.cuda.is_available() is False); nothing is printed for GPUs that do not exist")
+    if ndev < n and not one_dev:
+        raise SystemExit(f"bench.py --gpus {n}: only {ndev} GPU(s) visible; refusing to report n_gpus={n} "
+                         f"(S2V_BENCH_ONE_DEVICE=1 S2V_BENCH_BACKEND=gloo runs the {n} ranks on cuda:0 as a functional check)")
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), S2V_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:  # a dead rank leaves the others in a collective: end them (exact PIDs)
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -221,7 +287,17 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the one-off VAE decode timing")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        rc = spawn_ranks(args.gpus, argv)
+        if rc != 0:
+            raise SystemExit(rc if isinstance(rc, int) and rc > 0 else 1)
+        return
+    if env_world is not None and int(env_world) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}: the line reports the ranks that exist, not the flag")
 
     s2v = importlib.import_module("disentangled-subject-to-vid_amd")
     # S2V_BENCH_BACKEND=gloo + S2V_BENCH_ONE_DEVICE=1: a functional check of the multi-rank path on a one-GPU box (all ranks on cuda:0);
@@ -230,12 +306,17 @@ def main():
     one_dev = os.environ.get("S2V_BENCH_ONE_DEVICE", "0") == "1"
     if one_dev:
         os.environ["LOCAL_RANK"] = "0"
+    import torch.distributed as dist
+
+    if not one_dev and int(os.environ.get("LOCAL_RANK", "0")) >= torch.cuda.device_count():
+        raise SystemExit(f"LOCAL_RANK={os.environ.get('LOCAL_RANK')} but {torch.cuda.device_count()} GPU(s) visible")
     rank, world, local = s2v.dist.init_from_env(backend if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # from here on the number of ranks is what the process group says, never the flag
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the process group has {world} rank(s)")
     dev = f"cuda:{local}"
     torch.cuda.set_device(dev)
-    import torch.distributed as dist
 
     preset, F, H, W, T = WORKLOADS[args.workload]
     cfg = s2v.config.PRESETS[preset]()
@@ -246,12 +327,12 @@ def main():
     n_lora = 0
     if rank == 0:
         n_lora = load_synthetic(s2v, eng, cfg, 1234)
-    bcast_s = None
+    bcast_s = bcast_bytes = None
     if world > 1:
         torch.cuda.synchronize()
-        dist.barrier()
+        dist.barrier()  # also the communicator's first collective: its lazy set-up stays out of the broadcast time
         tb = time.time()
-        nbytes = s2v.dist.broadcast_arena(eng.weight_arena(), 0)
+        bcast_bytes = s2v.dist.broadcast_arena(eng.weight_arena(), 0)
         torch.cuda.synchronize()
         dist.barrier()
         bcast_s = time.time() - tb
@@ -288,18 +369,32 @@ def main():
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t0
+        total = nsteps
         if world > 1:
             tt = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = tt.item()
-        return el
+            ts = torch.tensor([nsteps], device=dev, dtype=torch.int64)  # the steps every rank actually ran, summed
+            dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+            total = int(ts.item())
+        return el, total
 
     # ---- the timed region of the contract: no event recording, no profiling inside it
-    elapsed = timed(bool(args.graph), args.steps, args.warmup)
+    elapsed, total_steps = timed(bool(args.graph), args.steps, args.warmup)
     finite = bool(torch.isfinite(latents.float()).all().item())
+    # who ran: one record per rank (device index, name, bus id), gathered on rank 0 -- n_gpus is the number of DISTINCT devices
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device": dev, "name": props.name, "pci_bus_id": getattr(props, "pci_bus_id", None),
+          "uuid": str(getattr(props, "uuid", "")), "steps": args.steps, "outputs_finite": finite}
+    ranks_info = [me]
+    if world > 1:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+    n_devices = len({(r["device"], r["uuid"]) for r in ranks_info})
+    finite = all(r["outputs_finite"] for r in ranks_info)
     # ---- the other launch mode, timed the same way (beside the metric, not in it)
     other_steps = min(args.steps, 5)
-    other = None if args.single_mode else timed(not bool(args.graph), other_steps, 1)
+    other = None if args.single_mode else timed(not bool(args.graph), other_steps, 1)[0]
     this_ms, other_ms = elapsed / args.steps * 1e3, None if other is None else other / other_steps * 1e3
     graph_ms, eager_ms = (this_ms, other_ms) if args.graph else (other_ms, this_ms)
 
@@ -347,9 +442,20 @@ def main():
         dom = max((n for n in per_kernel if n in flops), key=lambda n: per_kernel[n]["avg_ms"] * per_kernel[n]["launches"])
         ach = per_kernel[dom]["tflops"]
         peak = per_kernel[dom]["peak_tflops"]  # the dominant kernel's own matrix-core peak (fp8 GEMMs: 5 PF, everything else 2.5 PF)
+        traffic, traffic_files = pmc_traffic_bytes(dom, args.workload)
+        # unique operand bytes of one launch (bf16 activations; fp8 engines read 1-byte weights / activations on the GEMMs):
+        # attention reads Q, K, V^T and writes O; a GEMM reads A [M,K] and W [N,K] and writes C [M,N]
+        Eg = 1 if fp8 else 2
+        Mr = 2 * N
+        algo_bytes = {"attention": 4 * Mr * D * 2, "gemm_qkv": Mr * D * Eg + 3 * D * D * Eg + Mr * 3 * D * 2,
+                      "gemm_out": Mr * D * Eg + D * D * Eg + Mr * D * 2, "gemm_ff1_gelu": Mr * D * Eg + 4 * D * D * Eg + Mr * 4 * D * Eg,
+                      "gemm_ff2": Mr * 4 * D * Eg + 4 * D * D * Eg + Mr * D * 2}
         roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": pmc_traffic_bytes(dom),
-                    "traffic_unit": "bytes/launch (profiles/rNN_pmc_{fetch,write}.csv, FETCH_SIZE x2 per MI355X_MICROARCH)",
+                    "frac": round(ach / peak, 4), "traffic": traffic,
+                    "traffic_unit": "bytes/launch = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH, HBM section) from "
+                                    + (" + ".join("profiles/" + f for f in traffic_files) if traffic_files else "no PMC pass committed for this workload"),
+                    "algorithmic_bytes_per_launch": algo_bytes.get(dom),
+                    "traffic_over_algorithmic": round(traffic / algo_bytes[dom], 3) if traffic and algo_bytes.get(dom) else None,
                     "algorithmic_flops_per_launch": flops[dom], "avg_launch_ms": per_kernel[dom]["avg_ms"],
                     "measured": f"HIP events on the launch stream in a separate eager pass of {prof_steps} steps after the timed region",
                     "per_kernel": per_kernel}
@@ -413,23 +519,30 @@ def main():
         out = {
             "metric": "denoise steps/sec (CogVideoX-5B, 49f 720x480; one step = CFG-pair transformer forward + CFG + "
                       "scheduler step)" if "5b" in args.workload else f"denoise steps/sec ({args.workload})",
-            "value": round(args.gpus * args.steps / elapsed, 4),
+            "value": round(total_steps / elapsed, 4),  # sum over ranks of the steps they ran / max over ranks of the elapsed time
             "unit": "steps/s",
-            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "n_gpus": n_devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "fp8 (e4m3 W8A8 block linears) + bf16" if fp8 else "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
             "config": {"workload": args.workload, "latent_frames": F, "latent_hw": [H, W], "tokens": T + (F + 1) * (H // 2) * (W // 2),
-                       "cfg_pair": 2, "scheduler": "ddim-trailing-50", "parallelism": f"replicas x{args.gpus}",
+                       "cfg_pair": 2, "scheduler": "ddim-trailing-50", "parallelism": f"replicas x{world}",
+                       "rccl_ranks": world, "backend": (dist.get_backend() if dist.is_initialized() else None),
+                       "launcher": "self-spawned" if os.environ.get("S2V_BENCH_SPAWNED") == "1" else ("torchrun env" if env_world is not None else "single process"),
+                       "ranks": ranks_info,
+                       "one_device_functional_check": True if (one_dev and world > 1) else None,
                        "hipgraph": bool(args.graph), "graph_ms_per_step": None if graph_ms is None else round(graph_ms, 2),
                        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 2),
-                       "per_gpu_steps_per_s": round(args.steps / elapsed, 4),
+                       "per_gpu_steps_per_s": round(total_steps / elapsed / n_devices, 4),
                        "lora_merged": f"rank-128 synthetic adapter on {n_lora} weights (alpha / r = 0.5)" if n_lora else None, "weight_load_s": round(t_load, 2), "weight_broadcast_s": None if bcast_s is None else round(bcast_s, 3),
+                       "weight_broadcast_gb": None if not bcast_bytes else round(bcast_bytes / 1e9, 3),
+                       "weight_broadcast_gb_per_s": None if not bcast_s else round(bcast_bytes / bcast_s / 1e9, 1),
+                       "xgmi_link_bound_gb_per_s": 153.0 if world > 1 else None,
                        "outputs_finite": finite},
             "roofline": roofline,
             "wall_clock_per_video": video,
         }
-        if not args.no_cpu_baseline and args.gpus == 1 and not fp8:
+        if not args.no_cpu_baseline and world == 1 and not fp8:
             out["cpu_baseline"] = cpu_baseline(s2v, cfg, F, H, W, T, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
