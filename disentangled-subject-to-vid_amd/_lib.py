@@ -42,6 +42,7 @@ _SIGS = {
     "s2v_merge_lora": [_P, ctypes.c_char_p, _P, _P, _I32, _F, _P],
     "s2v_finalize_weights": [_P, _P],
     "s2v_weight_arena": [_P, ctypes.POINTER(_P), ctypes.POINTER(_I64)],
+    "s2v_weight_slot": [_P, ctypes.c_char_p, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64)],
     "s2v_mark_weights_loaded": [_P],
     "s2v_set_geometry": [_P, _I32, _I32, _I32, _I32, _I32],
     "s2v_set_rope": [_P, _P, _P, _P],

@@ -1,4 +1,5 @@
 """Build recipe for libs2v_hip.so (hipcc, gfx950 only).  `python build.py` or `build_library()`."""
+import hashlib
 import os
 import subprocess
 import sys
@@ -10,7 +11,8 @@ SOURCES = ["api.hip", "gemm.hip", "gemm_g4.hip", "attention.hip", "attention_q4.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value", "-Wno-inline-asm"]
 # the HBM-bound kernels mirror the reference's separately-rounded elementwise ops: no fma contraction there
 # (hipcc defaults to -ffp-contract=fast); the scheduler step is bit-exact against the CPU reference because of it
-EXTRA = {"attention_q4.hip": ["-fno-slp-vectorize"], "gemm_g4.hip": ["-fno-slp-vectorize"], "elementwise.hip": ["-ffp-contract=off"], "vae.hip": ["-ffp-contract=off"], "t5.hip": ["-ffp-contract=off"]}
+EXTRA = {"attention_q4.hip": ["-fno-slp-vectorize"], "gemm_g4.hip": ["-fno-slp-vectorize"], "elementwise.hip": ["-ffp-contract=off", "-DS2V_TU_FP_CONTRACT_OFF"], "vae.hip": ["-ffp-contract=off", "-DS2V_TU_FP_CONTRACT_OFF"],
+         "t5.hip": ["-ffp-contract=off", "-DS2V_TU_FP_CONTRACT_OFF"]}
 
 
 def _stale(out, deps):
@@ -20,47 +22,92 @@ def _stale(out, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _digest(paths, extra=()):
+    """content hash of the inputs of a build step: file bytes + the command-line pieces.  Staleness is decided by CONTENT, not by
+    modification time: a fresh checkout (new mtimes everywhere, or old ones) next to a binary that travelled from another tree
+    rebuilds exactly when the sources differ from the ones the binary was made from."""
+    h = hashlib.sha256()
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    for p in sorted(paths):
+        h.update(os.path.basename(p).encode() + b"\0")
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read().strip()
+    except OSError:
+        return None
+
+
 DIAG_LIB = os.path.join(HERE, "libs2v_hip_diag.so")
 
 
 def build_library(force=False, verbose=True, diag=False):
     """diag=False: the product library (exports exactly what include/s2v_hip.h declares).
     diag=True: libs2v_hip_diag.so = the same sources with -DS2V_DIAG (A/B reference kernels, stall accounting, ablations and
-    their knobs); only tools/ and the race-screen test load it."""
+    their knobs); only tools/ and the race-screen test load it.
+    force (or S2V_FORCE_BUILD=1 in the environment): recompile every translation unit and relink.  Otherwise a step runs when the
+    sha256 of its inputs (sources, every header / generated .inc, flags) differs from the stamp written beside its output:
+    `<lib>.stamp` travels with the .so (git-ignored like it), the per-object stamps live in build/."""
+    force = force or os.environ.get("S2V_FORCE_BUILD", "0") == "1"
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     objdir = os.path.join(HERE, "build_diag" if diag else "build")
     LIB = DIAG_LIB if diag else globals()["LIB"]
     FLAGS = globals()["FLAGS"] + (["-DS2V_DIAG"] if diag else [])
-    os.makedirs(objdir, exist_ok=True)
-    gen = os.path.join(CSRC, "gen_attn_q4.py")  # generated asm of attention_q4.hip (outputs are committed; regenerated when stale)
-    if _stale(os.path.join(CSRC, "attn_q4_body.inc"), [gen]):
-        subprocess.check_call([sys.executable, gen])
-    gen = os.path.join(CSRC, "gen_gemm_g4.py")
-    if _stale(os.path.join(CSRC, "gemm_g4_body.inc"), [gen]):
-        subprocess.check_call([sys.executable, gen])
-    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith((".h", ".inc"))]
+    gens = [("gen_attn_q4.py", "attn_q4_body.inc"), ("gen_gemm_g4.py", "gemm_g4_body.inc")]  # generated asm (outputs are committed)
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith((".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "s2v_hip.h"))
+    srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    gen_srcs = [os.path.join(CSRC, g) for g, _ in gens]
+    whole = _digest(srcs + headers + gen_srcs, FLAGS + [f"{k}:{v}" for k, v in sorted(EXTRA.items())])
+    if not force and os.path.exists(LIB) and _read(LIB + ".stamp") == whole:
+        if verbose:
+            print(f"up to date (content hash {whole[:12]}): {LIB}", flush=True)
+        return LIB
+    os.makedirs(objdir, exist_ok=True)
+    for g, out in gens:
+        gp, op = os.path.join(CSRC, g), os.path.join(CSRC, out)
+        stamp = os.path.join(objdir, g + ".stamp")
+        d = _digest([gp])
+        if force or not os.path.exists(op) or (_read(stamp) != d and _stale(op, [gp])):
+            if verbose:
+                print(f"{sys.executable} {gp}", flush=True)
+            subprocess.check_call([sys.executable, gp])
+        with open(stamp, "w") as f:
+            f.write(d)
+    headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith((".h", ".inc"))]
+    headers.append(os.path.join(HERE, "..", "include", "s2v_hip.h"))
+    whole = _digest(srcs + headers + gen_srcs, FLAGS + [f"{k}:{v}" for k, v in sorted(EXTRA.items())])
     objs = []
     procs = []
-    for src in SOURCES:
-        sp = os.path.join(CSRC, src)
-        if not os.path.exists(sp):
-            continue
+    for sp in srcs:
+        src = os.path.basename(sp)
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        if force or _stale(obj, [sp] + headers):
-            cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", sp, "-o", obj]
+        cmd = [hipcc] + FLAGS + EXTRA.get(src, []) + ["-c", sp, "-o", obj]
+        d = _digest([sp] + headers, cmd[1:-3])
+        if force or not os.path.exists(obj) or _read(obj + ".stamp") != d:
             if verbose:
                 print(" ".join(cmd), flush=True)
-            procs.append((src, subprocess.Popen(cmd)))
-    for src, p in procs:
+            procs.append((src, obj, d, subprocess.Popen(cmd)))
+    for src, obj, d, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.check_call(cmd)
+        with open(obj + ".stamp", "w") as f:
+            f.write(d)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    with open(LIB + ".stamp", "w") as f:
+        f.write(whole)
+    if verbose:
+        print(f"built {len(procs)} of {len(objs)} translation units, linked {LIB} (content hash {whole[:12]})", flush=True)
     return LIB
 
 

@@ -11,6 +11,14 @@ Reference behaviour followed (paths relative to the reference checkout):
                             `pytorch_lora_weights.safetensors`
   LoRA key handling         src/inference.py:83-92: keep `transformer.*`, strip the prefix, then
                             `convert_unet_state_dict_to_peft` (utils/state_dict_utils.py:39-51,248-253)
+  text encoder              `T5EncoderModel.from_pretrained(subfolder="text_encoder")` + `resize_token_embeddings(len(tokenizer))`
+                            after the `<cls>` token was added (src/inference.py:177-189): transformers' layout
+                            `model.safetensors` / `model-0000k-of-0000n.safetensors` + `model.safetensors.index.json`,
+                            tied `shared.weight` / `encoder.embed_tokens.weight`; the T5 tokenizer has 32 100 entries, the
+                            checkpoint's table 32 128 rows, so the "resize" to 32 101 is a TRUNCATION (rows [:n] kept bit for
+                            bit -- checked against transformers 5.15.0 in this container)
+  full VAE                  `AutoencoderKLCogVideoX.from_pretrained(subfolder="vae")` (src/inference.py:201,231): decoder AND
+                            encoder halves (the encoder runs the reference image, src/video_generate.py:26-38)
   LoRA scale                lora_alpha / r = 64 / 128 (src/inference.py:47-48,218-223); PEFT computes W x + (alpha/r) B A x,
                             which the merge W + (alpha/r) B A reproduces (SURVEY preamble 6)
 """
@@ -140,3 +148,94 @@ def load_transformer(model, transformer_dir, lora_dir=None, lora_alpha=64, rank=
 def load_vae_decoder(vae, vae_dir):
     sd = {k: t for k, t in iter_tensors(model_files(vae_dir)) if k.startswith("decoder.")}
     vae.load_state_dict(sd)
+
+
+def load_vae(vae, vae_dir, with_encoder=True):
+    """the whole AutoencoderKLCogVideoX checkpoint (src/inference.py:201,231) into a HipAutoencoderKLCogVideoX: `decoder.*` and,
+    with_encoder, `encoder.*` (215.6 M parameters in all: one state dict on the host is fine).  Returns the loaded key prefixes.
+    Keys of neither half (`quant_conv.*` / `post_quant_conv.*` exist only when `use_quant_conv`, which CogVideoX does not set)
+    are rejected loudly rather than dropped."""
+    want = ("decoder.", "encoder.") if with_encoder else ("decoder.",)
+    sd, other = {}, []
+    for k, t in iter_tensors(model_files(vae_dir)):
+        if k.startswith(want):
+            sd[k] = t
+        elif not k.startswith(("decoder.", "encoder.")):
+            other.append(k)
+    if other:
+        raise ValueError(f"VAE checkpoint holds tensors outside encoder / decoder that this path does not evaluate: {sorted(other)[:4]}")
+    if with_encoder and not any(k.startswith("encoder.") for k in sd):
+        raise FileNotFoundError(f"no `encoder.*` tensors under {vae_dir}")
+    vae.load_state_dict(sd)
+    return sorted({k.split(".", 1)[0] for k in sd})
+
+
+def t5_config(text_encoder_dir, num_tokens=None):
+    """T5Config from `<dir>/config.json`; num_tokens = len(tokenizer) after the `<cls>` token was added (src/inference.py:179-189)"""
+    from .t5 import T5Config
+    c = _config_json(text_encoder_dir)
+    kw = {k: v for k, v in c.items() if k in T5Config.__dataclass_fields__}
+    if c.get("feed_forward_proj", "gated-gelu") != "gated-gelu" or c.get("is_gated_act", True) is False:
+        raise ValueError(f"text encoder is not T5 v1.1 (gated-gelu): feed_forward_proj={c.get('feed_forward_proj')!r}")
+    if num_tokens is not None:
+        kw["vocab_size"] = int(num_tokens)
+    return T5Config(**kw)
+
+
+def resize_token_embeddings(table, num_tokens, new_rows=None):
+    """`text_encoder.resize_token_embeddings(n)` on the checkpoint's `shared.weight`: the first min(old, n) rows are kept bit for
+    bit (transformers `_get_resized_embeddings`).  For the shipped checkpoints n = 32 101 < 32 128, a truncation.  Growing the table
+    makes transformers draw the new rows from a distribution fitted to the old ones -- not reproducible from the file -- so a
+    caller who needs that passes the rows themselves (`new_rows` [n - old, d]) and anything else is an error."""
+    import torch
+
+    old = table.shape[0]
+    if num_tokens <= old:
+        return table[:num_tokens].contiguous()
+    if new_rows is None or tuple(new_rows.shape) != (num_tokens - old, table.shape[1]):
+        raise ValueError(f"resize_token_embeddings {old} -> {num_tokens} grows the table: pass new_rows [{num_tokens - old}, {table.shape[1]}]")
+    return torch.cat([table, new_rows.to(table.dtype)], 0).contiguous()
+
+
+def load_t5(text_encoder_dir, dtype=None, device="cuda:0", num_tokens=None, new_rows=None, model=None):
+    """HipT5EncoderModel from a transformers-layout T5 encoder directory, the way src/inference.py:183-189,213 builds it: shards
+    streamed one tensor at a time (4.7 B parameters), the tied embedding loaded once, the table resized to `num_tokens`
+    (= len(tokenizer) with `<cls>`; None keeps the checkpoint's rows), decoder / lm_head tensors of a full T5 checkpoint ignored."""
+    import torch
+
+    from .t5 import HipT5EncoderModel
+
+    files = model_files(text_encoder_dir, stem="model")
+    if model is None:
+        model = HipT5EncoderModel(t5_config(text_encoder_dir, num_tokens), dtype or torch.bfloat16, device)
+    elif num_tokens is not None and model.cfg.vocab_size != num_tokens:
+        raise ValueError(f"model built for {model.cfg.vocab_size} tokens, num_tokens={num_tokens}")
+
+    def stream():
+        seen_table = False
+        for k, t in iter_tensors(files):
+            if k in ("shared.weight", "encoder.embed_tokens.weight"):
+                if seen_table:
+                    continue  # the tied copy
+                seen_table = True
+                yield "shared.weight", resize_token_embeddings(t, model.cfg.vocab_size, new_rows)
+            elif k.startswith("encoder."):
+                yield k, t
+        if not seen_table:
+            raise FileNotFoundError(f"no shared.weight / encoder.embed_tokens.weight under {text_encoder_dir}")
+
+    model.load_state_dict(_Streamed(stream))
+    return model
+
+
+class _Streamed:
+    """a state dict that is read once, in file order, one tensor resident at a time (what load_state_dict's `.items()` loop needs)"""
+
+    def __init__(self, gen):
+        self._gen = gen
+
+    def items(self):
+        return self._gen()
+
+    def __contains__(self, k):
+        return False

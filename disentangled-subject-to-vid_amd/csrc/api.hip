@@ -204,7 +204,7 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     hipError_t e = hipMalloc((void**)&c->arena, c->arena_bytes);
     if (e != hipSuccess) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, hipGetErrorString(e), -2); }
     e = hipMemset(c->arena, 0, c->arena_bytes);
-    if (e != hipSuccess) { hipFree(c->arena); delete c; return s2v_fail(__FILE__, __LINE__, hipGetErrorString(e), -2); }
+    if (e != hipSuccess) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, hipGetErrorString(e), -2); }
     char* A = c->arena;
     c->layers.resize(L);
     char nm[160];
@@ -390,6 +390,19 @@ extern "C" int s2v_finalize_weights(s2v_ctx* c, s2v_stream stream) {
         c->lora_tmp_bytes = 0;
     }
     c->finalized = true;
+    return 0;
+}
+
+extern "C" int s2v_weight_slot(s2v_ctx* c, const char* name, int64_t* offset_bytes, int64_t* rows, int64_t* cols, int64_t* ld) {
+    S2V_REQUIRE(c && name && offset_bytes && rows && cols && ld, "s2v_weight_slot: null argument");
+    auto it = c->slots.find(name);
+    if (it == c->slots.end()) {
+        std::string m = std::string("s2v_weight_slot: unknown tensor name: ") + name;
+        return s2v_fail(__FILE__, __LINE__, m.c_str(), -3);
+    }
+    const Slot& s = it->second;
+    *offset_bytes = (int64_t)(s.dst - c->arena);
+    *rows = s.rows; *cols = s.cols; *ld = s.ld;
     return 0;
 }
 

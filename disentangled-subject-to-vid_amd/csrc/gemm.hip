@@ -1119,6 +1119,19 @@ static int launch_q4_t(const GemmArgs& a, hipStream_t st) {
 }
 #endif
 
+// compute units of the current device, queried once per device (launch-path heuristics count tile ROUNDS in these)
+static int device_cus() {
+    static int cus[64] = {0};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+    if (!cus[d]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+        cus[d] = n;
+    }
+    return cus[d];
+}
+
 template <int EPI>
 static int launch_pp64_t(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
@@ -1243,13 +1256,14 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
 #ifdef S2V_DIAG
     if (const char* e = getenv("S2V_G4_EPI_MASK")) g4_epi = (atoi(e) >> epi) & 1;  // bisecting aid: g4 for the epilogues of the mask only
 #endif
-    // One round of tiles (<= 256 CUs' worth) leaves the epilogue fully exposed, and the fused q/k-norm + rotary epilogue is the longest:
+    // One round of tiles (<= one per CU) leaves the epilogue fully exposed, and the fused q/k-norm + rotary epilogue is the longest:
     // eight waves run it faster than four (C1 QKV, 230 tiles: 65 us on the ping-pong kernel, 72 us on gemm_g4)
-    if (epi == EPI_BIAS_QKNORM && (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) <= 256) g4_epi = false;
+    const int64_t out_tiles = (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256), cus = device_cus();  // rounds are counted in THIS device's CUs
+    if (epi == EPI_BIAS_QKNORM && out_tiles <= cus) g4_epi = false;
     // the bias + GELU epilogue is the next longest: up to two rounds of tiles with a short reduction (C1 FF1: 300 tiles of 30 K-tiles) also run
     // faster on eight waves -- same-box A/B of the C1 step, 11.50 -> 11.12 ms (tools/c1_attn_kernel_probe.py, S2V_G4_EPI_MASK); same epilogue
     // code, bit-identical results
-    if (epi == EPI_BIAS_GELU && a.splitk <= 1 && a.K <= 2048 && (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) <= 512) g4_epi = false;
+    if (epi == EPI_BIAS_GELU && a.splitk <= 1 && a.K <= 2048 && out_tiles <= 2 * cus) g4_epi = false;
     const bool big_tiles = a.tile == 0 || a.conv || epi == EPI_BIAS_QKNORM;  // GemmArgs::tile: the caller asks for smaller tiles
     if (g_gemm_impl == 9 && big_tiles && g4_epi && w_tile_ok(a) && gemm_g4_ok(a, epi)) return launch_gemm_g4(a, epi, st);  // four-wave generated-asm K loop
     if ((g_gemm_impl == 7 || g_gemm_impl == 8 || g_gemm_impl == 9) && big_tiles && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {

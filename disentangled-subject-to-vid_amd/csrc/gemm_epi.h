@@ -7,6 +7,9 @@
 // No fma contraction in the epilogues: they restate separately-rounded elementwise ops (LayerNorm, rotary embedding, gate, residual) and
 // are compiled into more than one translation unit -- with -ffp-contract=fast hipcc fused `a * b + c` in gemm_g4.hip where it had not in
 // gemm.hip, and the rows of a split GEMM (256-row tiles on one kernel, the row tail on another) then differed by a bf16 ulp.
+// The translation unit's own setting is put back at the end of this header: hipcc's default `fast`, or `off` when the unit is built
+// with -ffp-contract=off (elementwise.hip / vae.hip / t5.hip; build.py defines S2V_TU_FP_CONTRACT_OFF beside that flag -- clang has no
+// predefined macro for it and `#pragma float_control(push / pop)` is not supported on amdgcn).
 #pragma clang fp contract(off)
 
 // ---------------------------------------------------------------------------------------------------
@@ -286,4 +289,8 @@ __host__ __device__ __forceinline__ bool epi_vec_ok(const GemmArgs& a, int epi) 
 }
 
 
-#pragma clang fp contract(fast)  // back to hipcc's default for whatever follows the include
+#ifdef S2V_TU_FP_CONTRACT_OFF
+#pragma clang fp contract(off)   // a unit built with -ffp-contract=off stays that way after the include
+#else
+#pragma clang fp contract(fast)  // hipcc's default
+#endif

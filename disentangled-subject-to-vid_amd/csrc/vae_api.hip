@@ -339,8 +339,41 @@ static void ws_activate(s2v_vae* v, int k) {
     v->ws_active = k;
 }
 
+// one workspace set (every operand / cache / scratch buffer of a decode at window th x tw) into the live members
+static int alloc_workspace_set(s2v_vae* v, int th, int tw, int fz_max) {
+    int rc = 0;
+    int64_t dmax = 0;
+    for_each_conv(v, [&](ConvL& c) {
+        const int64_t H = (int64_t)th << c.level, W = (int64_t)tw << c.level;
+        const int F = v->fmax[c.level] + (c.kt == 3 ? 2 : 0);
+        c.pad_bytes = (int64_t)F * (H + 2) * (W + 2) * c.cin * v->esz + 1024;
+        if (!rc) rc = dmalloc(v, &c.pad, c.pad_bytes, true);
+        const int64_t d = (int64_t)v->fmax[c.level] * H * W * (c.cin > c.cout ? c.cin : c.cout) * v->esz;
+        dmax = d > dmax ? d : dmax;
+    });
+    if (rc) return rc;
+    v->dense_bytes = dmax + (int64_t)256 * 1024 * v->esz;  // + one 128-row MFMA tile of slack
+    for (int i = 0; i < 3; ++i) S2V_TRY(dmalloc(v, &v->dense[i], v->dense_bytes, true));
+    S2V_TRY(dmalloc(v, &v->zq, (int64_t)fz_max * th * tw * v->Cz * v->esz + 64, true));
+    int cmax = 0;
+    for_each_conv(v, [&](ConvL& c) { cmax = c.cin > cmax ? c.cin : cmax; });
+    S2V_TRY(dmalloc(v, &v->yt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
+    S2V_TRY(dmalloc(v, &v->bt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
+    int lv = 0;
+    for (size_t s = 1; s < v->stages.size(); ++s) if (v->stages[s].has_up) lv++;
+    const int64_t pmax = (int64_t)v->fmax[lv] * ((int64_t)th << lv) * ((int64_t)tw << lv);
+    S2V_TRY(dmalloc(v, &v->gn_part, gn_stats_scratch_bytes(pmax, v->G) + 64, true));
+    S2V_TRY(dmalloc(v, &v->sums, sizeof(double) * 2 * v->G, true));
+    return 0;
+}
+
+// Workspace for windows up to th x tw latents, fz_max latent frames per batch, `nws` sets (tiles in flight).
+// The capacity fields (th / tw / fmax / ws_req) and v->ws are committed only AFTER the sets exist: a failed allocation leaves the
+// context at "no capacity" (the next decode allocates again instead of running on empty sets -- ADVICE r3), a failed set k > 0 is
+// freed and the decode proceeds with k sets.  The number of sets is bounded by 70 % of the free memory at this moment (other ranks
+// on the device and torch's caching allocator may move that figure: hence the retry-with-fewer path) and by S2V_VAE_WORKSPACE_MAX_GB.
 static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws = 1) {
-    if (v->th >= th && v->tw >= tw && v->fmax[0] >= fz_max && v->ws_req >= nws) return 0;
+    if (v->th >= th && v->tw >= tw && v->fmax[0] >= fz_max && v->ws_req >= nws && !v->ws.empty()) return 0;
     S2V_CHECK_HIP(hipDeviceSynchronize());
     for (void* p : v->geo_allocs) (void)hipFree(p);
     v->geo_allocs.clear();
@@ -348,14 +381,16 @@ static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws
     tw = tw > v->tw ? tw : v->tw;
     fz_max = fz_max > v->fmax[0] ? fz_max : v->fmax[0];
     nws = std::max(nws, v->ws_req);
-    v->ws_req = nws;
-    v->th = th; v->tw = tw;
+    const int nws_req = nws;
+    // from here until the commit below the context has NO capacity
+    v->th = v->tw = 0; v->ws_req = 0; v->ws.clear(); v->ws_active = 0; v->cur_h = v->cur_w = 0;
+    for (int i = 0; i < 8; ++i) v->fmax[i] = 0;
     // frames per level
     int f = fz_max, lvl = 0;
     v->fmax[0] = f;
     for (size_t s = 1; s < v->stages.size(); ++s)
         if (v->stages[s].has_up) { f = up_frames(f, v->stages[s].compress_time); v->fmax[++lvl] = f; }
-    {  // as many sets as 70 % of the free memory holds (never fewer than one)
+    {  // as many sets as 70 % of the free memory (and the optional byte cap) hold, never fewer than one
         int64_t set_bytes = 0, dmax = 0;
         for_each_conv(v, [&](ConvL& c) {
             const int64_t H = (int64_t)th << c.level, W = (int64_t)tw << c.level;
@@ -365,41 +400,36 @@ static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws
         set_bytes += 3 * dmax;
         v->set_bytes = set_bytes;
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && set_bytes > 0)
-            nws = (int)std::max<int64_t>(1, std::min<int64_t>(nws, (int64_t)(0.7 * (double)free_b) / set_bytes));
-    }
-    v->ws.assign(nws, s2v_vae::WS());
-    for (int k = 0; k < nws; ++k) {
-        int rc = 0;
-        int64_t dmax = 0;
-        for_each_conv(v, [&](ConvL& c) {
-            const int64_t H = (int64_t)th << c.level, W = (int64_t)tw << c.level;
-            const int F = v->fmax[c.level] + (c.kt == 3 ? 2 : 0);
-            c.pad_bytes = (int64_t)F * (H + 2) * (W + 2) * c.cin * v->esz + 1024;
-            if (!rc) rc = dmalloc(v, &c.pad, c.pad_bytes, true);
-            const int64_t d = (int64_t)v->fmax[c.level] * H * W * (c.cin > c.cout ? c.cin : c.cout) * v->esz;
-            dmax = d > dmax ? d : dmax;
-        });
-        if (rc) return rc;
-        v->dense_bytes = dmax + (int64_t)256 * 1024 * v->esz;  // + one 128-row MFMA tile of slack
-        for (int i = 0; i < 3; ++i) S2V_TRY(dmalloc(v, &v->dense[i], v->dense_bytes, true));
-        S2V_TRY(dmalloc(v, &v->zq, (int64_t)fz_max * th * tw * v->Cz * v->esz + 64, true));
-        {
-            int cmax = 0;
-            for_each_conv(v, [&](ConvL& c) { cmax = c.cin > cmax ? c.cin : cmax; });
-            S2V_TRY(dmalloc(v, &v->yt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
-            S2V_TRY(dmalloc(v, &v->bt, (int64_t)fz_max * th * tw * cmax * v->esz + 64, true));
-            {
-                int lv = 0;
-                for (size_t s = 1; s < v->stages.size(); ++s) if (v->stages[s].has_up) lv++;
-                const int64_t pmax = (int64_t)v->fmax[lv] * ((int64_t)th << lv) * ((int64_t)tw << lv);
-                S2V_TRY(dmalloc(v, &v->gn_part, gn_stats_scratch_bytes(pmax, v->G) + 64, true));
-            }
+        double budget = -1.0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = 0.7 * (double)free_b;
+        if (const char* e = getenv("S2V_VAE_WORKSPACE_MAX_GB")) {
+            const double cap = atof(e) * 1e9;
+            if (cap > 0 && (budget < 0 || cap < budget)) budget = cap;
         }
-        S2V_TRY(dmalloc(v, &v->sums, sizeof(double) * 2 * v->G, true));
-        v->cur_h = v->cur_w = 0;
-        ws_save(v, k);
+        if (budget >= 0 && set_bytes > 0)
+            nws = (int)std::max<int64_t>(1, std::min<int64_t>(nws, (int64_t)budget / set_bytes));
     }
+    std::vector<s2v_vae::WS> sets;
+    int rc = 0;
+    for (int k = 0; k < nws; ++k) {
+        const size_t mark = v->geo_allocs.size();
+        rc = alloc_workspace_set(v, th, tw, fz_max);
+        if (rc) {  // give the partial set back; with k sets built the decode runs k tiles in flight
+            (void)hipGetLastError();
+            for (size_t i = mark; i < v->geo_allocs.size(); ++i) (void)hipFree(v->geo_allocs[i]);
+            v->geo_allocs.resize(mark);
+            break;
+        }
+        v->ws.push_back(s2v_vae::WS());
+        v->cur_h = v->cur_w = 0;
+        ws_save(v, (int)v->ws.size() - 1);
+    }
+    if (v->ws.empty()) {  // not even one set: stay at "no capacity" and report the allocation failure
+        for (int i = 0; i < 8; ++i) v->fmax[i] = 0;
+        for_each_conv(v, [&](ConvL& c) { c.pad = nullptr; });
+        return rc ? rc : vfail("prepare_tile_capacity: no workspace set could be allocated");
+    }
+    nws = (int)v->ws.size();
     v->ws_active = nws - 1;  // the members hold the last set built
     ws_activate(v, 0);
     while ((int)v->side.size() < nws - 1) {
@@ -409,6 +439,9 @@ static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws
         v->side.push_back(sst); v->ev_side.push_back(e);
     }
     if (!v->ev_fork) S2V_CHECK_HIP(hipEventCreateWithFlags(&v->ev_fork, hipEventDisableTiming));
+    // commit: the capacity this context now really has (ws_req keeps the REQUEST so that a memory-bounded result is not retried on
+    // every decode; a later, larger request allocates again)
+    v->th = th; v->tw = tw; v->ws_req = nws_req;
     return 0;
 }
 

@@ -45,15 +45,29 @@ def broadcast_arena(arena, src=0, chunk_bytes=256 << 20):
 
 def broadcast_components(components, src=0):
     """replicate every component of the path -- transformer engine, VAE (decoder [+ encoder]), T5 encoder: anything with
-    .weight_arenas() -> [uint8 tensors] and .mark_weights_loaded() -- rank `src` -> all.  Returns the bytes moved."""
+    .weight_arenas() -> [uint8 tensors] and .mark_weights_loaded() -- rank `src` -> all.  Returns the bytes moved.
+    A component may also expose .arenas_loaded() -> [bool per arena] (the VAE: its encoder half exists on every replica but is
+    only filled when the sender loaded `encoder.*` weights): the sender's flags travel first, an arena the sender never filled is
+    not sent, and the receiver is told exactly which arenas now hold weights (mark_weights_loaded(loaded=flags))."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
     total = 0
+    me = dist.get_rank()
     for c in components:
-        for arena in c.weight_arenas():
-            total += broadcast_arena(arena, src)
-        if dist.get_rank() != src:
-            c.mark_weights_loaded()
+        arenas = c.weight_arenas()
+        flags = [c.arenas_loaded() if (me == src and hasattr(c, "arenas_loaded")) else None]
+        dist.broadcast_object_list(flags, src=src)
+        flags = flags[0]
+        if flags is not None and len(flags) != len(arenas):
+            raise RuntimeError(f"replica mismatch: sender has {len(flags)} weight arenas, this rank built {len(arenas)}")
+        for i, arena in enumerate(arenas):
+            if flags is None or flags[i]:
+                total += broadcast_arena(arena, src)
+        if me != src:
+            if flags is None:
+                c.mark_weights_loaded()
+            else:
+                c.mark_weights_loaded(loaded=list(flags))
     return total
 
 

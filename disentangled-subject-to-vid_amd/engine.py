@@ -108,6 +108,16 @@ class S2VEngine:
     def weight_arenas(self):
         return [self.weight_arena()]
 
+    def read_weight(self, name):
+        """one state-dict tensor as it sits in the arena (after load / LoRA merge), [rows, cols] in the model dtype: a strided view
+        of weight_arena() located by s2v_weight_slot (biases / norm vectors come back as [1, n]; conv weights flattened to
+        [out, in * kh * kw])"""
+        off, rows, cols, ld = (ctypes.c_int64() for _ in range(4))
+        _lib.check(_lib.lib().s2v_weight_slot(self._h, name.encode(), ctypes.byref(off), ctypes.byref(rows), ctypes.byref(cols), ctypes.byref(ld)))
+        esz = torch.empty((), dtype=self.dtype).element_size()
+        flat = self.weight_arena()[off.value : off.value + ((rows.value - 1) * ld.value + cols.value) * esz].view(self.dtype)
+        return flat.as_strided((rows.value, cols.value), (ld.value, 1))
+
     def mark_weights_loaded(self):
         _lib.check(_lib.lib().s2v_mark_weights_loaded(self._h))
 

@@ -22,6 +22,8 @@ from .schedulers import CogVideoXDPMScheduler
 
 
 class S2VPipeline:
+    _callback_tensor_inputs = ["latents", "prompt_embeds", "negative_prompt_embeds"]  # pipeline_cogvideox.py:166-170
+
     def __init__(self, transformer, scheduler, vae=None, vae_scale_factor_spatial=8, vae_scale_factor_temporal=4):
         self.transformer, self.scheduler, self.vae = transformer, scheduler, vae
         self.vae_scale_factor_spatial = vae_scale_factor_spatial
@@ -56,10 +58,13 @@ class S2VPipeline:
     def __call__(self, prompt_embeds=None, negative_prompt_embeds=None, ref_img_states=None, height=480, width=720,
                  num_frames=49, num_inference_steps=50, guidance_scale=6.0, use_dynamic_cfg=False, generator=None,
                  latents=None, output_type="latent", return_dict=True, fused=True, use_graph=False,
-                 callback_on_step_end=None):
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",)):
         if num_frames > 49:
             raise ValueError("The number of frames must be less than or equal to 49 due to static positional embeddings.")
         self.check_inputs(height, width, prompt_embeds, negative_prompt_embeds)
+        bad = [k for k in callback_on_step_end_tensor_inputs if k not in self._callback_tensor_inputs]
+        if bad:  # pipeline_cogvideox.py:385-390
+            raise ValueError(f"`callback_on_step_end_tensor_inputs` has to be in {self._callback_tensor_inputs}, but found {bad}")
         if negative_prompt_embeds is None:
             raise ValueError("Provide `negative_prompt_embeds`: the reference builds them from the empty prompt with its text "
                              "encoder (pipeline_cogvideox.py:239-318), which is a caller-side step here "
@@ -125,7 +130,24 @@ class S2VPipeline:
                                             generator=generator, return_dict=False)
                 latents = latents.to(dt)
             if callback_on_step_end is not None:
-                callback_on_step_end(self, i, t, {"latents": latents})
+                # custom_cogvideox_pipe.py:298-305: the callback sees the requested tensors -- `prompt_embeds` is, at that point of
+                # the reference loop, the CONCATENATED [negative | positive] pair (:196) -- and what it returns replaces them for
+                # the following steps (a returned `negative_prompt_embeds` is rebound there too, but nothing reads it after :196).
+                # A callback that returns nothing keeps everything (the reference would raise on `None.get`).
+                avail = {"latents": latents, "prompt_embeds": text, "negative_prompt_embeds": negative_prompt_embeds}
+                outs = callback_on_step_end(self, i, t, {k: avail[k] for k in callback_on_step_end_tensor_inputs}) or {}
+                new_lat = outs.get("latents", latents)
+                if new_lat is not latents:
+                    if fused:  # the step (and its captured graph) updates ONE buffer in place: keep it, take the values
+                        latents.copy_(new_lat.to(dev, dt).reshape(latents.shape))
+                    else:
+                        latents = new_lat.to(dev, dt)
+                new_text = outs.get("prompt_embeds", text)
+                if new_text is not text:
+                    text = new_text.to(dev, dt)
+                    if fused:
+                        eng.set_conditioning(text, ref)  # the hoisted text projection follows the new embeddings
+                negative_prompt_embeds = outs.get("negative_prompt_embeds", negative_prompt_embeds)
         if output_type == "latent":
             video = latents
         else:

@@ -95,6 +95,7 @@ class HipAutoencoderKLCogVideoX:
         self._cfg_c = c
         self._enc = ctypes.c_void_p()  # encoder handle (also created lazily when `encoder.*` weights arrive)
         self._enc_loaded = False       # weights present: load_state_dict saw `encoder.*` keys, or a replica was marked loaded
+        self._dec_loaded = False
         if with_encoder:
             _lib.check(_lib.lib().s2v_vae_enc_create(ctypes.byref(c), ctypes.byref(self._enc)))
 
@@ -166,6 +167,8 @@ class HipAutoencoderKLCogVideoX:
             _lib.check(_lib.lib().s2v_vae_finalize(halves[pre]))
         if "encoder." in loaded:
             self._enc_loaded = True
+        if "decoder." in loaded:
+            self._dec_loaded = True
 
     # ---- replicas: the weights of each half are one device range (dist.broadcast_components) ------------------------
     def weight_arenas(self, with_encoder=None):
@@ -184,12 +187,30 @@ class HipAutoencoderKLCogVideoX:
             out.append(torch.as_tensor(_ArenaView(p.value, n.value), device=self.device))
         return out
 
-    def mark_weights_loaded(self, with_encoder=None):
-        """the receiving side of a replica hand-off: the same halves weight_arenas() listed now hold a sender's weights"""
+    def arenas_loaded(self):
+        """one flag per arena of weight_arenas(): does it hold weights?  (the sender's side of dist.broadcast_components)"""
+        return [self._dec_loaded] + ([self._enc_loaded] if self._enc else [])
+
+    def mark_weights_loaded(self, with_encoder=None, loaded=None):
+        """the receiving side of a replica hand-off.  `loaded` = the SENDER's arenas_loaded(): only the halves the sender had
+        filled are marked (a sender that never saw `encoder.*` weights leaves this replica's encode() raising, as on the sender);
+        without it, the same halves weight_arenas() listed are taken to hold a sender's weights"""
+        if loaded is not None:
+            handles = [self._h] + ([self._enc] if self._enc else [])
+            if len(loaded) != len(handles):
+                raise _lib.S2VError(f"mark_weights_loaded: {len(loaded)} flags for {len(handles)} arenas")
+            for h, flag in zip(handles, loaded):
+                if flag:
+                    _lib.check(_lib.lib().s2v_vae_mark_weights_loaded(h))
+            self._dec_loaded = self._dec_loaded or bool(loaded[0])
+            if len(loaded) > 1 and loaded[1]:
+                self._enc_loaded = True
+            return
         if with_encoder is None:
             with_encoder = bool(self._enc)
         for h in [self._h] + ([self._enc] if with_encoder else []):
             _lib.check(_lib.lib().s2v_vae_mark_weights_loaded(h))
+        self._dec_loaded = True
         if with_encoder:
             self._enc_loaded = True
 

@@ -84,6 +84,10 @@ S2V_API int s2v_finalize_weights(s2v_ctx* ctx, s2v_stream stream);
 /* Total bytes of context-owned weights (for the broadcast) and access to the packed arena so that ONE
  * collective can replicate a finalized model rank0 -> all. */
 S2V_API int s2v_weight_arena(s2v_ctx* ctx, void** dev_ptr, int64_t* bytes);
+/* Where one state-dict tensor lives inside the arena: byte offset of element [0][0], its rows x cols and the leading dimension
+ * in elements of the model dtype (rows of the fused QKV / stacked modulation buffers are `ld` apart).  What a checkpoint tool
+ * needs to read a merged weight back (W + (alpha/r) B A of src/inference.py:218-229) without knowing the packing. */
+S2V_API int s2v_weight_slot(s2v_ctx* ctx, const char* name, int64_t* offset_bytes, int64_t* rows, int64_t* cols, int64_t* ld);
 
 /* Token geometry of the next calls: batch B (2 = CFG pair), text tokens T, latent frames F and latent H x W
  * (R = (H/2)(W/2) reference-image tokens, V = F*R video tokens, sequence order [text | ref | video]).

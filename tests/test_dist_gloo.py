@@ -171,3 +171,51 @@ def test_single_process_paths():
     assert d.broadcast_components([FakeEngine(10)]) == 0
     assert d.gather_results({0: torch.ones(2)})[0].sum() == 2
     assert d.shard_prompts(8, 3, 8) == [3]
+
+
+class FakeVAEFlags(FakeVAE):
+    """the protocol of HipAutoencoderKLCogVideoX since round 4: the sender's per-arena `loaded` flags travel with the
+    hand-off, so a half the sender never filled is neither sent nor marked on the receiver"""
+
+    def arenas_loaded(self):
+        return [self.loaded] + ([self.enc_loaded] if self.enc is not None else [])
+
+    def mark_weights_loaded(self, with_encoder=None, loaded=None):
+        if loaded is None:
+            return super().mark_weights_loaded(with_encoder)
+        self.loaded = self.loaded or loaded[0]
+        self.enc_loaded = self.enc_loaded or (len(loaded) > 1 and loaded[1])
+
+
+def _worker_flags(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    d = importlib.import_module("disentangled-subject-to-vid_amd.dist")
+    d.init_from_env("gloo")
+    vae = FakeVAEFlags()
+    if rank == 0:  # the sender loaded `decoder.*` only
+        vae.dec.fill_(7)
+        vae.loaded = True
+    moved = d.broadcast_components([vae], 0)
+    q.put((rank, moved, bool(vae.loaded), bool(vae.enc_loaded), int(vae.dec[0]), int(vae.enc.sum())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_receiver_marks_only_the_halves_the_sender_had_loaded():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_flags, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, moved, loaded, enc_loaded, d0, esum in got:
+        assert moved == 70001, "only the decoder arena travels"
+        assert loaded and not enc_loaded and d0 == 7 and esum == 0

@@ -123,3 +123,130 @@ def test_unknown_lora_keys_are_reported_not_fatal(s2v, capsys):
     del lora["transformer_blocks.0.attn1.to_z.weight"]
     eng2.load_state_dict(sd, lora=lora, lora_scale=0.5)
     assert torch.equal(eng.weight_arena(), eng2.weight_arena())
+
+
+def test_rank128_lora_merge_at_5b_width_vs_oracle(s2v):
+    """BASELINE configs[2] merges a rank-128 adapter (alpha / r = 64 / 128, src/inference.py:218-229) into 338 weights at D = 3072 -- the
+    size bench.py times.  ONE 5B-width block + the non-block targets (`patch_embed.proj` in its conv form, `patch_embed.text_proj`):
+    (1) fp32 engine: every merged weight read back from the arena (s2v_weight_slot) against oracle.transformer_ref.merge_lora, <= 1e-5;
+    (2) bf16 model forward (patch embed -> the block -> tail, so every merged weight is on the path) against the oracle's bf16 run."""
+    cfg = s2v.config.PRESETS["cogvideox-5b"]()
+    cfg.num_layers = 1
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=41, parity=True)
+    lora = s2v.weights.synthetic_lora(cfg, rank=128, seed=42, std=0.02)
+    targets = s2v.weights.lora_target_keys(cfg)
+    assert sorted(lora) == sorted(targets) and len(targets) == 8 + 2  # 338 = 42 x 8 + 2 on the full model
+    assert lora["patch_embed.proj.weight"][0].shape == (128, 16, 2, 2)
+    merged = tr.merge_lora(sd, lora, 0.5)
+
+    eng = s2v.S2VEngine(cfg, torch.float32, DEV)
+    eng.load_state_dict(sd, lora=lora, lora_scale=64 / 128)
+    worst = 0.0
+    for k in targets:
+        got = eng.read_weight(k).float().cpu()
+        exp = merged[k].reshape(merged[k].shape[0], -1)
+        assert got.shape == exp.shape, k
+        err = (got - exp).abs().max().item()
+        worst = max(worst, err)
+        assert err <= 1e-5, (k, err)
+        assert (exp - sd[k].reshape(exp.shape)).abs().max().item() > 1e-3, "the adapter must move the weight measurably"
+    untouched = "transformer_blocks.0.ff.net.0.proj.bias"
+    assert torch.equal(eng.read_weight(untouched).cpu().flatten(), sd[untouched])
+    eng.close()
+
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(43)
+    B, F, C, H, W, T = 2, 2, 16, 8, 12, 226
+    lat = torch.randn(B, F, C, H, W, generator=g).to(dt)
+    text = torch.randn(B, T, cfg.text_embed_dim, generator=g).to(dt)
+    ref = (torch.randn(1, 1, C, H, W, generator=g) * 0.7).to(dt)
+    ts = torch.tensor([500, 500])
+    ref_rope, rope = tr.pipeline_rope(H * 8, W * 8, F)
+    m = s2v.HipCogVideoXTransformer3DModel(cfg, dt, DEV)
+    m.load_state_dict({k: v.to(dt) for k, v in sd.items()}, lora=lora, lora_scale=0.5)
+    y = m(hidden_states=lat.to(DEV), encoder_hidden_states=text.to(DEV), ref_img_states=ref.to(DEV), timestep=ts.to(DEV), return_dict=False,
+          eval=True, image_rotary_emb=tuple(x.to(DEV) for x in rope), ref_image_rotary_emb=tuple(x.to(DEV) for x in ref_rope))[0]
+    torch.cuda.synchronize()
+    ocfg = dict(num_heads=cfg.num_attention_heads, num_layers=1, use_rope=True, norm_eps=1e-5)
+    merged_bf = tr.merge_lora({k: v.to(dt) for k, v in sd.items()}, lora, 0.5)  # merge in fp32, round to bf16: what the engine stores
+    with torch.no_grad():
+        exp = tr.transformer_forward(merged_bf, ocfg, lat, text, ref, ts, rope, ref_rope).float()
+        base = tr.transformer_forward({k: v.to(dt) for k, v in sd.items()}, ocfg, lat, text, ref, ts, rope, ref_rope).float()
+    rel = ((y.float().cpu() - exp).norm() / exp.norm()).item()
+    moved = ((base - exp).norm() / exp.norm()).item()
+    assert rel <= 2e-2, rel
+    assert moved >= 5 * rel, f"the adapter's effect ({moved:.3e}) must stand clear of the tolerance ({rel:.3e})"
+
+
+def test_t5_ingest_from_transformers_layout(s2v, tmp_path):
+    """src/inference.py:177-189: T5EncoderModel.from_pretrained(subfolder="text_encoder") + resize_token_embeddings(len(tokenizer)):
+    sharded `model-0000k-of-0000n.safetensors`, tied `encoder.embed_tokens.weight` copy, decoder tensors of a full checkpoint ignored,
+    the table truncated to the tokenizer's length.  Bitwise equal to the state-dict hand-over of the truncated weights; fp32 vs oracle."""
+    from oracle import t5_ref
+
+    cfgd = dict(vocab_size=100, d_model=128, d_kv=64, num_heads=2, d_ff=256, num_layers=2, relative_attention_num_buckets=32,
+                relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
+    sd = s2v.weights.synthetic_t5_state_dict(s2v.T5Config(**cfgd), seed=51)
+    files = dict(sd)
+    files["encoder.embed_tokens.weight"] = sd["shared.weight"].clone()
+    files["decoder.final_layer_norm.weight"] = torch.ones(128)
+    files["lm_head.weight"] = torch.zeros(100, 128)
+    d = tmp_path / "text_encoder"
+    d.mkdir()
+    keys = sorted(files)
+    wmap = {}
+    for i in range(2):
+        name = f"model-{i + 1:05d}-of-00002.safetensors"
+        part = {k: files[k].contiguous() for k in keys[i::2]}
+        save_file(part, str(d / name))
+        wmap.update({k: name for k in part})
+    (d / "model.safetensors.index.json").write_text(json.dumps({"weight_map": wmap}))
+    (d / "config.json").write_text(json.dumps({**cfgd, "feed_forward_proj": "gated-gelu", "model_type": "t5", "num_decoder_layers": 2}))
+    n_tok = 93  # len(tokenizer) after `<cls>`: smaller than the checkpoint's table, as 32 101 < 32 128 for the shipped model
+    m1 = ck.load_t5(str(d), torch.float32, DEV, num_tokens=n_tok)
+    assert m1.cfg.vocab_size == n_tok and m1.cfg.d_ff == 256
+    cfg2 = dict(cfgd, vocab_size=n_tok)
+    sd2 = dict(sd)
+    sd2["shared.weight"] = sd["shared.weight"][:n_tok].contiguous()
+    m2 = s2v.HipT5EncoderModel(s2v.T5Config(**cfg2), torch.float32, DEV)
+    m2.load_state_dict(sd2)
+    ids = torch.randint(0, n_tok, (2, 17), generator=torch.Generator().manual_seed(52))
+    ids[0, 3] = n_tok - 1  # the `<cls>` id = the last kept row
+    y1, y2 = m1(ids.to(DEV))[0], m2(ids.to(DEV))[0]
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2)
+    with torch.no_grad():
+        exp = t5_ref.encoder_forward(sd2, cfg2, ids).float()
+    assert (y1.cpu() - exp).abs().max().item() <= 1e-3
+    with pytest.raises(ValueError, match="grows the table"):
+        ck.load_t5(str(d), torch.float32, DEV, num_tokens=101)
+
+
+def test_full_vae_ingest_both_halves(s2v, tmp_path):
+    """src/inference.py:201,231 loads the whole AutoencoderKLCogVideoX; src/video_generate.py:26-38 runs its ENCODER on the reference image"""
+    cfgd = dict(block_out_channels=(16, 16, 32, 32), layers_per_block=1, norm_num_groups=4, latent_channels=16,
+                sample_height=96, sample_width=160, scaling_factor=0.7, temporal_compression_ratio=4)
+    cfg = s2v.VAEConfig(**cfgd)
+    sd = {**s2v.weights.synthetic_vae_state_dict(cfg, seed=31), **s2v.weights.synthetic_vae_encoder_state_dict(cfg, seed=33)}
+    (tmp_path / "vae").mkdir()
+    save_file({k: v.contiguous() for k, v in sd.items()}, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
+    v1 = s2v.HipAutoencoderKLCogVideoX(cfg, torch.float32, DEV)
+    assert ck.load_vae(v1, str(tmp_path / "vae")) == ["decoder", "encoder"]
+    assert v1.arenas_loaded() == [True, True]
+    v2 = s2v.HipAutoencoderKLCogVideoX(cfg, torch.float32, DEV)
+    v2.load_state_dict(sd)
+    lat = torch.randn(1, 3, 16, 12, 20, generator=torch.Generator().manual_seed(32))
+    img = torch.rand(1, 3, 1, 96, 160, generator=torch.Generator().manual_seed(34)) * 2 - 1
+    assert torch.equal(v1.decode_latents(lat.to(DEV)), v2.decode_latents(lat.to(DEV)))
+    z1 = v1.encode(img.to(DEV)).latent_dist.sample(generator=torch.Generator().manual_seed(1))
+    z2 = v2.encode(img.to(DEV)).latent_dist.sample(generator=torch.Generator().manual_seed(1))
+    torch.cuda.synchronize()
+    assert torch.equal(z1, z2)
+    v3 = s2v.HipAutoencoderKLCogVideoX(cfg, torch.float32, DEV)
+    assert ck.load_vae(v3, str(tmp_path / "vae"), with_encoder=False) == ["decoder"]
+    assert v3.arenas_loaded() == [True, False]
+    with pytest.raises(s2v._lib.S2VError, match="no `encoder"):
+        v3.encode(img.to(DEV))
+    save_file({**{k: v.contiguous() for k, v in sd.items()}, "quant_conv.weight": torch.zeros(2)}, str(tmp_path / "vae" / "diffusion_pytorch_model.safetensors"))
+    with pytest.raises(ValueError, match="outside encoder / decoder"):
+        ck.load_vae(v3, str(tmp_path / "vae"))

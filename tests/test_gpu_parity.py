@@ -522,3 +522,47 @@ def test_op_mod_gemv_register_form_equals_the_row_form_and_the_fp64_sum(s2v, B, 
     x = torch.nn.functional.silu(emb.float()).bfloat16().double()
     ref = x @ W.double().T + bias.double()
     assert (got - ref).abs().max().item() <= 2 ** -7 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("mode", ["fused_graph", "seams"])
+def test_pipeline_callback_overrides_are_honoured(s2v, mode):
+    """custom_cogvideox_pipe.py:298-305: what `callback_on_step_end` returns replaces `latents` and `prompt_embeds` (the concatenated
+    [negative | positive] pair at that point of the loop, :196) for the following steps.  The reference's own branch cannot be put in
+    a fixture (`locals()` inside a comprehension: KeyError under Python < 3.12), so the expectation is the oracle loop with the same
+    two overrides applied after step 0; fused mode must keep its one latent buffer (captured graph) and re-project the new text."""
+    from oracle import sched_ref
+
+    g = load_golden("pipeline_tiny.npz")
+    pipe = _pipe_from_golden(s2v, g, "ddim")
+    seen = []
+
+    def on_step(p_, i, tt, kw):
+        seen.append(sorted(kw))
+        if i == 0:
+            return {"latents": kw["latents"] * 0.5 + 0.1, "prompt_embeds": kw["prompt_embeds"].flip(0)}
+        return {}
+
+    out = pipe(output_type="latent", fused=mode != "seams", use_graph=mode == "fused_graph", callback_on_step_end=on_step,
+               callback_on_step_end_tensor_inputs=["latents", "prompt_embeds"], **_pipe_args(g))[0]
+    torch.cuda.synchronize()
+    assert seen == [["latents", "prompt_embeds"]] * 3
+    sd = weights_of(g)
+    cfg = dict(num_heads=2, num_layers=2, use_rope=True, norm_eps=1e-5)
+    cfg["num_heads"] = pipe.transformer.cfg.num_attention_heads
+    cfg["num_layers"] = pipe.transformer.cfg.num_layers
+    pe, ne, ref, lat = t(g["prompt_embeds"]), t(g["negative_prompt_embeds"]), t(g["ref"]), t(g["latents0"])
+    text = torch.cat([ne, pe], dim=0)
+    ref_rope, rope = tr.pipeline_rope(480, 720, lat.shape[1])
+    ac = sched_ref.alphas_cumprod(1.0)
+    with torch.no_grad():
+        for i, tt in enumerate(sched_ref.trailing_timesteps(3)):
+            npred = tr.transformer_forward(sd, cfg, torch.cat([lat] * 2), text, ref, torch.tensor([tt, tt]), rope, ref_rope)
+            lat, _ = sched_ref.ddim_step(ac, 3, sched_ref.cfg_combine(npred, 6.0), int(tt), lat)
+            lat = lat.float()
+            if i == 0:
+                lat, text = lat * 0.5 + 0.1, text.flip(0)
+    err = (out.float().cpu() - lat).abs().max().item()
+    assert err <= 1e-3, err
+    assert (lat - t(g["final_ddim"])).abs().max().item() > 1e-2, "the overrides must change the result"
+    with pytest.raises(ValueError, match="callback_on_step_end_tensor_inputs"):
+        pipe(output_type="latent", callback_on_step_end=on_step, callback_on_step_end_tensor_inputs=["noise_pred"], **_pipe_args(g))

@@ -164,3 +164,31 @@ def test_frames_uint8_matches_export_to_video_conversion(s2v):
     if out.endswith(".avi"):  # no imageio-ffmpeg on the box: Motion-JPEG AVI with the same frames
         n, fps, w, h, first = s2v.video_generate.read_avi_info(out)
         assert (n, w, h) == (u8.shape[0], u8.shape[2], u8.shape[1]) and fps == 8.0
+
+
+def test_tiled_decode_workspace_byte_cap_and_regrowth(s2v, monkeypatch):
+    """prepare_tile_capacity: the number of workspace sets (tiles in flight) is bounded by S2V_VAE_WORKSPACE_MAX_GB as well as
+    by the free memory; capacity is committed only after its sets exist, so a context that was granted ONE set decodes (bit-identically
+    to six in flight) and grows when a later, larger window asks for more"""
+    import os
+
+    g = load_golden("vae_tiny.npz")
+    lat = t(g["latents"]).to(DEV)
+    free = make_vae(s2v, TINY, torch.float32, weights_of(g))
+    free.enable_tiling()
+    y_free = free.decode_latents(lat)
+    n_free, set_bytes = free.workspace_info()
+    assert n_free >= 2 and set_bytes > 0
+    monkeypatch.setenv("S2V_VAE_WORKSPACE_MAX_GB", str(1.5 * set_bytes / 1e9))
+    capped = make_vae(s2v, TINY, torch.float32, weights_of(g))
+    capped.enable_tiling()
+    y_cap = capped.decode_latents(lat)
+    torch.cuda.synchronize()
+    assert capped.workspace_info()[0] == 1
+    assert torch.equal(y_cap, y_free)
+    monkeypatch.delenv("S2V_VAE_WORKSPACE_MAX_GB")
+    capped.disable_tiling()      # the untiled decode needs a larger window: the workspace is rebuilt, and the decode is the golden one
+    y_un = capped.decode_latents(lat).cpu()
+    assert np.abs(y_un[..., ::3, ::3].numpy() - g["dec_untiled_s3"]).max() <= 1e-3
+    capped.enable_tiling()
+    assert torch.equal(capped.decode_latents(lat), y_free)
