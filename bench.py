@@ -287,6 +287,8 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-vae", action="store_true", help="skip the one-off VAE decode timing")
+    ap.add_argument("--native-bcast", action="store_true", help="N > 1: replicate the weights with the library's own RCCL communicator "
+                    "(s2v_bcast_weights) instead of torch.distributed.broadcast")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -332,11 +334,19 @@ def main(argv=None):
         torch.cuda.synchronize()
         dist.barrier()  # also the communicator's first collective: its lazy set-up stays out of the broadcast time
         tb = time.time()
-        bcast_bytes = s2v.dist.broadcast_arena(eng.weight_arena(), 0)
+        if args.native_bcast:
+            comm = s2v.dist.RcclComm()
+            torch.cuda.synchronize()
+            dist.barrier()
+            tb = time.time()  # the communicator's set-up stays out of the broadcast time, as on the other path
+            comm.broadcast_weights(eng, 0)  # receivers are marked loaded by the library
+            bcast_bytes = eng.weight_arena().numel()
+        else:
+            bcast_bytes = s2v.dist.broadcast_arena(eng.weight_arena(), 0)
         torch.cuda.synchronize()
         dist.barrier()
         bcast_s = time.time() - tb
-        if rank != 0:
+        if rank != 0 and not args.native_bcast:
             eng.mark_weights_loaded()
     t_load = time.time() - t_load
 
@@ -535,6 +545,7 @@ def main(argv=None):
                        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 2),
                        "per_gpu_steps_per_s": round(total_steps / elapsed / n_devices, 4),
                        "lora_merged": f"rank-128 synthetic adapter on {n_lora} weights (alpha / r = 0.5)" if n_lora else None, "weight_load_s": round(t_load, 2), "weight_broadcast_s": None if bcast_s is None else round(bcast_s, 3),
+                       "weight_broadcast_via": None if bcast_s is None else ("s2v_bcast_weights (the library's own RCCL communicator)" if args.native_bcast else f"torch.distributed.broadcast ({dist.get_backend()}), 256-MiB chunks"),
                        "weight_broadcast_gb": None if not bcast_bytes else round(bcast_bytes / 1e9, 3),
                        "weight_broadcast_gb_per_s": None if not bcast_s else round(bcast_bytes / bcast_s / 1e9, 1),
                        "xgmi_link_bound_gb_per_s": 153.0 if world > 1 else None,

@@ -62,6 +62,13 @@ _SIGS = {
     "s2v_op_attention": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
     "s2v_op_linear_fp8": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P],
 }
+# replicas over RCCL behind the C ABI (csrc/rccl.hip); RCCL itself is bound at first use
+_SIGS.update({
+    "s2v_rccl_unique_id": [_P],
+    "s2v_rccl_comm_create": [_P, _I32, _I32, ctypes.POINTER(_P)],
+    "s2v_rccl_bcast": [_P, _P, _I64, _I32, _P],
+    "s2v_bcast_weights": [_P, _P, _I32, _P],
+})
 # VAE entry points are registered by vae.py through register_sigs()
 
 
@@ -91,6 +98,8 @@ def lib():
         l.s2v_version.restype = ctypes.c_char_p
         l.s2v_destroy.argtypes = [_P]
         l.s2v_destroy.restype = None
+        l.s2v_rccl_comm_destroy.argtypes = [_P]
+        l.s2v_rccl_comm_destroy.restype = None
         _lib = l
     return _lib
 

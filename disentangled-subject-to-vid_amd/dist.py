@@ -43,12 +43,65 @@ def broadcast_arena(arena, src=0, chunk_bytes=256 << 20):
     return n
 
 
-def broadcast_components(components, src=0):
+class RcclComm:
+    """the library's OWN RCCL communicator (csrc/rccl.hip: s2v_rccl_*): the weight broadcast without torch.distributed in the data
+    path -- what a C / C++ host of libs2v_hip.so would do.  torch.distributed (any backend, gloo included) only carries the 128-byte
+    unique id from rank 0 to the others.  One process per GPU; the communicator binds to the CURRENT device."""
+
+    def __init__(self, rank=None, world=None, device=None):
+        import ctypes
+
+        from . import _lib
+
+        self.rank = dist.get_rank() if rank is None else rank
+        self.world = dist.get_world_size() if world is None else world
+        if device is not None:
+            torch.cuda.set_device(device)
+        buf = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            _lib.check(_lib.lib().s2v_rccl_unique_id(buf))
+        box = [buf.raw if self.rank == 0 else None]
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0)
+        self._h = ctypes.c_void_p()
+        _lib.check(_lib.lib().s2v_rccl_comm_create(ctypes.create_string_buffer(box[0], 128), self.rank, self.world, ctypes.byref(self._h)))
+
+    def broadcast(self, arena, src=0):
+        """in place on torch's current stream; returns the bytes moved"""
+        from . import _lib
+
+        flat = arena.view(-1)
+        _lib.check(_lib.lib().s2v_rccl_bcast(self._h, _lib.ptr(flat), flat.numel() * flat.element_size(), src, _lib.stream_ptr()))
+        return flat.numel() * flat.element_size()
+
+    def broadcast_weights(self, engine, src=0):
+        """s2v_bcast_weights: the transformer engine's arena, receivers marked loaded by the library itself"""
+        from . import _lib
+
+        _lib.check(_lib.lib().s2v_bcast_weights(engine._h, self._h, src, _lib.stream_ptr()))
+
+    def close(self):
+        from . import _lib
+
+        if self._h:
+            _lib.lib().s2v_rccl_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def broadcast_components(components, src=0, comm=None):
     """replicate every component of the path -- transformer engine, VAE (decoder [+ encoder]), T5 encoder: anything with
     .weight_arenas() -> [uint8 tensors] and .mark_weights_loaded() -- rank `src` -> all.  Returns the bytes moved.
     A component may also expose .arenas_loaded() -> [bool per arena] (the VAE: its encoder half exists on every replica but is
     only filled when the sender loaded `encoder.*` weights): the sender's flags travel first, an arena the sender never filled is
-    not sent, and the receiver is told exactly which arenas now hold weights (mark_weights_loaded(loaded=flags))."""
+    not sent, and the receiver is told exactly which arenas now hold weights (mark_weights_loaded(loaded=flags)).
+    comm: an RcclComm -- the arenas then travel through the library's own RCCL communicator (s2v_rccl_bcast) instead of
+    torch.distributed.broadcast; the small flag objects still use torch.distributed."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
     total = 0
@@ -62,7 +115,7 @@ def broadcast_components(components, src=0):
             raise RuntimeError(f"replica mismatch: sender has {len(flags)} weight arenas, this rank built {len(arenas)}")
         for i, arena in enumerate(arenas):
             if flags is None or flags[i]:
-                total += broadcast_arena(arena, src)
+                total += comm.broadcast(arena, src) if comm is not None else broadcast_arena(arena, src)
         if me != src:
             if flags is None:
                 c.mark_weights_loaded()

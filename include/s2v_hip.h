@@ -160,6 +160,21 @@ S2V_API int s2v_profile_read(s2v_ctx* ctx, float* ms_by_class, int32_t* launches
 /* Marks every tensor as loaded on a replica whose arena was filled by a broadcast of s2v_weight_arena. */
 S2V_API int s2v_mark_weights_loaded(s2v_ctx* ctx);
 
+/* ---- replicas over RCCL: one process per GPU, ONE collective -- the weight broadcast root -> all ----------
+ * No reference code (the reference is single-process); replaces what a maintainer would otherwise write around
+ * torch.distributed.broadcast.  RCCL is bound at first use (dlopen librccl.so.1; a process that already loaded PyTorch-ROCm's copy
+ * shares it); every call fails with a message when it is absent.  Protocol: the root calls s2v_rccl_unique_id, ships the 128 bytes
+ * to the other ranks by any means (a file, a socket, torch.distributed's store), every rank -- with ITS GPU current -- calls
+ * s2v_rccl_comm_create, then s2v_bcast_weights / s2v_rccl_bcast on a stream of that GPU. */
+typedef struct s2v_rccl_comm s2v_rccl_comm;
+S2V_API int s2v_rccl_unique_id(void* id128 /* out: 128 bytes */);
+S2V_API int s2v_rccl_comm_create(const void* id128, int32_t rank, int32_t world, s2v_rccl_comm** out);
+S2V_API void s2v_rccl_comm_destroy(s2v_rccl_comm* comm);
+/* any device range (s2v_vae_weight_arena, s2v_t5_weight_arena ...), in place, asynchronous on `stream`, 256-MiB collectives */
+S2V_API int s2v_rccl_bcast(s2v_rccl_comm* comm, void* dev_ptr, int64_t bytes, int32_t root, s2v_stream stream);
+/* the transformer's finalized arena (merged LoRA, fused QKV, fp8 copies + scales) root -> all; receivers are marked loaded */
+S2V_API int s2v_bcast_weights(s2v_ctx* ctx, s2v_rccl_comm* comm, int32_t root, s2v_stream stream);
+
 /* ---- CogVideoX 3-D causal VAE decode ------------------------------------------------------------------------- */
 typedef struct s2v_vae s2v_vae;
 /* AutoencoderKLCogVideoX.__init__ (models/autoencoders/autoencoder_kl_cogvideox.py:1020-1052), decoder part */
