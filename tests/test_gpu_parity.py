@@ -547,9 +547,7 @@ def test_pipeline_callback_overrides_are_honoured(s2v, mode):
     torch.cuda.synchronize()
     assert seen == [["latents", "prompt_embeds"]] * 3
     sd = weights_of(g)
-    cfg = dict(num_heads=2, num_layers=2, use_rope=True, norm_eps=1e-5)
-    cfg["num_heads"] = pipe.transformer.cfg.num_attention_heads
-    cfg["num_layers"] = pipe.transformer.cfg.num_layers
+    cfg = dict(num_heads=2, num_layers=2, use_rope=True, norm_eps=1e-5)  # s2v.tiny(), as _pipe_from_golden builds it
     pe, ne, ref, lat = t(g["prompt_embeds"]), t(g["negative_prompt_embeds"]), t(g["ref"]), t(g["latents0"])
     text = torch.cat([ne, pe], dim=0)
     ref_rope, rope = tr.pipeline_rope(480, 720, lat.shape[1])
