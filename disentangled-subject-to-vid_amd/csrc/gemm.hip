@@ -1178,10 +1178,13 @@ static int launch_stag_t(const GemmArgs& a, hipStream_t st) {
 #ifdef S2V_DIAG
 int g_gemm_ablate = 0;
 int g_gemm_impl = 9;  // 9: gemm_g4 where it qualifies, gemm_bf16_pp64 otherwise (the product's choice); 7: gemm_bf16_pp64; 5 / 8: A/B references
+int g_gemm_g4t = 1;   // the persistent trickled-epilogue form of gemm_g4 where it qualifies (s2v_set_gemm_g4t: A/B switch of the diagnostics build)
+extern "C" __attribute__((visibility("default"))) int s2v_set_gemm_g4t(int on) { g_gemm_g4t = on; return 0; }
 extern "C" __attribute__((visibility("default"))) int s2v_set_gemm_impl(int impl) { g_gemm_impl = impl & 0xff; g_gemm_ablate = impl >> 8; return 0; }
 #else
 static constexpr int g_gemm_ablate = 0;
 static constexpr int g_gemm_impl = 9;  // 9: gemm_g4 where it qualifies, gemm_bf16_pp64 otherwise (the product's choice); 7: gemm_bf16_pp64; 5 / 8: A/B references
+static constexpr int g_gemm_g4t = 1;
 #endif
 
 template <int EPI>
@@ -1265,6 +1268,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     // code, bit-identical results
     if (epi == EPI_BIAS_GELU && a.splitk <= 1 && a.K <= 2048 && out_tiles <= 2 * cus) g4_epi = false;
     const bool big_tiles = a.tile == 0 || a.conv || epi == EPI_BIAS_QKNORM;  // GemmArgs::tile: the caller asks for smaller tiles
+    if (g_gemm_impl == 9 && g_gemm_g4t && big_tiles && w_tile_ok(a) && gemm_g4_ok(a, epi) && gemm_g4t_ok(a, epi, (int)cus)) return launch_gemm_g4t(a, epi, st);
     if (g_gemm_impl == 9 && big_tiles && g4_epi && w_tile_ok(a) && gemm_g4_ok(a, epi)) return launch_gemm_g4(a, epi, st);  // four-wave generated-asm K loop
     if ((g_gemm_impl == 7 || g_gemm_impl == 8 || g_gemm_impl == 9) && big_tiles && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");

@@ -80,6 +80,10 @@ int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st);  
 // gemm_g4.hip: 256 x 256 tiles, four waves, generated-asm K loop (plain bf16 operands; gemm_g4_ok says whether a call qualifies)
 bool gemm_g4_ok(const GemmArgs& a, int epi);
 int launch_gemm_g4(const GemmArgs& a, int epi, hipStream_t st);
+// gemm_g4t.hip: the same tiles as a persistent kernel whose epilogue is trickled through the next tile's K loop (gen_gemm_g4t.py);
+// bias / bias + GELU epilogues on whole 256 x 256 tiles with at least two rounds of them on `ncu` CUs
+bool gemm_g4t_ok(const GemmArgs& a, int epi, int ncu);
+int launch_gemm_g4t(const GemmArgs& a, int epi, hipStream_t st);
 // Few tiles and a long reduction (C1: the FF2 is 80 tiles of 120 K-tiles -- one K loop is 130 us however many CUs idle; the T5 encoder
 // at M = 452: 32-96 tiles): split K over S workgroups per tile (GemmArgs::splitk), S the largest count <= 4 that still fits one round
 // of `ncu` CUs and leaves an even number >= 16 of K-tiles per workgroup (below that the fp32 partial traffic costs what the shorter

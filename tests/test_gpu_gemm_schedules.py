@@ -67,6 +67,41 @@ def test_g4_generated_asm_kernel_matches_ring_bitwise_and_is_repeatable(s2v, M, 
         assert torch.equal(out, ref), f"rep {rep}: max diff {(out.float() - ref.float()).abs().max().item()}"
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 4096, 1280), (9472, 3840, 1920), (8192, 4096, 3072), (6144, 7680, 12288)])
+@pytest.mark.parametrize("epi", [0, 1])
+def test_g4t_trickled_epilogue_kernel_is_bit_identical_to_g4(s2v, M, N, K, epi):
+    """gemm_g4t (gemm_g4t.hip / gen_gemm_g4t.py: persistent, the previous tile's epilogue -- bias, rounding, GELU, LDS transposition,
+    stores -- trickled through the MFMA gaps of the next tile's K loop, in generated asm; the product's kernel for the FF1 projection,
+    attention.py:1237-1243) against gemm_g4 with the C++ epilogue: same products, same accumulation order, the same epilogue
+    arithmetic instruction for instruction -> BIT-IDENTICAL, launch after launch, product build and diagnostics build.  Shapes: the
+    minimum depth (K = 1280: the unrolled trickle is the whole loop), the 2B model's K = 1920 on a tile count that does not divide by
+    the XCDs (37 x 15 = 555 tiles: uneven ranges, workgroups with two and three tiles), the C3 depths 3072 and 12288."""
+    import ctypes
+
+    L = s2v._lib
+    D = L.diag_lib()
+    D.s2v_set_gemm_g4t.argtypes = [ctypes.c_int]
+    g = torch.Generator().manual_seed(M + N + K + 2)
+    A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).bfloat16().to(DEV)
+    b = (torch.randn(N, generator=g) * 0.2).bfloat16().to(DEV)
+    try:
+        D.s2v_set_gemm_g4t(0)
+        ref = run(L, A, W, b, M, N, K, epi, 9)  # gemm_g4
+        assert torch.isfinite(ref.float()).all()
+        D.s2v_set_gemm_g4t(1)
+        for rep in range(4):
+            out = run(L, A, W, b, M, N, K, epi, 9 if rep % 2 else None)  # gemm_g4t: diagnostics build / product build
+            assert torch.equal(out, ref), f"rep {rep}: {(out != ref).sum().item()} elements differ, max {(out.float() - ref.float()).abs().max().item()}"
+    finally:
+        D.s2v_set_gemm_g4t(1)
+    y = A.float() @ W.float().T + b.float()
+    if epi == 1:
+        y = torch.nn.functional.gelu(y.bfloat16().float(), approximate="tanh")
+    rel = ((ref.float() - y).norm() / y.norm()).item()
+    assert rel <= 1e-2, rel
+
+
 @pytest.mark.parametrize("epi", [0, 1])
 def test_four_wave_persistent_kernel_matches_pingpong(s2v, epi):
     """gemm_q4 (diagnostics build only: persistent 4-wave kernel whose epilogue trickles through the next tile's K loop): 1536
