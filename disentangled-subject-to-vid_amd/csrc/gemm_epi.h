@@ -66,6 +66,18 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, const
     }
 }
 
+// v + v[lane ^ 1], then + [lane ^ 2], then + [lane ^ 4]: the sum over the 8 lanes that hold one 64-column row, the same additions in the
+// same order as three __shfl_xor steps -- but as DPP operands (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror: after the two
+// quad steps every lane of a quad holds the quad's sum, and lane i's mirror 7 - i sits in the other quad) instead of three ds_bpermute
+// round trips through the LDS crossbar, each behind its own s_waitcnt lgkmcnt(0): 192 of them per q / k wave tile were ~20 k of the
+// ~37 k exposed cycles of a QKV tile's epilogue on a wave that has its SIMD to itself
+__device__ __forceinline__ float oct_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true));
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, true));
+    return v;
+}
+
 // bias of a wave's 64 columns, 4 per lane and (i, rq).  The whole-tile case is ONE clause of eight independent loads (a per-load
 // bounds branch serialised them: eight global latencies, ~6000 cycles of a 128 x 64 epilogue)
 __device__ __forceinline__ void load_bias64(const GemmArgs& a, int nw, int hi, u32x2 (&bvec)[8]) {
@@ -200,12 +212,12 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
                 float s = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += x[e];
-                s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+                s = oct_sum(s);
                 const float mean = s * (1.0f / 64.0f);
                 float q = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { const float d = x[e] - mean; q += d * d; }
-                q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64); q += __shfl_xor(q, 4, 64);
+                q = oct_sum(q);
                 const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + a.qk_eps);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = bf2f(f2bf((x[e] - mean) * rstd * qw[e] + qb[e]));
