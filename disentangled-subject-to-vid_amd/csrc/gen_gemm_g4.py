@@ -65,8 +65,21 @@ VREG, VWR = 100, 228                       # "reg": two sets of 16 pieces x 4 VG
 # QKV 2152 vs 2155 cycles per K-tile, out 2282 vs 2286, FF1 2188 vs 2203, FF2 2459 vs 2459): the W lead is not what the loop waits for.
 # Kept as an option (default off: the body is byte-identical to the round's product loop).
 W3 = os.environ.get("G4_W3", "0") == "1"
+# G4_A3 = 1: THREE stages for the A operand AND the issue order swapped (LDS: [A0 | A1 | A2 | W0 | W1] x 32 KiB).  vmcnt counts in issue order,
+# so an operand only gains lead if what is issued BEHIND it may stay in flight at the wait: the W pieces of K-tile t+2 go out in step 3 of K-tile
+# t (right behind the barrier that frees their stage), the A pieces of K-tile t+2 in step 0 of K-tile t (stage (t+2) % 3, free since the barrier
+# of K-tile t-1), and the wait of step 3 is vmcnt(8): K-tile t+1 has landed, the A pieces of K-tile t+2 are still on their way.  A then has
+# 1.75 K-tiles to arrive (two stages: 1.0), W 1.0 (0.75).  The A stage is run-time state as the W stage is under G4_W3 (same registers).
+# Measured (profiles/r04_gemm_g4_a3.txt, same box, cycles per K-tile, floor 2065): QKV 2153 -> 2130, out 2267 -> 2177, FF1 2193 -> 2158,
+# FF2 2439 -> 2141 (2.309 -> 2.160 ms, 1256 -> 1343 TFLOP/s); bit-identical.  The round-3 G4_W3 (three W stages) gave nothing because the A
+# pieces were issued behind the W pieces' wait: under an in-order counter the operand that is issued LAST before the wait gets the lead.
+# The activations (A) are the operand that streams from HBM (FF2: 0.94 GB); the weights come back from the MALL.
+A3 = os.environ.get("G4_A3", "1") == "1" and os.environ.get("G4_W3", "0") != "1" and os.environ.get("G4_STAGE", "dma") == "dma"  # the product loop since round 4
+assert not (A3 and W3)
 S_WNEXT, S_WDMA, S_WM0, WBASE = 42, 43, 48, 100
-A_STRIDE, W_BASE, W_STRIDE = (32768, 65536, 32768) if W3 else (65536, 32768, 65536)
+A_STRIDE, W_BASE, W_STRIDE = (32768, 65536, 32768) if W3 else (32768, 98304, 32768) if A3 else (65536, 32768, 65536)
+A_POL = (" " + os.environ["G4_A_POL"]) if os.environ.get("G4_A_POL") else ""   # cache-policy bits of the A / W pieces (nt, sc0, sc1): an experiment switch
+W_POL = (" " + os.environ["G4_W_POL"]) if os.environ.get("G4_W_POL") else ""
 PF = int(os.environ.get("G4_PF", "0"))  # K-tiles between the L2 prefetch of a tile and its staging (0: none -- the default, see above); even
 
 
@@ -91,6 +104,8 @@ def vaddr(is_w, g, s):
 
 
 def ktile(emit, g, first=False, dma_w=True, dma_a=True, last=False, prefetch=False):
+    if A3:
+        return ktile_a3(emit, g, first, dma_w, dma_a, last)
     for s in range(4):
         cur, nxt = s & 1, (s & 1) ^ 1
         if s == 3 and not last:
@@ -119,14 +134,14 @@ def ktile(emit, g, first=False, dma_w=True, dma_a=True, last=False, prefetch=Fal
                     else:
                         emit(f"s_add_u32 m0, s{S_M0W}, {(g ^ 1) * 65536 + 32768 + p * 4096}")
                 else:
-                    emit(f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]")
+                    emit(f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]{W_POL}")
             if W3 and s == 1 and not last and k >= 12:  # W fragment addresses of K-tile t+1 (set g^1, idle since step 3 of K-tile t-1)
                 emit(f"v_add_u32 {vr(vaddr(True, g ^ 1, k - 12))}, s{S_WNEXT}, {vr(WBASE + k - 12)}")
             if s == 3 and dma_a:  # A piece p of K-tile t+2 -> stage g
                 if k & 1 == 0:
                     emit(f"s_add_u32 m0, s{S_M0W}, {g * A_STRIDE + p * 4096}")
                 else:
-                    emit(f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]")
+                    emit(f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]{A_POL}")
             if s == 1 and prefetch and PF:  # the A pointer is at K-tile t+2, the W pointer (advanced in step 0) too
                 if k == 3:
                     emit(f"global_load_dword {vr(VPFD)}, {vr(VPF)}, s[{S_A}:{S_A + 1}] offset:{(PF - 2) * 128}")
@@ -143,6 +158,56 @@ def ktile(emit, g, first=False, dma_w=True, dma_a=True, last=False, prefetch=Fal
         if s == 3 and dma_a:
             emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
             emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
+
+
+def ktile_a3(emit, g, first, dma_w, dma_a, last):
+    """K-tile t under G4_A3 (stage parity g = t & 1 for W and for the fragment-address register set; the A stage is run-time):
+    step 0: A pieces of K-tile t+2 -> A stage s43;  step 1: A fragment addresses of K-tile t+1 = s42 + stage-0 addresses, then rotate;
+    step 3: vmcnt(8) [the A pieces just issued stay in flight] + barrier, then W pieces of K-tile t+2 -> W stage g"""
+    for s in range(4):
+        cur, nxt = s & 1, (s & 1) ^ 1
+        if s == 3 and not last:
+            emit(f"s_waitcnt vmcnt({8 if dma_a else 0}) lgkmcnt(0)")
+            emit("s_barrier")
+        else:
+            emit("s_waitcnt lgkmcnt(0)")
+        if s == 0 and dma_a:
+            emit(f"s_add_u32 s{S_WM0}, s{S_M0W}, s{S_WDMA}")
+        for k in range(16):
+            i, j = k >> 2, k & 3
+            acc = ar(ACC + 64 * i + 16 * j, 16)
+            c = "0" if (first and s == 0) else acc
+            emit(f"v_mfma_f32_32x32x16_bf16 {acc}, {vr(wf(cur, i), 4)}, {vr(af(cur, j), 4)}, {c}")
+            if k < 8 and not (last and s == 3):
+                gs, ss = (g, s + 1) if s < 3 else (g ^ 1, 0)
+                if k < 4:
+                    emit(f"ds_read_b128 {vr(wf(nxt, k), 4)}, {vr(vaddr(True, gs, ss))} offset:{k * 4096}")
+                else:
+                    emit(f"ds_read_b128 {vr(af(nxt, k - 4), 4)}, {vr(vaddr(False, gs, ss))} offset:{(k - 4) * 4096}")
+            p = k >> 1
+            if s == 0 and dma_a:  # A piece p of K-tile t+2 -> A stage (t+2) % 3
+                if k & 1 == 0:
+                    emit(f"s_add_u32 m0, s{S_WM0}, {p * 4096}")
+                else:
+                    emit(f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]{A_POL}")
+            if s == 1 and not last and k >= 12:  # A fragment addresses of K-tile t+1 (set g^1, idle since step 3 of K-tile t-1)
+                emit(f"v_add_u32 {vr(vaddr(False, g ^ 1, k - 12))}, s{S_WNEXT}, {vr(WBASE + k - 12)}")
+            if s == 3 and dma_w:  # W piece p of K-tile t+2 -> W stage g (free since this step's barrier)
+                if k & 1 == 0:
+                    emit(f"s_add_u32 m0, s{S_M0W}, {W_BASE + g * W_STRIDE + p * 4096}")
+                else:
+                    emit(f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]{W_POL}")
+        if s == 0 and dma_a:
+            emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
+            emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
+        if s == 1 and not last:  # rotate the A stages: K-tile t+2 reads what this K-tile's DMA wrote
+            emit(f"s_mov_b32 s{S_WNEXT}, s{S_WDMA}")
+            emit(f"s_add_u32 s{S_WDMA}, s{S_WDMA}, {A_STRIDE}")
+            emit(f"s_cmp_ge_u32 s{S_WDMA}, {3 * A_STRIDE}")
+            emit(f"s_cselect_b32 s{S_WDMA}, 0, s{S_WDMA}")
+        if s == 3 and dma_w:
+            emit(f"s_add_u32 s{S_W}, s{S_W}, 128")
+            emit(f"s_addc_u32 s{S_W + 1}, s{S_W + 1}, 0")
 
 
 REGV = int(os.environ.get("G4_REGV", "0"))  # "reg" placement: 0 = loads dense in step 0, writes dense in step 2; 1 = loads one per two MFMAs over steps 0-1; 2 = + writes over steps 1-2
@@ -261,6 +326,8 @@ def gen():
         L.append(ln)
 
     emit("; ---- gemm_g4 K loop (generated by gen_gemm_g4.py; do not edit)")
+    if A3:
+        return gen_a3(emit, L)
     # prologue: K-tile 0 whole -> stage 0, A half of K-tile 1 -> stage 1 (its W half follows in step 0 of K-tile 0)
     for p in range(8):
         emit(f"s_add_u32 m0, s{S_M0W}, {p * 4096}")
@@ -325,6 +392,56 @@ def gen():
     emit("s_nop 15")
     # split K: this workgroup's partial tile goes to its slot (the stores read a[...] here, inside the statement that produced them:
     # as operands of a second statement the compiler copied all 256 accumulators out and back, with spills)
+    emit(f"s_cmp_lt_u32 s{S_SK + 2}, 2")
+    emit("s_cbranch_scc1 L_g4_end_%=")
+    for ln in gen_sk_store(f"s{S_SK}", f"s{S_SK + 1}", f"v{V_SK}"):
+        emit(ln)
+    emit("L_g4_end_%=:")
+    return L
+
+
+def gen_a3(emit, L):
+    """prologue of the G4_A3 loop: K-tiles 0 and 1 whole (A0, W0, A1, W1: 32 pieces); K-tile 2's A half follows in step 0 of K-tile 0"""
+    assert PF == 0
+    for t in range(2):
+        for p in range(8):
+            emit(f"s_add_u32 m0, s{S_M0W}, {t * A_STRIDE + p * 4096}")
+            emit("s_nop 0")
+            emit(f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]")
+        for p in range(8):
+            emit(f"s_add_u32 m0, s{S_M0W}, {W_BASE + t * W_STRIDE + p * 4096}")
+            emit("s_nop 0")
+            emit(f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]")
+        for sp in (S_A, S_W):
+            emit(f"s_add_u32 s{sp}, s{sp}, 128")
+            emit(f"s_addc_u32 s{sp + 1}, s{sp + 1}, 0")
+    emit(f"s_mov_b32 s{S_WNEXT}, {A_STRIDE}")
+    emit(f"s_mov_b32 s{S_WDMA}, {2 * A_STRIDE}")
+    for x in range(4):
+        emit(f"v_mov_b32 {vr(WBASE + x)}, {vr(vaddr(False, 0, x))}")
+    emit("s_waitcnt vmcnt(16)")  # K-tile 0 landed; K-tile 1 stays in flight
+    emit("s_barrier")
+    for n in range(8):
+        if n < 4:
+            emit(f"ds_read_b128 {vr(wf(0, n), 4)}, {vr(vaddr(True, 0, 0))} offset:{n * 4096}")
+        else:
+            emit(f"ds_read_b128 {vr(af(0, n - 4), 4)}, {vr(vaddr(False, 0, 0))} offset:{(n - 4) * 4096}")
+    emit("; K-tile 0")
+    ktile(emit, 0, first=True)
+    emit("L_g4_loop_%=:")
+    emit(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    emit("s_cbranch_scc1 L_g4_nopf_%=")
+    ktile(emit, 1)
+    ktile(emit, 0)
+    emit(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    emit("s_branch L_g4_loop_%=")
+    emit("L_g4_nopf_%=:")
+    ktile(emit, 1)                                   # K-tile nT-3: the last one that stages (A and W of K-tile nT-1)
+    ktile(emit, 0, dma_a=False, dma_w=False)         # K-tile nT-2
+    ktile(emit, 1, dma_w=False, dma_a=False, last=True)
+    emit("s_waitcnt vmcnt(0)")
+    emit("s_nop 15")
+    emit("s_nop 15")
     emit(f"s_cmp_lt_u32 s{S_SK + 2}, 2")
     emit("s_cbranch_scc1 L_g4_end_%=")
     for ln in gen_sk_store(f"s{S_SK}", f"s{S_SK + 1}", f"v{V_SK}"):
@@ -403,11 +520,11 @@ def main():
             for ln in body:
                 f.write('"' + ln + '\\n\\t"\n')
     clob = [f"v{r}" for r in range(0, 64)] + ([f"v{r}" for r in range(VREG, VWR + 2)] if STAGE == "reg" else [f"v{VPFD}", f"v{VPFD + 1}"])
-    if W3:
+    if W3 or A3:
         clob += [f"v{WBASE + x}" for x in range(4)] + [f"s{S_WNEXT}", f"s{S_WDMA}", f"s{S_WM0}"]
     with open(os.path.join(here, "gemm_g4_regs.h"), "w") as f:
         f.write("// generated by gen_gemm_g4.py: the physical registers the K loop of gemm_g4 owns, and its LDS size\n#pragma once\n")
-        f.write(f"#define G4_PF {PF}\n#define G4_LDS_BYTES {163840 if W3 else 131072}\n")
+        f.write(f"#define G4_PF {PF}\n#define G4_LDS_BYTES {163840 if (W3 or A3) else 131072}\n")
         f.write(f"#define G4_A_STRIDE {A_STRIDE}\n#define G4_W_BASE {W_BASE}\n#define G4_W_STRIDE {W_STRIDE}  // LDS map of the operand stages: A stage g at g * A_STRIDE, W stage h at W_BASE + h * W_STRIDE\n")
         for k in range(8):
             f.write(f'#define G4_ACC{k} "{{a[{32 * k}:{32 * k + 31}]}}"\n')

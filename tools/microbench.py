@@ -14,6 +14,8 @@ L = s2v._lib
 DEV = "cuda:0"
 LABELS = {0: "tile128x128", 2: "stag256x128", 5: "w8-lockstep", 7: "pp64-pingpong", 8: "q4-fourwave", 9: "g4-asm"}
 IMPLS = [int(x) for x in os.environ.get("S2V_IMPLS", "7,5").split(",")]
+if os.environ.get("S2V_NO_G4T") == "1":
+    L.diag_lib().s2v_set_gemm_g4t(0)  # impl 9 then means gemm_g4 itself, not the persistent gemm_g4t where that qualifies
 
 
 def timeit(fn, iters=10, warm=3):

@@ -15,6 +15,7 @@ DEV = "cuda:0"
 M = 38400
 lib = L.diag_lib()
 lib.s2v_g4_debug_read.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+lib.s2v_set_gemm_g4t(0)  # this tool reads gemm_g4's own stamps: keep the persistent gemm_g4t out of the routing
 for name, N, K, epi in (("qkv", 9216, 3072, 0), ("out", 3072, 3072, 0), ("ff1+gelu", 12288, 3072, 1), ("ff2", 3072, 12288, 0)):
     A = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
     W = (torch.randn(N, K, device=DEV) * 0.02).bfloat16()
