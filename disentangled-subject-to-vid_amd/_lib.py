@@ -6,7 +6,7 @@ import os
 import torch  # noqa: F401  (must be imported first so the process-wide HIP runtime is torch's libamdhip64)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libs2v_hip.so")
+LIB_PATH = os.environ.get("S2V_LIB") or os.path.join(_HERE, "libs2v_hip.so")  # S2V_LIB: an experiment build of the SAME library (tools/ab_step.sh)
 
 DTYPE_F32, DTYPE_BF16 = 0, 1
 TORCH_DTYPE = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16}

@@ -7,11 +7,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libs2v_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_g4.hip", "gemm_g4t.hip", "attention.hip", "attention_q4.hip", "elementwise.hip", "vae.hip", "vae_api.hip", "t5.hip", "rccl.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_g4.hip", "gemm_g4t.hip", "gemm_g4f.hip", "attention.hip", "attention_q4.hip", "elementwise.hip", "vae.hip", "vae_api.hip", "t5.hip", "rccl.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value", "-Wno-inline-asm"]
 # the HBM-bound kernels mirror the reference's separately-rounded elementwise ops: no fma contraction there
 # (hipcc defaults to -ffp-contract=fast); the scheduler step is bit-exact against the CPU reference because of it
-EXTRA = {"attention_q4.hip": ["-fno-slp-vectorize"], "gemm_g4.hip": ["-fno-slp-vectorize"], "gemm_g4t.hip": ["-fno-slp-vectorize"], "elementwise.hip": ["-ffp-contract=off", "-DS2V_TU_FP_CONTRACT_OFF"], "vae.hip": ["-ffp-contract=off", "-DS2V_TU_FP_CONTRACT_OFF"],
+EXTRA = {"attention_q4.hip": ["-fno-slp-vectorize"], "gemm_g4.hip": ["-fno-slp-vectorize"], "gemm_g4t.hip": ["-fno-slp-vectorize"], "gemm_g4f.hip": ["-fno-slp-vectorize"], "elementwise.hip": ["-ffp-contract=off", "-DS2V_TU_FP_CONTRACT_OFF"], "vae.hip": ["-ffp-contract=off", "-DS2V_TU_FP_CONTRACT_OFF"],
          "t5.hip": ["-ffp-contract=off", "-DS2V_TU_FP_CONTRACT_OFF"]}
 
 
@@ -59,7 +59,7 @@ def build_library(force=False, verbose=True, diag=False):
     objdir = os.path.join(HERE, "build_diag" if diag else "build")
     LIB = DIAG_LIB if diag else globals()["LIB"]
     FLAGS = globals()["FLAGS"] + (["-DS2V_DIAG"] if diag else [])
-    gens = [("gen_attn_q4.py", "attn_q4_body.inc"), ("gen_gemm_g4.py", "gemm_g4_body.inc"), ("gen_gemm_g4t.py", "gemm_g4t_body_gelu.inc")]  # generated asm (outputs are committed)
+    gens = [("gen_attn_q4.py", "attn_q4_body.inc"), ("gen_gemm_g4.py", "gemm_g4_body.inc"), ("gen_gemm_g4t.py", "gemm_g4t_body_gelu.inc"), ("gen_gemm_g4f.py", "gemm_g4f_body_a3.inc")]  # generated asm (outputs are committed)
     headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith((".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "s2v_hip.h"))
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]

@@ -1202,6 +1202,7 @@ int launch_gemm_fp8(const GemmArgs& a, int epi, hipStream_t st) {
     S2V_REQUIRE(a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM && a.w_rows_padded >= ((a.N + WBN - 1) / WBN) * WBN,
                 "gemm_fp8: operands must be padded to whole 256-row tiles");
     S2V_REQUIRE(epi_vec_ok(a, epi), "gemm_fp8: output rows must be 16-byte aligned and N a multiple of 8");
+    if (g_gemm_impl == 9 && gemm_g4f_ok(a, epi)) return launch_gemm_g4f(a, epi, st);  // four-wave generated-asm loop (gemm_g4f.hip)
     switch (epi) {
         case EPI_BIAS: return launch_fp8_t<EPI_BIAS>(a, st);
         case EPI_BIAS_GELU: return launch_fp8_t<EPI_BIAS_GELU>(a, st);

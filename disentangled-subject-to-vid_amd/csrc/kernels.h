@@ -80,6 +80,9 @@ int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st);  
 // gemm_g4.hip: 256 x 256 tiles, four waves, generated-asm K loop (plain bf16 operands; gemm_g4_ok says whether a call qualifies)
 bool gemm_g4_ok(const GemmArgs& a, int epi);
 int launch_gemm_g4(const GemmArgs& a, int epi, hipStream_t st);
+// gemm_g4f.hip: the four-wave loop on e4m3 operands (launch_gemm_fp8 routes to it where gemm_g4f_ok)
+bool gemm_g4f_ok(const GemmArgs& a, int epi);
+int launch_gemm_g4f(const GemmArgs& a, int epi, hipStream_t st);
 // gemm_g4t.hip: the same tiles as a persistent kernel whose epilogue is trickled through the next tile's K loop (gen_gemm_g4t.py);
 // bias / bias + GELU epilogues on whole 256 x 256 tiles with at least two rounds of them on `ncu` CUs
 bool gemm_g4t_ok(const GemmArgs& a, int epi, int ncu);
