@@ -662,7 +662,7 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     a.qkv = c->QKV; a.ld_qkv = 3 * D; a.vt = c->VT; a.ntok_pad = c->ntok_pad; a.out = c->Xn; a.ld_out = D;
     a.B = c->B; a.H = c->cfg.num_heads; a.Ntok = c->Ntok; a.scale = 0.125f;
     a.queue = c->attn_queue; a.num_cus = c->num_cus;  // launches of one context are ordered on its stream: one queue suffices
-    if (attn_mx_out(c)) { a.mx_q = (unsigned char*)c->aq; a.mx_s = c->hs; }
+    if (attn_mx_out(c)) { a.mx_q = (unsigned char*)c->aq; a.mx_s = c->hs; a.mx_rows = (int)c->Mpad; }
     ProfScope ps(c, PK_ATTN, st);
     if (c->mfma) S2V_TRY(launch_attn_bf16(a, st));
     else S2V_TRY(launch_attn_simple(a, c->dtype, st));
@@ -696,7 +696,7 @@ static int run_block(s2v_ctx* c, int l, const char* mod_base /* [B][mod_stride] 
         if (half == 0) {
             S2V_TRY(run_attention(c, l, st, prequant));
             g.A = c->Xn; g.lda = D; g.W = w.wo; g.ldw = D; g.bias = w.bo; g.K = D;
-            if (attn_mx_out(c)) { g.A = c->aq; g.mx_a_s = c->hs; }
+            if (attn_mx_out(c)) { g.A = c->aq; g.mx_a_s = c->hs; g.mx_rows = (int)c->Mpad; }
             ProfScope ps(c, PK_OUT, st);
             if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS_GATE_RES, w.q_o, w.s_o, st));
             else S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
@@ -708,14 +708,14 @@ static int run_block(s2v_ctx* c, int l, const char* mod_base /* [B][mod_stride] 
 #ifdef S2V_DIAG
             mx = mx && g_fp8_mx;
 #endif
-            if (mx) { f.mx_out_q = c->hq; f.mx_out_s = c->hs; }
+            if (mx) { f.mx_out_q = c->hq; f.mx_out_s = c->hs; f.mx_rows = (int)c->Mpad; }
             {
                 ProfScope ps(c, PK_FF1, st);
                 if (c->fp8) S2V_TRY(linear_fp8(c, f, EPI_BIAS_GELU, w.q_1, w.s_1, st, prequant));
                 else S2V_TRY(linear(c, f, EPI_BIAS_GELU, st));
             }
             g.A = c->Hb; g.lda = 4 * D; g.W = w.w2; g.ldw = 4 * D; g.bias = w.b2; g.K = 4 * D;
-            if (mx) { g.A = c->hq; g.mx_a_s = c->hs; }
+            if (mx) { g.A = c->hq; g.mx_a_s = c->hs; g.mx_rows = (int)c->Mpad; }
             ProfScope ps(c, PK_FF2, st);
             if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS_GATE_RES, w.q_2, w.s_2, st));
             else S2V_TRY(linear(c, g, EPI_BIAS_GATE_RES, st));
@@ -821,7 +821,7 @@ extern "C" int s2v_attn_forward(s2v_ctx* c, int32_t layer, const void* hidden, c
     const LayerW& w = c->layers[layer];
     GemmArgs g{};
     g.A = c->Xn; g.lda = D; g.W = w.wo; g.ldw = D; g.bias = w.bo; g.C = c->Hb; g.ldc = D; g.M = (int)c->M; g.N = D; g.K = D;
-    if (attn_mx_out(c)) { g.A = c->aq; g.mx_a_s = c->hs; }
+    if (attn_mx_out(c)) { g.A = c->aq; g.mx_a_s = c->hs; g.mx_rows = (int)c->Mpad; }
     if (c->fp8) S2V_TRY(linear_fp8(c, g, EPI_BIAS, w.q_o, w.s_o, st));  // the same operands run_block feeds its out-projection
     else S2V_TRY(linear(c, g, EPI_BIAS, st));
     for (int b = 0; b < B; ++b) {
@@ -1008,12 +1008,12 @@ extern "C" int s2v_op_ff_fp8(const void* x, const void* w1, const void* b1, cons
         GemmArgs f{};
         f.A = xq; f.lda = D; f.W = w1q; f.ldw = D; f.bias = b1; f.C = hb; f.ldc = F; f.M = M; f.N = F; f.K = D;
         f.a_rows_padded = M; f.w_rows_padded = F; f.a_scale = xs; f.w_scale = w1s;
-        if (mx) { f.mx_out_q = (unsigned char*)hq; f.mx_out_s = hsc; }
+        if (mx) { f.mx_out_q = (unsigned char*)hq; f.mx_out_s = hsc; f.mx_rows = M; }
         S2V_TRY(launch_gemm_fp8(f, EPI_BIAS_GELU, st));
         GemmArgs g{};
         g.A = hq; g.lda = F; g.W = w2q; g.ldw = F; g.bias = b2; g.C = out; g.ldc = D; g.M = M; g.N = D; g.K = F;
         g.a_rows_padded = M; g.w_rows_padded = D; g.w_scale = w2s;
-        if (mx) g.mx_a_s = hsc;
+        if (mx) { g.mx_a_s = hsc; g.mx_rows = M; }
         else {
             S2V_TRY(launch_quant_rows_fp8(hb, F, M, F, hq, hs_row, st));
             g.a_scale = hs_row;

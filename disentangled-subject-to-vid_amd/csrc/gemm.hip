@@ -546,7 +546,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
     }
     const int nT = a.K / BKE;
     const bool mx = FP8 && a.mx_a_s != nullptr;                 // block-scaled A (GemmArgs::mx_a_s)
-    const unsigned offS = (unsigned)((w4 * 64 + lane) * (a.K >> 5));  // scale row of lane: rows w4 * 64 + lane of the tile
+    const unsigned offS = (unsigned)((w4 * 64 + lane) * 4);     // scale dword of lane: rows w4 * 64 + lane of the tile (K-tile major: contiguous)
     const int ldst = (g * 128 + w4 * 8) * 128;  // byte offset of the wave's piece 0 inside an operand image
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_base_u32(smem));  // LDS destinations as integers: no null-check SALU per piece
     auto dma_a = [&](int t) {
@@ -559,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
         for (int i = 0; i < 4; ++i)
             glds16_saddr_m0(tb, offA[i], base + i * 4096);
         if (mx && !g) {  // the K-tile's four block scales of the tile's 256 rows: one dword per row, 64 rows per wave of group 0
-            const char* sb = (const char*)a.mx_a_s + (size_t)m0 * (a.K >> 5) + tc * 4;
+            const char* sb = (const char*)a.mx_a_s + ((size_t)tc * a.mx_rows + m0) * 4;
             glds4_saddr_m0(sb, offS, lds0 + 131072 + (t & 1) * 1024 + w4 * 256);
         }
     };
@@ -1198,6 +1198,7 @@ static int launch_fp8_t(const GemmArgs& a, hipStream_t st) {
 int launch_gemm_fp8(const GemmArgs& a, int epi, hipStream_t st) {
     S2V_REQUIRE(!a.conv && (a.a_scale || a.mx_a_s) && a.w_scale, "gemm_fp8: plain mode with the weight scales and row or block scales of A only");
     S2V_REQUIRE(!a.mx_out_q || (epi == EPI_BIAS_GELU && a.mx_out_s && a.N % 64 == 0), "gemm_fp8: MX output is the GELU epilogue's, N a multiple of 64");
+    S2V_REQUIRE(!(a.mx_out_q || a.mx_a_s) || a.mx_rows >= ((a.M + WBM - 1) / WBM) * WBM, "gemm_fp8: MX block scales are K-tile major, mx_rows must cover the padded M");
     S2V_REQUIRE(a.K % 128 == 0 && a.lda % 16 == 0 && a.ldw % 16 == 0, "gemm_fp8: K must be a multiple of 128, rows 16-byte aligned");
     S2V_REQUIRE(a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM && a.w_rows_padded >= ((a.N + WBN - 1) / WBN) * WBN,
                 "gemm_fp8: operands must be padded to whole 256-row tiles");

@@ -67,15 +67,15 @@ __global__ __launch_bounds__(256, 1) void gemm_g4f(const GemmArgs a, int tiles_m
     // MX: the K-tile's scale dword of row (wave * 64 + lane) of the tile; the lane reads the dwords of its A-fragment rows wm * 128 + j * 32 + fr
     u32x4 vmx = {(unsigned)(8 * hi), 0u, 0u, 0u};
     u32x2 ssc = {0u, 0u};
-    unsigned ssm0 = 0;
-    if (MX) {
-        const int sstride = a.K >> 5;  // scale bytes per row
-        vmx[1] = (unsigned)((wave * 64 + lane) * sstride);
+    u32x2 ssm0 = {0u, 0u};  // {LDS address of the wave's 64 scale dwords in scale stage 0, bytes between the scale rows of consecutive K-tiles}
+    if (MX) {  // K-tile major scales: K-tile kt's dwords of the tile's rows are contiguous, the next K-tile is mx_rows dwords further
+        vmx[1] = (unsigned)((wave * 64 + lane) * 4);
         vmx[2] = lds0 + G4F_MX_S_BASE + (wm * 128 + fr) * 4;
-        const unsigned long long sp = (unsigned long long)((const char*)a.mx_a_s + (size_t)m0 * sstride);
+        const unsigned long long sp = (unsigned long long)((const char*)a.mx_a_s + (size_t)m0 * 4);
         ssc[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sp);
         ssc[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sp >> 32));
-        ssm0 = lds0 + G4F_MX_S_BASE + wave * 256;
+        ssm0[0] = lds0 + G4F_MX_S_BASE + wave * 256;
+        ssm0[1] = (unsigned)(a.mx_rows * 4);
     }
 
     f32x32 AC[8];
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 1) void gemm_g4f(const GemmArgs a, int tiles_m
             : "=" G4F_ACC0(AC[0]), "=" G4F_ACC1(AC[1]), "=" G4F_ACC2(AC[2]), "=" G4F_ACC3(AC[3]), "=" G4F_ACC4(AC[4]), "=" G4F_ACC5(AC[5]),
               "=" G4F_ACC6(AC[6]), "=" G4F_ACC7(AC[7]), "+" G4F_PTR(ptr), "+" G4F_SIN(sin), "+" G4F_VADDR(vaddr)
             : G4F_VOFF(voff)
-            : G4F_CLOBBERS, "v164", "v165", "v166", "v167", "s44", "s45", "s46");
+            : G4F_CLOBBERS, "v164", "v165", "v166", "v167", "s44", "s45", "s46", "s47");
     }
     __builtin_amdgcn_s_barrier();  // every wave is done with the stages: the epilogue patches alias them
 

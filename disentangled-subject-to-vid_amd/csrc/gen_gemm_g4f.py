@@ -20,7 +20,7 @@ Registers: a[0:255] acc[i][j] at 64 i + 16 j; v[0:127] fragments [buffer][W 0-3 
 parity][2 s + kk]; v[144:159] IN staging offsets [A | W][piece]; v[160:163] stage-0 A addresses (a3); v164 IN 8 hi; v165 IN scale staging offset; v166 IN
 scale read address (stage 0, fragment row 0); v[168:175] block scales [K-tile parity][j]; v176 unit scales;
 s[36:37] / s[38:39] A / W source; s40 IN LDS address of the wave's piece 0; s41 IN pairs of K-tiles in the loop = (nT - 4) / 2; s42 / s43 / s48
-A stage rotation (a3); s[44:45] IN scale source (mx), s46 IN LDS address of the wave's 64 scale dwords in scale stage 0 (mx); nT = K / 128 even, >= 4.
+A stage rotation (a3); s[44:45] IN scale source (mx), s46 IN LDS address of the wave's 64 scale dwords in scale stage 0, s47 IN bytes between the scale dwords of consecutive K-tiles (mx: the scales are K-tile major); nT = K / 128 even, >= 4.
 """
 import os
 
@@ -134,7 +134,7 @@ def ktile(emit, M, g, first=False, dma=True, last=False):
                 emit(f"global_load_lds_dword {vr(V_SOFF)}, s[{S_SC}:{S_SC + 1}]")
                 emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
                 emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
-                emit(f"s_add_u32 s{S_SC}, s{S_SC}, 4")
+                emit(f"s_add_u32 s{S_SC}, s{S_SC}, s{S_SM0 + 1}")
                 emit(f"s_addc_u32 s{S_SC + 1}, s{S_SC + 1}, 0")
 
 
@@ -153,7 +153,7 @@ def prologue(emit, M):
         emit(f"s_add_u32 m0, s{S_SM0}, {stage * 1024}")
         emit("s_nop 0")
         emit(f"global_load_lds_dword {vr(V_SOFF)}, s[{S_SC}:{S_SC + 1}]")
-        emit(f"s_add_u32 s{S_SC}, s{S_SC}, 4")
+        emit(f"s_add_u32 s{S_SC}, s{S_SC}, s{S_SM0 + 1}")
         emit(f"s_addc_u32 s{S_SC + 1}, s{S_SC + 1}, 0")
 
     emit(f"v_mov_b32 {vr(V_UNIT)}, 0x7f7f7f7f")
@@ -217,7 +217,7 @@ def main():
         for k in range(8):
             f.write(f'#define G4F_ACC{k} "{{a[{32 * k}:{32 * k + 31}]}}"\n')
         f.write(f'#define G4F_VADDR "{{v[{VADDR}:{VADDR + 15}]}}"\n#define G4F_VOFF "{{v[{VOFF}:{VOFF + 15}]}}"\n#define G4F_VMX "{{v[{V_SH}:{V_SH + 3}]}}"\n')
-        f.write(f'#define G4F_PTR "{{s[{S_A}:{S_A + 3}]}}"\n#define G4F_SIN "{{s[{S_M0W}:{S_M0W + 1}]}}"\n#define G4F_SSC "{{s[{S_SC}:{S_SC + 1}]}}"\n#define G4F_SSM0 "{{s{S_SM0}}}"\n')
+        f.write(f'#define G4F_PTR "{{s[{S_A}:{S_A + 3}]}}"\n#define G4F_SIN "{{s[{S_M0W}:{S_M0W + 1}]}}"\n#define G4F_SSC "{{s[{S_SC}:{S_SC + 1}]}}"\n#define G4F_SSM0 "{{s[{S_SM0}:{S_SM0 + 1}]}}"\n')
         clob = [f"v{r}" for r in range(0, 128)] + [f"v{r}" for r in range(ABASE, V_SH)] + [f"v{r}" for r in range(V_SB, V_UNIT + 1)] + [f"s{S_ANEXT}", f"s{S_ADMA}", f"s{S_AM0}"]
         f.write("#define G4F_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + ', "vcc", "scc", "m0", "memory"\n')
 
