@@ -210,7 +210,7 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
                     if (q_row[j] < a.Ntok) *(u32x2*)(a.mx_q + orow * a.ld_out + h * 64 + 16 * u + hi * 8) = u32x2{w0, w1};
                 }
             }
-            if (hi == 0 && q_row[j] < a.Ntok) *(unsigned short*)(a.mx_s + ((size_t)(h >> 1) * a.mx_rows + orow) * 4 + (h & 1) * 2) = (unsigned short)ebs;  // K-tile major: head h = blocks 2 h, 2 h + 1 of K-tile h / 2
+            if (hi == 0 && q_row[j] < a.Ntok) *(unsigned short*)(a.mx_s + ((size_t)(h >> 1) * a.mx_rows + mx_perm_row((int64_t)orow)) * 4 + (h & 1) * 2) = (unsigned short)ebs;  // K-tile major: head h = blocks 2 h, 2 h + 1 of K-tile h / 2
         }
     }
 }

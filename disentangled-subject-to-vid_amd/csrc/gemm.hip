@@ -597,7 +597,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
         if (FP8 && mx && s == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                sb_[j] = (int)(*(const unsigned*)(smem + 131072 + (t & 1) * 1024 + (wm * 128 + j * 32 + fr) * 4) >> (8 * hi));
+                sb_[j] = (int)(*(const unsigned*)(smem + 131072 + (t & 1) * 1024 + (wm * 128 + fr * 4 + j) * 4) >> (8 * hi));  // rows permuted inside a 128-row half (kernels.h)
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {

@@ -272,7 +272,7 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
                 const unsigned e2 = eb | ((unsigned)__builtin_amdgcn_update_dpp(0, (int)eb, 0x104, 0xf, 0xf, true) << 8);  // lane c16 = 0: + lane 4's block
                 if (mrow[u] < a.M && n_ok) {
                     *(u32x2*)(a.mx_out_q + (size_t)mrow[u] * a.N + n) = u32x2{w0, w1};
-                    if (c16 == 0) *(unsigned short*)(a.mx_out_s + ((size_t)(n >> 7) * a.mx_rows + mrow[u]) * 4 + ((n >> 5) & 3)) = (unsigned short)e2;  // K-tile major
+                    if (c16 == 0) *(unsigned short*)(a.mx_out_s + ((size_t)(n >> 7) * a.mx_rows + mx_perm_row(mrow[u])) * 4 + ((n >> 5) & 3)) = (unsigned short)e2;  // K-tile major, rows permuted
                 }
             } else if (mrow[u] < a.M && n_ok) {
                 if (EPI == EPI_BIAS_GATE_RES) *(u32x4*)((bf16_t*)a.X + (size_t)mrow[u] * a.ldx + n) = o;

@@ -4,7 +4,7 @@
 // vector epilogue with the dequantisation scales (gemm_epi.h, SC = true) on the wave tile's two 64-column halves.
 // MX = false: per-token scales a_scale[m] (activations quantised by ln_modulate_k / quant_rows_fp8_k), unit block scales in the MFMA,
 //             three A stages.  MX = true: A is an MX image (mx_a_s: one E8M0 scale per row and 32 elements, written by the attention /
-//             GELU epilogues), the block scales travel through LDS beside the two operand stages.
+//             GELU epilogues), the lane's block scales come straight into registers (one 16-byte load per K-tile).
 #define S2V_HOST
 #include "common.h"
 #include "kernels.h"
@@ -17,8 +17,7 @@ typedef __attribute__((ext_vector_type(16))) unsigned int u32x16;
 template <int EPI, bool MX>
 __global__ __launch_bounds__(256, 1) void gemm_g4f(const GemmArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int A_STRIDE = MX ? G4F_MX_A_STRIDE : G4F_A3_A_STRIDE, W_BASE = MX ? G4F_MX_W_BASE : G4F_A3_W_BASE,
-                  W_STRIDE = MX ? G4F_MX_W_STRIDE : G4F_A3_W_STRIDE;
+    constexpr int A_STRIDE = G4F_A3_A_STRIDE, W_BASE = G4F_A3_W_BASE, W_STRIDE = G4F_A3_W_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -68,13 +67,11 @@ __global__ __launch_bounds__(256, 1) void gemm_g4f(const GemmArgs a, int tiles_m
     u32x4 vmx = {(unsigned)(8 * hi), 0u, 0u, 0u};
     u32x2 ssc = {0u, 0u};
     u32x2 ssm0 = {0u, 0u};  // {LDS address of the wave's 64 scale dwords in scale stage 0, bytes between the scale rows of consecutive K-tiles}
-    if (MX) {  // K-tile major scales: K-tile kt's dwords of the tile's rows are contiguous, the next K-tile is mx_rows dwords further
-        vmx[1] = (unsigned)((wave * 64 + lane) * 4);
-        vmx[2] = lds0 + G4F_MX_S_BASE + (wm * 128 + fr) * 4;
+    if (MX) {  // K-tile major scales with the rows of a 128-row half permuted (kernels.h): the lane's four dwords are 16 consecutive bytes
+        vmx[1] = (unsigned)((wm * 128 + fr * 4) * 4);
         const unsigned long long sp = (unsigned long long)((const char*)a.mx_a_s + (size_t)m0 * 4);
         ssc[0] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)sp);
         ssc[1] = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(sp >> 32));
-        ssm0[0] = lds0 + G4F_MX_S_BASE + wave * 256;
         ssm0[1] = (unsigned)(a.mx_rows * 4);
     }
 

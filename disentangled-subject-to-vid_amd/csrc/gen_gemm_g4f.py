@@ -12,15 +12,16 @@ Per step: 16 MFMA, 16 ds_read_b128 (the next step's eight fragments), 8 LDS-DMA 
 
 "a3": the schedule of gen_gemm_g4.py's product loop -- three A stages, A pieces of K-tile t+2 in step 0, vmcnt(8) + barrier at step 1, W
 pieces of K-tile t+2 behind the barrier; LDS [A0 | A1 | A2 | W0 | W1] x 32 KiB.
-"mx": two stages [A | W] x 2 + 2 x 1 KiB of block scales (the three-stage map leaves no room for them): W pieces of K-tile t+1 in step 0,
-vmcnt(0) + barrier at step 1, then the A pieces and the scale dword (one per row: the K-tile's four block scales) of K-tile t+2; the lane's
-four scale dwords of K-tile t+1 (rows of its A fragments) are read behind that barrier and shifted by 8 hi at the start of K-tile t+1, so
-that byte 0 / byte 2 (op_sel_hi) are the blocks 2 s + hi of steps 0 / 1.
+"mx": the same loop; the block scales do not pass through LDS (the three-stage map leaves no room, and a first two-stage form with the
+scales staged beside the tiles ran at 3.0-3.3 k cycles per K-tile): the scale array is laid out K-tile major with the rows of a 128-row half
+permuted (kernels.h GemmArgs::mx_a_s) so that the four dwords a lane needs -- rows j * 32 + fr of its four A fragments -- are 16
+consecutive bytes: ONE global_load_dwordx4 per wave and K-tile, requested a K-tile ahead in front of the A pieces (the vmcnt(8) of step 1
+covers it), shifted by 8 hi at the start of its K-tile so that byte 0 / byte 2 (op_sel_hi) are the blocks 2 s + hi of steps 0 / 1.
 Registers: a[0:255] acc[i][j] at 64 i + 16 j; v[0:127] fragments [buffer][W 0-3 | A 0-3] x 8; v[128:143] IN fragment addresses [A | W][stage
-parity][2 s + kk]; v[144:159] IN staging offsets [A | W][piece]; v[160:163] stage-0 A addresses (a3); v164 IN 8 hi; v165 IN scale staging offset; v166 IN
-scale read address (stage 0, fragment row 0); v[168:175] block scales [K-tile parity][j]; v176 unit scales;
+parity][2 s + kk]; v[144:159] IN staging offsets [A | W][piece]; v[160:163] stage-0 A addresses (a3); v164 IN 8 hi; v165 IN byte offset of the lane's four scale dwords
+inside a K-tile's scale row (mx); v[168:175] block scales [K-tile parity][j]; v176 unit scales;
 s[36:37] / s[38:39] A / W source; s40 IN LDS address of the wave's piece 0; s41 IN pairs of K-tiles in the loop = (nT - 4) / 2; s42 / s43 / s48
-A stage rotation (a3); s[44:45] IN scale source (mx), s46 IN LDS address of the wave's 64 scale dwords in scale stage 0, s47 IN bytes between the scale dwords of consecutive K-tiles (mx: the scales are K-tile major); nT = K / 128 even, >= 4.
+A stage rotation (a3); s[44:45] IN scale source (mx), s47 IN bytes between the scale rows of consecutive K-tiles (mx); nT = K / 128 even, >= 4.
 """
 import os
 
@@ -51,10 +52,7 @@ def vaddr(is_w, g, x):
 class Map:
     def __init__(self, mx):
         self.mx = mx
-        if mx:
-            self.A_STRIDE, self.W_BASE, self.W_STRIDE, self.S_BASE, self.LDS = 65536, 32768, 65536, 131072, 131072 + 2048
-        else:
-            self.A_STRIDE, self.W_BASE, self.W_STRIDE, self.S_BASE, self.LDS = 32768, 98304, 32768, 0, 163840
+        self.A_STRIDE, self.W_BASE, self.W_STRIDE, self.S_BASE, self.LDS = 32768, 98304, 32768, 0, 163840
 
 
 def mfma(emit, M, t_par, s, k, first):
@@ -75,19 +73,21 @@ def frag_read(emit, buf, n, kk, g, s):
 
 
 def ktile(emit, M, g, first=False, dma=True, last=False):
-    """K-tile t (parity g).  dma: it stages K-tile t+2 (a3: A in step 0, W in step 1; mx: W of t+1 in step 0, A + scales of t+2 in step 1)"""
+    """K-tile t (parity g).  dma: it stages K-tile t+2 (A pieces in step 0, W pieces in step 1 behind the barrier).  mx: the lane's four
+    scale dwords of K-tile t+1 are requested (ONE global_load_dwordx4: the scale array is laid out for it, kernels.h) ahead of the A pieces,
+    so the vmcnt(8) of step 1 covers them; they are shifted by 8 hi at the start of K-tile t+1."""
     mx = M.mx
     for s in range(2):
         if s == 1 and not last:
-            emit(f"s_waitcnt vmcnt({0 if (mx or not dma) else 8}) lgkmcnt(0)")
+            emit(f"s_waitcnt vmcnt({8 if dma else 0}) lgkmcnt(0)")
             emit("s_barrier")
         else:
             emit("s_waitcnt lgkmcnt(0)")
-        if mx and s == 0:  # the block scales read behind the previous K-tile's barrier: byte 0 / 2 = blocks hi / 2 + hi
+        if mx and s == 0:  # byte 0 / 2 = blocks hi / 2 + hi of the K-tile
             for j in range(4):
                 emit(f"v_lshrrev_b32 {vr(V_SB + 4 * g + j)}, {vr(V_SH)}, {vr(V_SB + 4 * g + j)}")
             emit("s_nop 1")  # VALU result -> scale operand of the next MFMA
-        if not mx and s == 0 and dma:
+        if s == 0 and dma:
             emit(f"s_add_u32 s{S_AM0}, s{S_M0W}, s{S_ADMA}")
         for k in range(16):
             mfma(emit, M, g, s, k, first)
@@ -97,45 +97,28 @@ def ktile(emit, M, g, first=False, dma=True, last=False):
             elif not last:
                 frag_read(emit, 0, n, kk, g ^ 1, 0)          # the next K-tile's step 0 (behind the barrier)
             p = k >> 1
-            if not mx:
-                if s == 0 and dma:   # A piece p of K-tile t+2 -> A stage (t+2) % 3
-                    emit(f"s_add_u32 m0, s{S_AM0}, {p * 4096}" if k & 1 == 0 else f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]")
-                if s == 0 and not last and k >= 12:  # A fragment addresses of K-tile t+1 (set g^1)
-                    emit(f"v_add_u32 {vr(vaddr(False, g ^ 1, k - 12))}, s{S_ANEXT}, {vr(ABASE + k - 12)}")
-                if s == 1 and dma:   # W piece p of K-tile t+2 -> W stage g
-                    emit(f"s_add_u32 m0, s{S_M0W}, {M.W_BASE + g * M.W_STRIDE + p * 4096}" if k & 1 == 0 else f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]")
-            else:
-                if s == 0 and (dma or dma is None):   # W piece p of K-tile t+1 -> W stage g^1  (dma None: the last W half only)
-                    emit(f"s_add_u32 m0, s{S_M0W}, {M.W_BASE + (g ^ 1) * M.W_STRIDE + p * 4096}" if k & 1 == 0 else f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]")
-                if s == 1 and dma:   # A piece p of K-tile t+2 -> A stage g
-                    emit(f"s_add_u32 m0, s{S_M0W}, {g * M.A_STRIDE + p * 4096}" if k & 1 == 0 else f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]")
-                if s == 1 and not last and k >= 12:  # the lane's scale dwords of K-tile t+1 (stage g^1), rows of its four A fragments
-                    j = k - 12
-                    emit(f"ds_read_b32 {vr(V_SB + 4 * (g ^ 1) + j)}, {vr(V_SRD)} offset:{(g ^ 1) * 1024 + j * 128}")
-        if not mx:
-            if s == 0 and dma:
-                emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
-                emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
-            if s == 0 and not last:
-                emit(f"s_mov_b32 s{S_ANEXT}, s{S_ADMA}")
-                emit(f"s_add_u32 s{S_ADMA}, s{S_ADMA}, {M.A_STRIDE}")
-                emit(f"s_cmp_ge_u32 s{S_ADMA}, {3 * M.A_STRIDE}")
-                emit(f"s_cselect_b32 s{S_ADMA}, 0, s{S_ADMA}")
-            if s == 1 and dma:
-                emit(f"s_add_u32 s{S_W}, s{S_W}, 128")
-                emit(f"s_addc_u32 s{S_W + 1}, s{S_W + 1}, 0")
-        else:
-            if s == 0 and (dma or dma is None):
-                emit(f"s_add_u32 s{S_W}, s{S_W}, 128")
-                emit(f"s_addc_u32 s{S_W + 1}, s{S_W + 1}, 0")
-            if s == 1 and dma:   # + the scale dword of K-tile t+2 -> scale stage g, behind the A pieces
-                emit(f"s_add_u32 m0, s{S_SM0}, {g * 1024}")   # s46 = LDS address of the wave's 64 scale dwords in scale stage 0
-                emit("s_nop 0")
-                emit(f"global_load_lds_dword {vr(V_SOFF)}, s[{S_SC}:{S_SC + 1}]")
-                emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
-                emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
+            if mx and s == 0 and k == 0 and not last:        # scales of K-tile t+1, older than every A piece of this step
+                emit(f"global_load_dwordx4 {vr(V_SB + 4 * (g ^ 1), 4)}, {vr(V_SOFF)}, s[{S_SC}:{S_SC + 1}]")
+            if s == 0 and dma:   # A piece p of K-tile t+2 -> A stage (t+2) % 3
+                emit(f"s_add_u32 m0, s{S_AM0}, {p * 4096}" if k & 1 == 0 else f"global_load_lds_dwordx4 {vr(VOFF + p)}, s[{S_A}:{S_A + 1}]")
+            if s == 0 and not last and k >= 12:  # A fragment addresses of K-tile t+1 (set g^1)
+                emit(f"v_add_u32 {vr(vaddr(False, g ^ 1, k - 12))}, s{S_ANEXT}, {vr(ABASE + k - 12)}")
+            if s == 1 and dma:   # W piece p of K-tile t+2 -> W stage g
+                emit(f"s_add_u32 m0, s{S_M0W}, {M.W_BASE + g * M.W_STRIDE + p * 4096}" if k & 1 == 0 else f"global_load_lds_dwordx4 {vr(VOFF + 8 + p)}, s[{S_W}:{S_W + 1}]")
+        if s == 0 and dma:
+            emit(f"s_add_u32 s{S_A}, s{S_A}, 128")
+            emit(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
+        if s == 0 and not last:
+            emit(f"s_mov_b32 s{S_ANEXT}, s{S_ADMA}")
+            emit(f"s_add_u32 s{S_ADMA}, s{S_ADMA}, {M.A_STRIDE}")
+            emit(f"s_cmp_ge_u32 s{S_ADMA}, {3 * M.A_STRIDE}")
+            emit(f"s_cselect_b32 s{S_ADMA}, 0, s{S_ADMA}")
+            if mx:
                 emit(f"s_add_u32 s{S_SC}, s{S_SC}, s{S_SM0 + 1}")
                 emit(f"s_addc_u32 s{S_SC + 1}, s{S_SC + 1}, 0")
+        if s == 1 and dma:
+            emit(f"s_add_u32 s{S_W}, s{S_W}, 128")
+            emit(f"s_addc_u32 s{S_W + 1}, s{S_W + 1}, 0")
 
 
 def prologue(emit, M):
@@ -149,28 +132,19 @@ def prologue(emit, M):
         emit(f"s_add_u32 s{sp}, s{sp}, 128")
         emit(f"s_addc_u32 s{sp + 1}, s{sp + 1}, 0")
 
-    def scales(stage):
-        emit(f"s_add_u32 m0, s{S_SM0}, {stage * 1024}")
-        emit("s_nop 0")
-        emit(f"global_load_lds_dword {vr(V_SOFF)}, s[{S_SC}:{S_SC + 1}]")
+    emit(f"v_mov_b32 {vr(V_UNIT)}, 0x7f7f7f7f")
+    if M.mx:   # K-tile 0's scale dwords first (K-tile 1's follow in step 0 of K-tile 0)
+        emit(f"global_load_dwordx4 {vr(V_SB, 4)}, {vr(V_SOFF)}, s[{S_SC}:{S_SC + 1}]")
         emit(f"s_add_u32 s{S_SC}, s{S_SC}, s{S_SM0 + 1}")
         emit(f"s_addc_u32 s{S_SC + 1}, s{S_SC + 1}, 0")
-
-    emit(f"v_mov_b32 {vr(V_UNIT)}, 0x7f7f7f7f")
-    if M.mx:   # K-tile 0 whole, A half + scales of K-tile 1 (its W half follows in step 0 of K-tile 0)
-        pieces(False, 0); scales(0); pieces(True, 0); pieces(False, 1); scales(1)
-        emit("s_waitcnt vmcnt(9)")
-        emit("s_barrier")
-        for j in range(4):
-            emit(f"ds_read_b32 {vr(V_SB + j)}, {vr(V_SRD)} offset:{j * 128}")
-    else:      # K-tiles 0 and 1 whole; K-tile 2's A half follows in step 0 of K-tile 0
-        pieces(False, 0); pieces(True, 0); pieces(False, 1); pieces(True, 1)
-        emit(f"s_mov_b32 s{S_ANEXT}, {M.A_STRIDE}")
-        emit(f"s_mov_b32 s{S_ADMA}, {2 * M.A_STRIDE}")
-        for x in range(4):
-            emit(f"v_mov_b32 {vr(ABASE + x)}, {vr(vaddr(False, 0, x))}")
-        emit("s_waitcnt vmcnt(16)")
-        emit("s_barrier")
+    # K-tiles 0 and 1 whole; K-tile 2's A half follows in step 0 of K-tile 0
+    pieces(False, 0); pieces(True, 0); pieces(False, 1); pieces(True, 1)
+    emit(f"s_mov_b32 s{S_ANEXT}, {M.A_STRIDE}")
+    emit(f"s_mov_b32 s{S_ADMA}, {2 * M.A_STRIDE}")
+    for x in range(4):
+        emit(f"v_mov_b32 {vr(ABASE + x)}, {vr(vaddr(False, 0, x))}")
+    emit("s_waitcnt vmcnt(16)")
+    emit("s_barrier")
     for n in range(8):
         for kk in range(2):
             frag_read(emit, 0, n, kk, 0, 0)
@@ -191,8 +165,8 @@ def gen(mx):
     emit(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
     emit("s_branch L_g4f_loop_%=")
     emit("L_g4f_tail_%=:")
-    ktile(emit, M, 1)                                         # K-tile nT-3: the last one that stages (a3: all of K-tile nT-1; mx: W of nT-2, A + scales of nT-1)
-    ktile(emit, M, 0, dma=(None if mx else False))            # K-tile nT-2 (mx: still stages the W half of K-tile nT-1)
+    ktile(emit, M, 1)                                         # K-tile nT-3: the last one that stages (all of K-tile nT-1)
+    ktile(emit, M, 0, dma=False)                              # K-tile nT-2 (mx: still requests the scales of K-tile nT-1)
     ktile(emit, M, 1, dma=False, last=True)
     emit("s_waitcnt vmcnt(0)")
     emit("s_nop 15")

@@ -63,7 +63,9 @@ struct GemmArgs {
     //   Layout of the scales (round 4): K-TILE MAJOR -- [K / 128][mx_rows] dwords, dword (kt, m) = the four block scales of row m inside
     //   the 128 elements of K-tile kt (byte b = block 4 kt + b).  A GEMM's K-tile then finds the dwords of its 256 rows in ONE contiguous
     //   KiB (an LDS-DMA dword per lane over [M][K / 32] touched 64 cache lines per wave and K-tile: the MX loops ran at 3.3 k cycles per
-    //   K-tile against 2.15 k for the unit-scale loop).  mx_rows = rows of that array (>= the padded M).
+    //   K-tile against 2.15 k for the unit-scale loop).  mx_rows = rows of that array (>= the padded M, a multiple of 128).
+    //   Inside every 128-row half the rows are PERMUTED: row m sits at mx_perm_row(m) = (m & ~127) | (m & 31) << 2 | (m >> 5) & 3, so that
+    //   the rows j * 32 + fr (j = 0..3) of the four A fragments of a lane are four consecutive dwords -- one 16-byte load.
     unsigned char* mx_out_q; unsigned char* mx_out_s;
     const unsigned char* mx_a_s;
     int mx_rows;
@@ -80,6 +82,7 @@ enum { EPI_BIAS_ADD = 3 };
 // pass over 2/3 of the QKV buffer less per layer).  Rows are tokens: r = m % tok_per_batch, rotary for r >= text_len.
 enum { EPI_BIAS_QKNORM = 4 };
 
+__host__ __device__ __forceinline__ int64_t mx_perm_row(int64_t m) { return (m & ~(int64_t)127) | ((m & 31) << 2) | ((m >> 5) & 3); }
 int launch_gemm_bf16(const GemmArgs& a, int epi, hipStream_t st);              // MFMA path, bf16 only
 int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st);  // any dtype, any shape
 // gemm_g4.hip: 256 x 256 tiles, four waves, generated-asm K loop (plain bf16 operands; gemm_g4_ok says whether a call qualifies)
