@@ -39,15 +39,35 @@ template <> struct ET<bf16_t> {
     static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
 };
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Wave-wide butterfly v (op) v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 -- the operand order of the __shfl_xor loop this replaces, so sums
+// keep their bits -- without the LDS crossbar: __shfl_xor lowers to ds_bpermute_b32 behind five VALU of index arithmetic and an
+// s_waitcnt lgkmcnt(0) per step.  ^ 32 / ^ 16: v_permlane32_swap / v_permlane16_swap of two copies (gfx950); ^ 8: DPP row_ror:8;
+// ^ 4: row_shl:4 into the banks whose lanes have bit 2 clear + row_shr:4 into the others; ^ 2 / ^ 1: quad_perm.
+template <typename Op>
+__device__ __forceinline__ float wave_butterfly(float v, Op op) {
+    {
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, true)));  // row_ror:8
+    {
+        int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x104, 0xf, 0x5, true);                  // row_shl:4 -> banks 0, 2
+        t = __builtin_amdgcn_update_dpp(t, __float_as_int(v), 0x114, 0xf, 0xa, false);                     // row_shr:4 -> banks 1, 3
+        v = op(v, __int_as_float(t));
+    }
+    v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
+    v = op(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
     return v;
 }
+__device__ __forceinline__ float wave_sum(float v) {
+    return wave_butterfly(v, [](float a, float b) { return a + b; });
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    return wave_butterfly(v, [](float a, float b) { return fmaxf(a, b); });
 }
 
 // 16-byte vector of T
