@@ -41,6 +41,9 @@ WORKLOADS = {
     "cogvideox-5b-49x720x1280": ("cogvideox-5b", 13, 90, 160, 226),
     "cogvideox-5b-fp8-49x720x1280": ("cogvideox-5b-fp8", 13, 90, 160, 226),
     "cogvideox-5b-fp8-49x480x720": ("cogvideox-5b-fp8", 13, 60, 90, 226),
+    # an option BEYOND configs[4]'s "fp8 weights": additionally q / k as MX e4m3 and QK^T on the scaled fp8 MFMA (weight_format 2)
+    "cogvideox-5b-fp8qk-49x720x1280": ("cogvideox-5b-fp8qk", 13, 90, 160, 226),
+    "cogvideox-5b-fp8qk-49x480x720": ("cogvideox-5b-fp8qk", 13, 60, 90, 226),
 }
 
 
@@ -322,7 +325,7 @@ def main(argv=None):
 
     preset, F, H, W, T = WORKLOADS[args.workload]
     cfg = s2v.config.PRESETS[preset]()
-    fp8 = cfg.weight_format == "fp8"
+    fp8 = cfg.weight_format in ("fp8", "fp8-qk")
     dt = torch.bfloat16
     eng = s2v.S2VEngine(cfg, dt, dev)
     t_load = time.time()
@@ -534,7 +537,7 @@ def main(argv=None):
             "n_gpus": n_devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "fp8 (e4m3 W8A8 block linears) + bf16" if fp8 else "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
+            "dtype": ("fp8 (e4m3 W8A8 block linears, MX e4m3 QK^T) + bf16" if cfg.weight_format == "fp8-qk" else "fp8 (e4m3 W8A8 block linears) + bf16") if fp8 else "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
             "config": {"workload": args.workload, "latent_frames": F, "latent_hw": [H, W], "tokens": T + (F + 1) * (H // 2) * (W // 2),
                        "cfg_pair": 2, "scheduler": "ddim-trailing-50", "parallelism": f"replicas x{world}",
                        "rccl_ranks": world, "backend": (dist.get_backend() if dist.is_initialized() else None),

@@ -60,6 +60,7 @@ _SIGS = {
     "s2v_op_ff_fp8": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "s2v_op_mod_gemv": [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _P],
     "s2v_op_attention": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "s2v_op_attention_fp8qk": [_P, _P, _P, _I64, _P, _I32, _I32, _I32, _P],
     "s2v_op_linear_fp8": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P],
 }
 # replicas over RCCL behind the C ABI (csrc/rccl.hip); RCCL itself is bound at first use

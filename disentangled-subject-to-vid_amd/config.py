@@ -72,4 +72,11 @@ def cogvideox_5b_fp8():
     return cfg
 
 
-PRESETS = {"cogvideox-2b": cogvideox_2b, "cogvideox-5b": cogvideox_5b, "cogvideox-5b-fp8": cogvideox_5b_fp8}
+def cogvideox_5b_fp8_qk():
+    """fp8 weights AND fp8 QK^T (weight_format 2): an option beyond BASELINE configs[4]'s "fp8 weights", labelled as such wherever it is reported"""
+    cfg = cogvideox_5b()
+    cfg.weight_format = "fp8-qk"
+    return cfg
+
+
+PRESETS = {"cogvideox-2b": cogvideox_2b, "cogvideox-5b": cogvideox_5b, "cogvideox-5b-fp8": cogvideox_5b_fp8, "cogvideox-5b-fp8qk": cogvideox_5b_fp8_qk}

@@ -50,7 +50,9 @@ struct s2v_ctx {
                                  // reference-image copy of chunks 0-2: cond_shift, cond_scale, cond_gate)
     float* lora_tmp = nullptr;   // fp32 scratch of s2v_merge_lora
     size_t lora_tmp_bytes = 0;
-    bool fp8 = false;            // cfg.weight_format == 1
+    bool fp8 = false;            // cfg.weight_format == 1 or 2
+    bool fp8_qk = false;         // cfg.weight_format == 2: additionally q / k as MX e4m3 and QK^T on the scaled fp8 MFMA (attn_q4f)
+    unsigned char *q8 = nullptr, *k8 = nullptr; unsigned short* q8s = nullptr; unsigned* k8s = nullptr;  // workspace (fp8_qk): AttnArgs::q8 ... k8s
     char* aq = nullptr;          // workspace: e4m3 activations [Mpad][4D] of the GEMM being fed
     float* aq_scale = nullptr;   // workspace: their per-token scales [Mpad]
     unsigned char *hq = nullptr, *hs = nullptr;  // workspace (fp8): GELU(FF1) as MX e4m3 [Mpad][4D] + block scales [Mpad][4D / 32]
@@ -190,9 +192,10 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     c->mod_rows = 2 * L * MC * D + 2 * D;
     const int64_t o_mod_w = carve(c->mod_rows * TE), o_mod_b = carve(c->mod_rows);
     // fp8 copies live in the same arena (one broadcast replicates everything a replica needs)
-    c->fp8 = cfg->weight_format == 1;
-    if (cfg->weight_format != 0 && cfg->weight_format != 1) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format must be 0 or 1", -1); }
-    if (c->fp8 && (!c->mfma || D % 128 != 0)) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format 1 (fp8) needs the bf16 MFMA path and inner_dim % 128 == 0", -1); }
+    c->fp8 = cfg->weight_format == 1 || cfg->weight_format == 2;
+    c->fp8_qk = cfg->weight_format == 2;
+    if (cfg->weight_format < 0 || cfg->weight_format > 2) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format must be 0, 1 or 2", -1); }
+    if (c->fp8 && (!c->mfma || D % 128 != 0)) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format 1 / 2 (fp8) needs the bf16 MFMA path and inner_dim % 128 == 0", -1); }
     struct QOffs { int64_t q_qkv, q_o, q_1, q_2, s_qkv, s_o, s_1, s_2; };
     std::vector<QOffs> qo(c->fp8 ? L : 0);
     auto carve_b = [&](int64_t bytes) { int64_t o = off; off += rup(bytes, 256); return o; };
@@ -456,6 +459,10 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     const int64_t oaq = carve(c->fp8 ? c->Mpad * 4 * D : 0), oaqs = carve(c->fp8 ? c->Mpad * 4 : 0);
     // fp8: the FF1 epilogue leaves GELU(h) as MX e4m3 (bytes + one E8M0 scale per 32 columns), the FF2 reads it in place
     const int64_t ohq = carve(c->fp8 ? c->Mpad * 4 * D : 0), ohs = carve(c->fp8 ? c->Mpad * 4 * D / 32 : 0);
+    // fp8_qk: MX e4m3 images of q and k for attn_q4f (AttnArgs::q8 ... k8s)
+    const int64_t BH = (int64_t)B * c->cfg.num_heads;
+    const int64_t oq8 = carve(c->fp8_qk ? BH * c->Ntok * 64 : 0), oq8s = carve(c->fp8_qk ? BH * c->Ntok * 2 : 0);
+    const int64_t ok8 = carve(c->fp8_qk ? BH * c->ntok_pad * 64 : 0), ok8s = carve(c->fp8_qk ? BH * c->ntok_pad * 4 : 0);
     // split-K partial tiles + arrival counters (linear(): only geometries whose FF2 has at most half as many 256 x 256 tiles as CUs)
     c->sk_tiles = (c->mfma && ((c->M + 255) / 256) * ((D + 255) / 256) * 2 <= c->num_cus) ? c->num_cus : 0;
     const int64_t osk = carve((int64_t)c->sk_tiles * 262144), oskc = carve((int64_t)c->sk_tiles * 4);
@@ -469,6 +476,7 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     c->pos_tab = w + opos; c->rope_pk = (float*)(w + opk); c->rope_paired = false;
     c->aq = w + oaq; c->aq_scale = (float*)(w + oaqs);
     c->hq = (unsigned char*)(w + ohq); c->hs = (unsigned char*)(w + ohs);
+    c->q8 = (unsigned char*)(w + oq8); c->q8s = (unsigned short*)(w + oq8s); c->k8 = (unsigned char*)(w + ok8); c->k8s = (unsigned*)(w + ok8s);
     c->sk_ws = (float*)(w + osk); c->sk_cnt = (unsigned*)(w + oskc);
     return 0;
 }
@@ -663,6 +671,16 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     a.B = c->B; a.H = c->cfg.num_heads; a.Ntok = c->Ntok; a.scale = 0.125f;
     a.queue = c->attn_queue; a.num_cus = c->num_cus;  // launches of one context are ordered on its stream: one queue suffices
     if (attn_mx_out(c)) { a.mx_q = (unsigned char*)c->aq; a.mx_s = c->hs; a.mx_rows = (int)c->Mpad; }
+    if (c->fp8_qk) {  // weight_format 2: q (times scale * log2 e) and k as MX e4m3, QK^T on the scaled fp8 MFMA (the pass is timed with the V^T pass)
+        {
+            ProfScope ps(c, PK_QKNORM, st);
+            S2V_TRY(launch_qk_quant_mx(c->QKV, 3 * D, c->B, c->cfg.num_heads, c->Ntok, c->ntok_pad, a.scale * 1.4426950408889634f, c->q8, c->q8s, c->k8,
+                                       c->k8s, st));
+        }
+        a.q8 = c->q8; a.q8s = c->q8s; a.k8 = c->k8; a.k8s = c->k8s;
+        ProfScope ps(c, PK_ATTN, st);
+        return launch_attn_q4f(a, true, st);
+    }
     ProfScope ps(c, PK_ATTN, st);
     if (c->mfma) S2V_TRY(launch_attn_bf16(a, st));
     else S2V_TRY(launch_attn_simple(a, c->dtype, st));
@@ -1031,6 +1049,27 @@ extern "C" int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias,
     S2V_REQUIRE(emb && W && out, "s2v_op_mod_gemv: null argument");
     S2V_REQUIRE(dtype == S2V_DTYPE_BF16 || dtype == S2V_DTYPE_F32, "s2v_op_mod_gemv: dtype must be bf16 or f32");
     return launch_mod_gemv(emb, B, temb_dim, W, bias, rows, out, dtype, (hipStream_t)stream, impl == 1);
+}
+
+// attention with QK^T on the scaled fp8 MFMA as weight_format 2 runs it: q (times scale * log2 e) and k of the bf16 qkv rows become MX e4m3
+// images in `scratch` (also returned to the caller for inspection: layout in kernels.h AttnArgs::q8 ... k8s, offsets below), V^T and P.V stay bf16.
+extern "C" int s2v_op_attention_fp8qk(const void* qkv, void* vt_scratch, void* scratch, int64_t scratch_bytes, void* out, int32_t B, int32_t H,
+                                      int32_t Ntok, s2v_stream stream) {
+    S2V_REQUIRE(qkv && vt_scratch && scratch && out, "s2v_op_attention_fp8qk: null argument");
+    const int D = H * 64;
+    const int64_t ntok_pad = rup(Ntok, 64), BH = (int64_t)B * H;
+    const int64_t oq8 = 0, oq8s = oq8 + rup(BH * Ntok * 64, 256), ok8 = oq8s + rup(BH * Ntok * 2, 256), ok8s = ok8 + rup(BH * ntok_pad * 64, 256);
+    S2V_REQUIRE(scratch_bytes >= ok8s + BH * ntok_pad * 4, "s2v_op_attention_fp8qk: scratch too small (B*H*(66*Ntok + 68*ntok_pad) + 1024 bytes)");
+    AttnArgs a{};
+    a.qkv = qkv; a.ld_qkv = 3 * D; a.out = out; a.ld_out = D; a.B = B; a.H = H; a.Ntok = Ntok; a.scale = 0.125f;
+    a.ntok_pad = (int)ntok_pad; a.vt = vt_scratch;
+    char* w = (char*)scratch;
+    a.q8 = (unsigned char*)(w + oq8); a.q8s = (unsigned short*)(w + oq8s); a.k8 = (unsigned char*)(w + ok8); a.k8s = (unsigned*)(w + ok8s);
+    hipStream_t st = (hipStream_t)stream;
+    S2V_TRY(launch_v_transpose(qkv, 3 * D, B, H, Ntok, vt_scratch, a.ntok_pad, st));
+    S2V_TRY(launch_qk_quant_mx(qkv, 3 * D, B, H, Ntok, a.ntok_pad, a.scale * 1.4426950408889634f, (unsigned char*)a.q8, (unsigned short*)a.q8s,
+                               (unsigned char*)a.k8, (unsigned*)a.k8s, st));
+    return launch_attn_q4f(a, false, st);
 }
 
 extern "C" int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok,

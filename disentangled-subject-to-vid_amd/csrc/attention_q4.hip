@@ -65,8 +65,12 @@ extern "C" __attribute__((visibility("default"))) int s2v_attn_slow_read(unsigne
 #endif
 // JB = 32-row blocks per wave: 2 = attn_q4 (four waves x 64 rows, one per SIMD), 1 = attn_q8 (eight waves x 32 rows, two per SIMD, the
 // same fine-grained stream in both: gen_attn_q4.py)
-template <int JB>
+// F8 (JB = 2 only, attn_q4f): q and k are read as MX e4m3 images (AttnArgs::q8 / k8 + block scales, made by qk_quant_mx_k) and S^T = K.Q^T runs
+// on v_mfma_scale_f32_32x32x64_f8f6f4 -- 4 MFMA of 64 cycles per KV tile instead of 16 of 32; V^T, P.V, softmax and the epilogue are the bf16
+// kernel's.  No reference code for it (the reference has no fp8 path): parity unpinned, selected only by weight_format 2.
+template <int JB, bool F8 = false>
 __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg, char* smem) {
+    static_assert(!F8 || JB == 2, "the fp8 QK^T body exists for the four-wave form only");
     constexpr int NW = 8 / JB;  // waves per work item
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -76,7 +80,7 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
     const int D = a.H * 64;
 
     const bf16_t* qkv = (const bf16_t*)a.qkv + (size_t)b * a.Ntok * a.ld_qkv;
-    const char* Kg = (const char*)(qkv + D + h * 64);
+    const char* Kg = (const char*)(qkv + D + h * 64);  // (F8: the e4m3 image, below)
     const char* VTg = (const char*)((const bf16_t*)a.vt + (size_t)(b * a.H + h) * 64 * a.ntok_pad);
     const int nt = (a.Ntok + KV_TILE - 1) / KV_TILE;
     const unsigned lds0 = lds_base_u32(smem);
@@ -86,13 +90,26 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
     const int srow = wave * 8 + (lane >> 3);
     const int sc = (lane & 7) ^ ((srow >> 1) & 7);
     u32x8 vin;  // [0..3] fragment address of k-step kk in slot 0 (the 32-row half and the slot are immediates), [4..7] staging offsets
+    u32x4 kin = {0, 0, 0, 0};  // F8: [0 / 1] LDS address of chunks hi / 2 + hi of key fr in slot 0, [2] the lane's dword of a tile's block scales
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) vin[kk] = lds0 + fr * 128 + (((kk * 2 + hi) ^ ((fr >> 1) & 7)) << 4);
-    vin[4] = (unsigned)(2 * (srow * a.ld_qkv + sc * 8));
-    vin[5] = vin[4] + 64u * a.ld_qkv;
+    if constexpr (F8) {
+        // e4m3 K tile: 64 keys x 64 B; wave w stages keys 16 w .. 16 w + 15 (one 1-KiB piece), lane = (key, 16-byte position), the chunk XOR
+        // ((key >> 2) & 3) on the SOURCE address; a lane's MFMA operand of a 32-key half = chunks hi and 2 + hi of key fr
+        Kg = (const char*)a.k8 + (size_t)(b * a.H + h) * a.ntok_pad * 64;
+        const int krow = wave * 16 + (lane >> 2);
+        kin[0] = lds0 + fr * 64 + (((0 + hi) ^ ((fr >> 2) & 3)) << 4);
+        kin[1] = lds0 + fr * 64 + (((2 + hi) ^ ((fr >> 2) & 3)) << 4);
+        kin[2] = (unsigned)lane * 4;
+        vin[4] = (unsigned)(krow * 64 + (((lane & 3) ^ ((krow >> 2) & 3)) << 4));
+        vin[5] = 0;
+    } else {
+        vin[4] = (unsigned)(2 * (srow * a.ld_qkv + sc * 8));
+        vin[5] = vin[4] + 64u * a.ld_qkv;
+    }
     vin[6] = (unsigned)(2 * (srow * a.ntok_pad + sc * 8));
     vin[7] = vin[6] + 64u * a.ntok_pad;
-    const unsigned k_tile_stride = (unsigned)KV_TILE * a.ld_qkv * 2;
+    const unsigned k_tile_stride = F8 ? 4096u : (unsigned)KV_TILE * a.ld_qkv * 2;
     const unsigned m0w = lds0 + wave * 1024;  // LDS address of this wave's first piece in slot 0
     // tiles past the end are clamped (re-staged into a dead slot): every wave issues the same number of DMAs in every iteration
     auto k_src = [&](int t) __attribute__((always_inline)) { return Kg + (size_t)min(t, nt - 1) * k_tile_stride; };
@@ -100,7 +117,7 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int p = 0; p < JB; ++p) glds16_saddr_m0(k_src(i), vin[4 + p], m0w + i * 16384 + p * 4096);
+        for (int p = 0; p < (F8 ? 1 : JB); ++p) glds16_saddr_m0(k_src(i), vin[4 + p], m0w + i * 16384 + p * 4096);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -108,19 +125,35 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
 
     // Q fragments of the wave's row blocks, pre-multiplied by scale * log2(e) and rounded to bf16 once (as attn_pp_item); word 16 j + 4 kk
     const float c0 = a.scale * 1.4426950408889634f;
-    typedef __attribute__((ext_vector_type(16 * JB))) unsigned int qf_t;
+    typedef __attribute__((ext_vector_type((F8 ? 8 : 16) * JB))) unsigned int qf_t;
     qf_t qf;
     int q_row[JB];
+    u32x4 ks_ring = {0, 0, 0, 0};  // F8: block scales of K tiles 0 .. 2 (the body loads tile t + 3 in iteration t)
+    u32x2 qs = {0, 0};             // F8: block scale of (query row of block j, 32-element block hi) in byte 0
+    const char* ksb = nullptr;
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
         q_row[j] = qb * 256 + wave * (32 * JB) + j * 32 + fr;
         const int q_ld = min(q_row[j], a.Ntok - 1);
+        if constexpr (F8) {  // the image already carries scale * log2(e) (qk_quant_mx_k)
+            const size_t qr = (size_t)(b * a.H + h) * a.Ntok + q_ld;
+            const u32x4 lo = *(const u32x4*)(a.q8 + qr * 64 + hi * 16), hi4 = *(const u32x4*)(a.q8 + qr * 64 + 32 + hi * 16);
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const bf16x8 q = *(const bf16x8*)(qkv + (size_t)q_ld * a.ld_qkv + h * 64 + kk * 16 + hi * 8);
+            for (int e = 0; e < 4; ++e) { qf[8 * j + e] = lo[e]; qf[8 * j + 4 + e] = hi4[e]; }
+            qs[j] = ((unsigned)a.q8s[qr] >> (8 * hi)) & 0xffu;
+        } else {
 #pragma unroll
-            for (int e = 0; e < 8; e += 2) qf[16 * j + 4 * kk + (e >> 1)] = pack2bf((float)q[e] * c0, (float)q[e + 1] * c0);
+            for (int kk = 0; kk < 4; ++kk) {
+                const bf16x8 q = *(const bf16x8*)(qkv + (size_t)q_ld * a.ld_qkv + h * 64 + kk * 16 + hi * 8);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) qf[16 * j + 4 * kk + (e >> 1)] = pack2bf((float)q[e] * c0, (float)q[e + 1] * c0);
+            }
         }
+    }
+    if constexpr (F8) {
+        ksb = (const char*)(a.k8s + (size_t)(b * a.H + h) * (a.ntok_pad / 64) * 64);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ks_ring[i] = *(const unsigned*)(ksb + (size_t)min(i, nt - 1) * 256 + lane * 4);
     }
     u32x4 ptr, sin;  // sources of the next K / V^T tile to stage (64-bit each); nt, K tile stride, Ntok, LDS address of the wave's first piece
     {
@@ -135,7 +168,16 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if constexpr (JB == 2) {
+    if constexpr (F8) {
+        u32x2 ksbp;
+        ksbp[0] = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)ksb);
+        ksbp[1] = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)ksb >> 32));
+        asm volatile(
+#include "attn_q4f_body.inc"
+            : "=" Q4F_OT0(OT[0]), "=" Q4F_OT1(OT[JB - 1]), "=" Q4F_LRUN(LR), "+" Q4F_PTR(ptr), "=" Q4F_CNT(slow_cnt), "+" Q4F_KS(ks_ring)
+            : Q4F_QF(qf), Q4F_VIN(vin), Q4F_SIN(sin), Q4F_QS(qs), Q4F_KIN(kin), Q4F_KSB(ksbp)
+            : Q4F_CLOBBERS);
+    } else if constexpr (JB == 2) {
         asm volatile(
 #include "attn_q4_body.inc"
             : "=" Q4_OT0(OT[0]), "=" Q4_OT1(OT[JB - 1]), "=" Q4_LRUN(LR), "+" Q4_PTR(ptr), "=" Q4_CNT(slow_cnt)
@@ -214,14 +256,14 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
         }
     }
 }
-template <int JB>
+template <int JB, bool F8 = false>
 __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_k(const AttnArgs a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 slots][K tile | VT tile]
     int first, cnt;
     attn_xcd_range((int)gridDim.x, blockIdx.x & 7, first, cnt);
-    attn_qx_item<JB>(a, nqb, first + (int)(blockIdx.x >> 3), smem);
+    attn_qx_item<JB, F8>(a, nqb, first + (int)(blockIdx.x >> 3), smem);
 }
-template <int JB>
+template <int JB, bool F8 = false>
 __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const AttnArgs a, int nqb, int total, int* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_item;
@@ -243,7 +285,7 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
         const int wg = s_item;
         __syncthreads();
         if (wg < 0) break;
-        attn_qx_item<JB>(a, nqb, wg, smem);
+        attn_qx_item<JB, F8>(a, nqb, wg, smem);
     }
     if (threadIdx.x == 0) {
         __threadfence();
@@ -254,21 +296,21 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
     }
 }
 
-template <int JB>
+template <int JB, bool F8 = false>
 static int launch_attn_qx(const AttnArgs& a, bool persistent, hipStream_t st) {
     const int nqb = (a.Ntok + 255) / 256;  // 256 query rows per item in both forms
     const int total = nqb * a.B * a.H;
     const size_t lds = 65536;
     const dim3 blk(64 * (8 / JB));
     if (persistent && a.queue != nullptr && a.num_cus >= 8) {
-        const void* fn = (const void*)attn_qx_persist_k<JB>;
+        const void* fn = (const void*)attn_qx_persist_k<JB, F8>;
         S2V_TRY(ensure_lds_attr(fn, 65536));
         int* queue = a.queue;
         void* args[] = {(void*)&a, (void*)&nqb, (void*)&total, (void*)&queue};
         S2V_CHECK_HIP(hipLaunchKernel(fn, dim3((a.num_cus / 8) * 8), blk, args, lds, st));
         return 0;
     }
-    const void* fn = (const void*)attn_qx_k<JB>;
+    const void* fn = (const void*)attn_qx_k<JB, F8>;
     S2V_TRY(ensure_lds_attr(fn, 65536));
     void* args[] = {(void*)&a, (void*)&nqb};
     S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(total), blk, args, lds, st));
@@ -276,3 +318,7 @@ static int launch_attn_qx(const AttnArgs& a, bool persistent, hipStream_t st) {
 }
 int launch_attn_q4(const AttnArgs& a, bool persistent, hipStream_t st) { return launch_attn_qx<2>(a, persistent, st); }
 int launch_attn_q8(const AttnArgs& a, bool persistent, hipStream_t st) { return launch_attn_qx<1>(a, persistent, st); }
+int launch_attn_q4f(const AttnArgs& a, bool persistent, hipStream_t st) {
+    S2V_REQUIRE(a.q8 && a.k8 && a.q8s && a.k8s && a.vt, "attn_q4f: the MX images of q / k (launch_qk_quant_mx) and V^T are required");
+    return launch_attn_qx<2, true>(a, persistent, st);
+}

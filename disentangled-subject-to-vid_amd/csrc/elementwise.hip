@@ -395,6 +395,65 @@ __global__ __launch_bounds__(256) void v_transpose_k(const bf16_t* qkv, int ld_q
     }
 }
 
+// q / k of the normalised, rotated QKV buffer -> MX e4m3 images for the fp8 QK^T of attn_q4f (AttnArgs::q8 ... k8s; weight_format 2; no
+// reference code: the reference has no fp8 path).  A block = 64 tokens of one head of q or k; a thread = 16 head-dim elements, two threads = one
+// 32-element MX block: x = bf16 value (q: times scale * log2 e, in fp32), amax over the block, E8M0 scale = the smallest power of two with
+// amax / scale <= 448, byte = rne_e4m3(x / scale).  Rows [Ntok, ntok_pad) of k are written as zeros with unit scales.
+__global__ __launch_bounds__(256) void qk_quant_mx_k(const bf16_t* qkv, int ld_qkv, int H, int Ntok, int ntok_pad, float q_prescale,
+                                                      unsigned char* q8, unsigned short* q8s, unsigned char* k8, unsigned* k8s) {
+    const int tile = blockIdx.x, h = blockIdx.y, b = blockIdx.z >> 1, is_k = blockIdx.z & 1;
+    const int tid = threadIdx.x, kr = tid >> 2, qt = tid & 3, blk = qt >> 1;
+    const int n = tile * 64 + kr;
+    if (!is_k && n >= Ntok) return;
+    const int D = H * 64;
+    float x[16];
+    if (n < Ntok) {
+        const bf16_t* src = qkv + (size_t)(b * Ntok + n) * ld_qkv + is_k * D + h * 64 + qt * 16;
+        const u32x4 v0 = *(const u32x4*)src, v1 = *(const u32x4*)(src + 8);
+        const float c = is_k ? 1.0f : q_prescale;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            x[2 * e] = __uint_as_float(v0[e] << 16) * c; x[2 * e + 1] = __uint_as_float(v0[e] & 0xffff0000u) * c;
+            x[8 + 2 * e] = __uint_as_float(v1[e] << 16) * c; x[8 + 2 * e + 1] = __uint_as_float(v1[e] & 0xffff0000u) * c;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) x[e] = 0.f;
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(x[e]));
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    unsigned eb = (__float_as_uint(amax * (1.0f / 448.0f)) + 0x7fffffu) >> 23;
+    eb = n < Ntok ? min(max(eb, 1u), 253u) : 127u;
+    const float inv = __uint_as_float((254u - eb) << 23);
+    u32x4 o;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        int r = 0;
+        r = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * w] * inv, x[4 * w + 1] * inv, r, false);
+        r = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * w + 2] * inv, x[4 * w + 3] * inv, r, true);
+        o[w] = (unsigned)r;
+    }
+    const size_t bh = (size_t)b * H + h;
+    if (is_k) {
+        *(u32x4*)(k8 + (bh * ntok_pad + n) * 64 + qt * 16) = o;
+        if ((qt & 1) == 0)
+            ((unsigned char*)k8s)[((bh * (ntok_pad / 64) + tile) * 64 + blk * 32 + (kr & 31)) * 4 + (kr >> 5)] = (unsigned char)eb;
+    } else {
+        *(u32x4*)(q8 + (bh * Ntok + n) * 64 + qt * 16) = o;
+        if ((qt & 1) == 0) ((unsigned char*)q8s)[(bh * Ntok + n) * 2 + blk] = (unsigned char)eb;
+    }
+}
+int launch_qk_quant_mx(const void* qkv, int ld_qkv, int B, int H, int Ntok, int ntok_pad, float q_prescale, unsigned char* q8, unsigned short* q8s,
+                       unsigned char* k8, unsigned* k8s, hipStream_t st) {
+    S2V_REQUIRE(ntok_pad % 64 == 0 && ntok_pad >= Ntok, "qk_quant_mx: ntok_pad must be a multiple of 64 covering Ntok");
+    hipLaunchKernelGGL(qk_quant_mx_k, dim3(ntok_pad / 64, H, 2 * B), dim3(256), 0, st, (const bf16_t*)qkv, ld_qkv, H, Ntok, ntok_pad, q_prescale, q8,
+                       q8s, k8, k8s);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_qk_norm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t st) {
     dim3 grid((unsigned)(a.B * a.Ntok), (unsigned)((2 * a.H * 8 + 255) / 256));
     if (dtype == S2V_BF16)

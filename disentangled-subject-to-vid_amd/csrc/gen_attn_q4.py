@@ -34,6 +34,16 @@ import os
 import sys
 
 JB = 2  # set by main() per output
+# F8 (set by main() for attn_q4f_body.inc, JB = 2 only): Q and K are MX e4m3 images (32-element blocks along the head dimension, one E8M0 scale
+# each; produced by qk_quant_mx_k, elementwise.hip) and S^T = K.Q^T is ONE v_mfma_scale_f32_32x32x64_f8f6f4 per (row block, 32-key half):
+# 4 MFMA of 64 cycles per tile instead of 16 of 32.  No reference code (the reference has no fp8 path: parity unpinned); P.V stays bf16.
+#   K tile in LDS: 64 keys x 64 B (4 KiB = ONE 1-KiB piece per wave), 16-byte chunks XOR-ed with (key >> 2) & 3 on the source address; a lane's
+#   operand = chunks hi and 2 + hi of its row (the instruction's logical blocks are bytes 16 b .. 16 b + 15 of both lane halves, tools/probes/mfma_mx.hip),
+#   i.e. two ds_read_b128 per 32-key half: v[KIN + 0 / 1] = addresses of the two chunks in slot 0 (v[VIN + 0 .. 3] stay the V^T fragment addresses).
+#   K block scales: one dword per lane and tile ([tile][lane] in memory: byte kb = scale of (key 32 kb + (lane & 31), block lane >> 5)), loaded
+#   straight into a ring of four VGPRs three tiles ahead (the end-of-iteration vmcnt(4) covers it as it covers the LDS-DMA pieces);
+#   Q block scales: v[QS + j], byte 0.
+F8 = False
 # Deferred maximum: a row keeps the maximum its first tile adopted until a partial row sum of a later tile exceeds 2^64, i.e. until some
 # p = exp2(s - m) does -- fp32 and bf16 share the exponent range, sums and P.V stay below 2^64 * N * |v| << 2^127, and every quantity is
 # scale-free, so nothing is lost by letting m lag (keys 2^126 below the adopted maximum flush to zero, as they would below any maximum).
@@ -55,11 +65,13 @@ SPLIT = os.environ.get("Q4_SPLIT", "")
 SUM = os.environ.get("Q4_SUM", "add")
 ABLATE = set(filter(None, os.environ.get("Q4_ABLATE", "").split(",")))  # timing experiments only (results are wrong)
 S_KPTR, S_VPTR, S_T, S_END, S_KADV, S_VADV, S_NT, S_KSTR, S_NTOK, S_M0W, S_THR, S_RET, S_X0, S_X1, S_CNT, S_ONES = 36, 38, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53
+S_KSB, S_KSX, S_NTM1, S_KSA = 54, 56, 57, 58  # F8: IN K block-scale base (64-bit); scratch; nt - 1; address of the tile being loaded (64-bit)
 
 
-def layout(jb):
-    global JB, ST, NEGM, PK, TMP, PS, VIN, LRUN, VS, OT, QF, KF, VF, NM
+def layout(jb, f8=False):
+    global JB, ST, NEGM, PK, TMP, PS, VIN, LRUN, VS, OT, QF, KF, VF, NM, F8, KS, QS, KIN
     JB = jb
+    F8 = f8
     ST, NEGM, PK, TMP = 0, 64 * jb, 80 * jb, 96 * jb
     PS = TMP + 8
     VIN = PS + 4 * jb
@@ -68,6 +80,9 @@ def layout(jb):
     OT, QF, KF = 0, 32 * jb, 48 * jb
     VF = KF + 32
     NM = 8 * jb            # MFMAs per segment
+    KS = VS + 12           # F8: ring of four K block-scale registers (tile t -> KS + (t & 3)); IN: the first three
+    QS = KS + 4            # F8: IN Q block scales of row block j
+    KIN = QS + 2           # F8: IN [0 / 1] address of chunks hi / 2 + hi of the lane's key in slot 0 (e4m3 K tile), [2] 4 * lane (scale dword of a tile)
 
 
 def vr(base, n=1):
@@ -172,6 +187,19 @@ def frag_read(dst_base, i, slot, is_v):
     # fragment i = (k-step i >> 1, 32-row half i & 1) of the K (V^T) tile in ring slot `slot`
     off = slot * 16384 + (8192 if is_v else 0) + (i & 1) * 4096
     return f"ds_read_b128 {ar(dst_base + 4 * i, 4)}, {vr(VIN + (i >> 1))} offset:{off}"
+
+
+def frag_read_k8(i, slot):
+    # F8: fragment i = (32-key half i >> 1, chunk pair member i & 1) of the e4m3 K tile in ring slot `slot`
+    kb, c = i >> 1, i & 1
+    return f"ds_read_b128 {ar(KF + 8 * kb + 4 * c, 4)}, {vr(KIN + c)} offset:{slot * 16384 + kb * 2048}"
+
+
+def qk_mfma_f8(buf, i, ring):
+    j, kb = i % JB, i // JB
+    sel = f" op_sel:[{kb},0,0] op_sel_hi:[0,0,0]"
+    return (f"v_mfma_scale_f32_32x32x64_f8f6f4 {vr(st(buf, j, kb), 16)}, {ar(KF + 8 * kb, 8)}, {ar(QF + 8 * j, 8)}, {vr(NEGM + 16 * j, 16)}, "
+            f"{vr(KS + ring)}, {vr(QS + j)}{sel}")
 
 
 def qk_mfma(buf, i):
@@ -320,6 +348,8 @@ def gen():
     emit(f"s_mov_b32 s{S_ONES}, 0x3f803f80")         # bf16 (1.0, 1.0)
     emit(f"s_mov_b32 s{S_KADV}, s{S_KSTR}")
     emit(f"s_mov_b32 s{S_VADV}, 128")
+    if F8:
+        emit(f"s_sub_u32 s{S_NTM1}, s{S_NT}, 1")
     emit(f"s_sub_u32 s{S_END}, s{S_NT}, 5")      # phase A ends at nt - 5 ...
     emit(f"s_cmp_gt_i32 s{S_END}, 0")
     emit("s_cbranch_scc1 L_q4_pa_%=")
@@ -328,13 +358,23 @@ def gen():
     emit(f"s_mov_b32 s{S_KADV}, 0")
     emit("L_q4_pa_%=:")
     # ---------------- prologue: K(0) fragments, S(0) -> st[0], K(1) fragments, tail mask, adoption of tile 0's maxima
-    for i in range(8):
-        emit(frag_read(KF, i, 0, False))
-    emit("s_waitcnt lgkmcnt(0)")
-    for i in range(NM):
-        emit(qk_mfma(0, i))
-    for i in range(8):
-        emit(frag_read(KF, i, 1, False))
+    if F8:
+        for i in range(4):
+            emit(frag_read_k8(i, 0))
+        emit("s_waitcnt lgkmcnt(0)")
+        for i in range(2 * JB):
+            emit(qk_mfma_f8(0, i, 0))
+        for i in range(4):
+            emit(frag_read_k8(i, 1))
+        emit("s_nop 15")
+    else:
+        for i in range(8):
+            emit(frag_read(KF, i, 0, False))
+        emit("s_waitcnt lgkmcnt(0)")
+        for i in range(NM):
+            emit(qk_mfma(0, i))
+        for i in range(8):
+            emit(frag_read(KF, i, 1, False))
     emit("s_nop 15")
     emit("s_nop 15")
     emit(f"s_cmp_ge_u32 s{S_NTOK}, 64")
@@ -356,14 +396,24 @@ def gen():
             first, last = [], []
             if i in read_gaps:
                 (first if READPOS == "first" else last).append(frag_read(VF, list(read_gaps).index(i), U, True))
-            for p in range(JB):
+            for p in range(1 if F8 else JB):  # F8: an e4m3 K tile is one piece per wave
                 if i == gap_m0[p]:
                     last.append(f"s_add_u32 m0, s{S_M0W}, {U * 16384 + p * 4096}")
                 if i == gap_dma[p]:
                     (first if DMAPOS == "first" else last).append(f"global_load_lds_dwordx4 {vr(VIN + 4 + p)}, s[{S_KPTR}:{S_KPTR + 1}]")
+            if F8 and i == gap_m0[1]:   # block scales of K tile min(t + 3, nt - 1) -> ring register (t + 3) & 3
+                last += [f"s_add_u32 s{S_KSX}, s{S_T}, 3", f"s_min_u32 s{S_KSX}, s{S_KSX}, s{S_NTM1}", f"s_lshl_b32 s{S_KSX}, s{S_KSX}, 8"]
+            if F8 and i == gap_m0[1] + 1:
+                last += [f"s_add_u32 s{S_KSA}, s{S_KSB}, s{S_KSX}", f"s_addc_u32 s{S_KSA + 1}, s{S_KSB + 1}, 0"]
+            if F8 and i == gap_dma[1]:
+                last.append(f"global_load_dword {vr(KS + ((U + 3) & 3))}, {vr(KIN + 2)}, s[{S_KSA}:{S_KSA + 1}]")
             if i == NM - 2:
                 last += [f"s_add_u32 s{S_KPTR}, s{S_KPTR}, s{S_KADV}", f"s_addc_u32 s{S_KPTR + 1}, s{S_KPTR + 1}, 0"]
-            for ln in [qk_mfma(nxt, i)] + first + soft[soft_lo(i):soft_lo(i + 1)] + last:
+            if F8:  # four 64-cycle MFMAs, one per four gaps of the softmax stream
+                head = [qk_mfma_f8(nxt, i // 4, (U + 1) & 3)] if i % 4 == 0 else []
+            else:
+                head = [qk_mfma(nxt, i)]
+            for ln in head + first + soft[soft_lo(i):soft_lo(i + 1)] + last:
                 emit(ln)
         # check of tile t: the partial row sums against the threshold (any lane)
         max_ps(emit, cur)
@@ -377,7 +427,10 @@ def gen():
         ladd = {1: (0, 0), 7: (0, 1), 13: (1, 0), 15: (1, 1)} if JB == 2 else {1: (0, 0), 7: (0, 1)}
         for i in range(NM):
             first, last = [], []
-            if i in read_gaps:
+            if F8:
+                if i in (0, 2, 4, 6):
+                    (first if READPOS == "first" else last).append(frag_read_k8(i >> 1, slot2))
+            elif i in read_gaps:
                 (first if READPOS == "first" else last).append(frag_read(KF, list(read_gaps).index(i), slot2, False))
             if i in ladd:
                 jj, x = ladd[i]
@@ -458,15 +511,19 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "attn_q4_regs.h"), "w") as f:
         f.write("// generated by gen_attn_q4.py: the physical registers the bodies of attn_q4 (JB = 2) / attn_q8 (JB = 1) own\n#pragma once\n")
-        for jb, name in ((2, "Q4"), (1, "Q8")):
-            layout(jb)
+        for jb, name, f8 in ((2, "Q4", False), (1, "Q8", False), (2, "Q4F", True)):
+            layout(jb, f8)
             with open(os.path.join(here, f"attn_{name.lower()}_body.inc"), "w") as g:
                 for ln in gen():
                     g.write('"' + ln + '\\n\\t"\n')
             clob = [f"v{r}" for r in list(range(0, VIN)) + list(range(VS, VS + 12))] + [f"a{r}" for r in range(KF, VF + 32)]
             clob += [f"s{r}" for r in (S_T, S_END, S_KADV, S_VADV, S_THR, S_RET, S_X0, S_X1, S_ONES)]
-            for nm, cls, base, n in [("VIN", "v", VIN, 8), ("LRUN", "v", LRUN, 2), ("QF", "a", QF, 16 * jb), ("PTR", "s", S_KPTR, 4),
-                                     ("SIN", "s", S_NT, 4)] + [(f"OT{j}", "a", OT + 32 * j, 32) for j in range(jb)]:
+            extra = []
+            if f8:
+                clob += [f"s{r}" for r in (S_KSX, S_NTM1, S_KSA, S_KSA + 1)]
+                extra = [("KS", "v", KS, 4), ("QS", "v", QS, 2), ("KIN", "v", KIN, 4), ("KSB", "s", S_KSB, 2)]  # KS is in / out ("+"): the body reloads the ring
+            for nm, cls, base, n in [("VIN", "v", VIN, 8), ("LRUN", "v", LRUN, 2), ("QF", "a", QF, (8 if f8 else 16) * jb), ("PTR", "s", S_KPTR, 4),
+                                     ("SIN", "s", S_NT, 4)] + extra + [(f"OT{j}", "a", OT + 32 * j, 32) for j in range(jb)]:
                 f.write(f'#define {name}_{nm} "{{{cls}[{base}:{base + n - 1}]}}"\n')
             f.write(f'#define {name}_CNT "{{s{S_CNT}}}"\n')
             f.write(f"#define {name}_CLOBBERS " + ", ".join(f'"{c}"' for c in clob) + ', "vcc", "scc", "m0", "memory"\n')

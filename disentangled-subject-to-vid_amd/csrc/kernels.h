@@ -120,7 +120,17 @@ struct AttnArgs {
     // fp8 engine, attn_q4 only: write the output as MX e4m3 [B*Ntok][ld_out] bytes + block scales (K-tile major, GemmArgs::mx_a_s:
     // [ld_out / 128][mx_rows] dwords) INSTEAD of the bf16 `out` (the out-projection reads it through GemmArgs::mx_a_s)
     unsigned char* mx_q; unsigned char* mx_s; int mx_rows;
+    // fp8 QK^T (weight_format 2, attn_q4f): MX e4m3 images of q (pre-multiplied by scale * log2 e) and k, written by launch_qk_quant_mx:
+    //   q8 [B][H][Ntok][64] bytes, q8s [B][H][Ntok] (byte 0 / 1 = E8M0 scale of head-dim block 0 / 1),
+    //   k8 [B][H][ntok_pad][64] bytes (rows past Ntok zero), k8s [B][H][ntok_pad / 64][64] dwords: dword (hi * 32 + r) of a 64-key tile holds in
+    //   byte kb the E8M0 scale of (key 32 kb + r, block hi) -- the scale VGPR of the QK^T MFMA, loaded as is
+    const unsigned char* q8; const unsigned short* q8s; const unsigned char* k8; const unsigned* k8s;
 };
+// q / k of the (normalised, rotated) QKV buffer -> the MX e4m3 images above (elementwise.hip)
+int launch_qk_quant_mx(const void* qkv, int ld_qkv, int B, int H, int Ntok, int ntok_pad, float q_prescale, unsigned char* q8, unsigned short* q8s,
+                       unsigned char* k8, unsigned* k8s, hipStream_t st);
+// attn_q4 with QK^T on the scaled fp8 MFMA (attention_q4.hip); needs a.q8 / q8s / k8 / k8s and a.vt
+int launch_attn_q4f(const AttnArgs& a, bool persistent, hipStream_t st);
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st);
 int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st);
 // four-wave form of the bf16 kernel (attention_q4.hip); persistent needs a.queue / a.num_cus

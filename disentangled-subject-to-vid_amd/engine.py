@@ -33,9 +33,9 @@ class S2VEngine:
         c.dtype = _lib.DTYPE_OF[dtype]
         c.norm_eps = cfg.norm_eps
         c.force_simple = int(force_simple)
-        if cfg.weight_format not in (None, "fp8"):
-            raise _lib.S2VError(f"unknown weight_format {cfg.weight_format!r} (None or 'fp8')")
-        c.weight_format = 1 if cfg.weight_format == "fp8" else 0
+        if cfg.weight_format not in (None, "fp8", "fp8-qk"):
+            raise _lib.S2VError(f"unknown weight_format {cfg.weight_format!r} (None, 'fp8' or 'fp8-qk')")
+        c.weight_format = {None: 0, "fp8": 1, "fp8-qk": 2}[cfg.weight_format]
         if cfg.lora_adaln_scope not in ("shipped", "intended"):
             raise _lib.S2VError(f"unknown lora_adaln_scope {cfg.lora_adaln_scope!r} ('shipped' or 'intended')")
         c.lora_adaln_scope = 1 if cfg.lora_adaln_scope == "intended" else 0

@@ -51,7 +51,11 @@ typedef struct s2v_model_config {
     int32_t weight_format;    /* 0 = the model dtype; 1 = W8A8 fp8 (BASELINE configs[4]): the four big linears of every block
                                * (fused QKV, attention out, FF1, FF2) keep OCP e4m3 weights with per-output-channel scales
                                * (quantised by s2v_finalize_weights after any LoRA merge) and take per-token e4m3 activations,
-                               * on v_mfma_scale_f32_32x32x64_f8f6f4; bf16 model dtype only, inner_dim % 128 == 0 */
+                               * on v_mfma_scale_f32_32x32x64_f8f6f4; bf16 model dtype only, inner_dim % 128 == 0;
+                               * 2 = 1 plus fp8 QK^T (an option beyond "fp8 weights", off unless asked for): after the per-head LayerNorm and
+                               * rotary embedding q (times scale * log2 e) and k are re-quantised as MX e4m3 (one power-of-two scale per
+                               * 32 head-dim elements) and S = K.Q^T of the attention runs on the same scaled fp8 MFMA; softmax, P and P.V
+                               * stay fp32 / bf16.  The reference has no fp8 path: parity unpinned, tolerance stated in tests/test_gpu_fp8.py */
     int32_t lora_adaln_scope; /* where the subject-LoRA acts inside CogVideoXLayerNormZero (normalization.py:467-484):
                                * 0 = as shipped: `enable_lora([self.linear], False)` sets an attribute nothing reads, so the LoRA
                                *     is active on both evaluations of norm{1,2}.linear and is merged into it (SURVEY preamble 6);
@@ -316,6 +320,14 @@ S2V_API int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias, vo
                             int64_t rows, int32_t dtype, int32_t impl, s2v_stream stream);
 S2V_API int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype,
                      int32_t impl, s2v_stream stream);
+/* The same joint attention (F.scaled_dot_product_attention at attention_processor.py:2083-2087, head_dim 64, scale 1/8) as weight_format 2
+ * runs it: q (times scale * log2 e) and k of the bf16 qkv rows [B*Ntok, 3*H*64] are quantised to MX e4m3 (32-element blocks along the
+ * head dimension, E8M0 scales) into `scratch` and QK^T runs on v_mfma_scale_f32_32x32x64_f8f6f4; V^T (vt_scratch: B*H*64*rup(Ntok,64)
+ * bf16), softmax and P.V as s2v_op_attention impl 0.  scratch >= B*H*(66*Ntok + 68*rup(Ntok,64)) + 1024 bytes; it holds, 256-byte
+ * aligned and in this order, q8 [B][H][Ntok][64], q8s [B][H][Ntok][2], k8 [B][H][Npad][64], k8s [B][H][Npad/64][64] dwords (byte kb of
+ * dword hi*32+r = scale of (key 32*kb+r, block hi)).  No reference arithmetic exists for fp8 (parity unpinned). */
+S2V_API int s2v_op_attention_fp8qk(const void* qkv, void* vt_scratch, void* scratch, int64_t scratch_bytes, void* out, int32_t B,
+                                   int32_t H, int32_t Ntok, s2v_stream stream);
 
 #ifdef __cplusplus
 }

@@ -1,6 +1,7 @@
 """fp8 (e4m3 W8A8) linears vs bf16 linears at the real depth / width of CogVideoX-5B (42 layers), small geometry (322 tokens) and the
 C3 token count (2 layers are not enough to see depth effects; 42 layers at 19126 tokens take ~1.5 s per forward): relative L2 of
-the noise prediction of ONE forward and of the latents after 3 DDIM steps.  There is no reference for this path (parity unpinned)."""
+the noise prediction of ONE forward and of the latents after 3 DDIM steps; the same for "fp8-qk" (weight_format 2: additionally MX e4m3 q / k and
+QK^T on the scaled fp8 MFMA).  There is no reference for these paths (parity unpinned)."""
 import copy, importlib, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,9 +21,9 @@ for (F, H, W, T, tag) in ((3, 8, 12, 226, "322 tokens"), (13, 60, 90, 226, "1912
     pe, ne = (torch.randn(1, T, 4096, generator=g, device=DEV).bfloat16() for _ in range(2))
     ref = (torch.randn(1, 1, 16, H, W, generator=g, device=DEV) * 0.7).bfloat16()
     res = {}
-    for fmt in ("bf16", "fp8"):
+    for fmt in ("bf16", "fp8", "fp8-qk"):
         c = copy.copy(cfg)
-        c.weight_format = None if fmt == "bf16" else "fp8"
+        c.weight_format = None if fmt == "bf16" else fmt
         m = s2v.HipCogVideoXTransformer3DModel(c, torch.bfloat16, DEV)
         m.load_state_dict(sd)
         eng = m.engine
@@ -36,4 +37,5 @@ for (F, H, W, T, tag) in ((3, 8, 12, 226, "322 tokens"), (13, 60, 90, 226, "1912
         torch.cuda.synchronize()
         res[fmt] = (npred, lat.float().clone())
         del m, pipe, eng
-    print(f"{tag}: fp8 vs bf16 rel-L2  one forward (42 layers) {rel(res['fp8'][0], res['bf16'][0]):.3e}   latents after 3 DDIM steps {rel(res['fp8'][1], res['bf16'][1]):.3e}", flush=True)
+    for fmt in ("fp8", "fp8-qk"):
+        print(f"{tag}: {fmt} vs bf16 rel-L2  one forward (42 layers) {rel(res[fmt][0], res['bf16'][0]):.3e}   latents after 3 DDIM steps {rel(res[fmt][1], res['bf16'][1]):.3e}", flush=True)
