@@ -323,7 +323,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_stag(const GemmArgs a, int t
 
 // ---------------------------------------------------------------------------------------------------
 // 256 x 256 block tiles (gemm_bf16_w8, gemm_bf16_pp64).  A four-wave 128 x 128-wave-tile form, a ping-pong on K32 stages and a
-// sixteen-wave ping-pong were measured and removed.
+// sixteen-wave ping-pong were measured (HISTORY.md section 3) and removed.
 #define WBM 256
 #define WBN 256
 #define K32 32
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
 }
 
 // ---------------------------------------------------------------------------------------------------
-#ifdef S2V_DIAG  // an experiment kept for the record ("four-wave persistent form"): it equals gemm_bf16_pp64, it does
+#ifdef S2V_DIAG  // an experiment kept for the record (HISTORY.md section 3, "four-wave persistent form"): it equals gemm_bf16_pp64, it does
                  // not beat it, and it serves two epilogues only -- libs2v_hip_diag.so / tools/stall_q4.py / tools/check_q4.py
 // gemm_q4: PERSISTENT 256 x 256 block tile, FOUR waves (2 x 2) of 128 x 128 wave tiles = ONE wave per SIMD, K-tiles of 128 bytes
 // in two 64-KiB LDS stages.  A 128 x 128 wave tile reads 8 fragments per 16 MFMA where the 128 x 64 tiles of the eight-wave kernels
