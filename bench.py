@@ -327,6 +327,19 @@ def main(argv=None):
     cfg = s2v.config.PRESETS[preset]()
     fp8 = cfg.weight_format in ("fp8", "fp8-qk")
     dt = torch.bfloat16
+    vae = None
+    if rank == 0 and not args.no_vae:
+        # The decoder is created, and its first tiled decode run, BEFORE the transformer engine exists: the runtime binds a stream to a hardware
+        # queue at its first use, and the six streams of the tiled decode (six tiles in flight) share the queues best when they are bound while
+        # no other stream of the process has been used (HISTORY.md section 3, tools/vae_inproc_probe.py: 0.525 s against 0.57-0.59 s for a
+        # decoder created after a loaded engine; the untiled decode is the same either way).  A caller gets the same by constructing
+        # HipAutoencoderKLCogVideoX before the transformer; nothing here is inside the timed region of the metric.
+        vcfg = s2v.VAEConfig(scaling_factor=cfg.vae_scaling_factor)
+        vae = s2v.HipAutoencoderKLCogVideoX(vcfg, dt, dev)
+        vae.load_state_dict(s2v.weights.synthetic_vae_state_dict(vcfg, seed=7, device=dev))
+        vae.use_tiling = True
+        vae.decode_latents(torch.randn(1, F, cfg.in_channels, H, W, generator=torch.Generator().manual_seed(3)).to(dev, dt))
+        torch.cuda.synchronize()
     eng = s2v.S2VEngine(cfg, dt, dev)
     t_load = time.time()
     n_lora = 0
@@ -477,10 +490,6 @@ def main(argv=None):
     if rank == 0 and not args.no_vae:
         # wall-clock per video = 50 denoise steps + VAE decode (BASELINE.json metric, second half); decode is timed once
         # outside the step timing, untiled (288 GB part) and tiled (what src/inference.py:204-207 enables)
-        torch.cuda.empty_cache()  # the tiled decode sizes its workspace sets (tiles in flight) by the free HBM: hand back torch's cached blocks
-        vcfg = s2v.VAEConfig(scaling_factor=cfg.vae_scaling_factor)
-        vae = s2v.HipAutoencoderKLCogVideoX(vcfg, dt, dev)
-        vae.load_state_dict(s2v.weights.synthetic_vae_state_dict(vcfg, seed=7, device=dev))
         dec = {}
         for tiling in (False, True):
             vae.use_tiling = tiling
