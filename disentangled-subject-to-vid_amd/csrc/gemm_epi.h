@@ -146,6 +146,18 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
         }
         rot_load(0, 0);
     }
+    // EPI_BIAS_ADD on 64-row wave tiles (the VAE's residual convolutions on gemm_bf16_stag: K loops of 17 us, two dependent memory latencies per
+    // epilogue were 0.65 ms of a 2.6 ms launch, tools/vae_conv_rates.py): the residual vectors of ALL row groups are requested here, before the
+    // accumulators go through the patch, instead of one GRP at a time behind the read-back
+    constexpr bool PRE = EPI == EPI_BIAS_ADD && MB == 2;
+    u32x4 xpre[PRE ? MB * 4 : 1];
+    if (PRE) {
+        const int npre = nw + c16 * 8 < a.N ? nw + c16 * 8 : 0;
+#pragma unroll
+        for (int it = 0; it < MB * 4; ++it)
+            xpre[it] = *(const u32x4*)((const bf16_t*)a.R + (size_t)min(mw + it * 8 + (lane >> 3), a.M - 1) * a.ldr + npre);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // SC (fp8 operands): acc * a_scale[row] * w_scale[column] first -- the dequantisation of the per-token / per-channel scales
     float sa[MB];
 #pragma unroll
@@ -199,7 +211,8 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
                 g[u] = *(const u32x4*)((const bf16_t*)gsel + (size_t)b * a.gate_stride + nc);
                 xo[u] = *(const u32x4*)((const bf16_t*)a.X + (size_t)m * a.ldx + nc);
             } else if (EPI == EPI_BIAS_ADD) {
-                xo[u] = *(const u32x4*)((const bf16_t*)a.R + (size_t)m * a.ldr + nc);
+                if (PRE) xo[u] = xpre[PRE ? it0 + u : 0];
+                else xo[u] = *(const u32x4*)((const bf16_t*)a.R + (size_t)m * a.ldr + nc);
             }
         }
 #pragma unroll

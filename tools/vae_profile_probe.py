@@ -11,6 +11,9 @@ if "tiled" in sys.argv:
     vae.enable_tiling()
 lat = torch.randn(1, 13, 16, 60, 90, device=DEV).bfloat16()
 vae.decode_latents(lat); torch.cuda.synchronize()
+if "once" in sys.argv:  # tools/vae_conv_rates.py: one more decode only (the conv log then holds exactly two decodes)
+    vae.decode_latents(lat); torch.cuda.synchronize()
+    sys.exit(0)
 t0 = time.time()
 for _ in range(3):
     vae.decode_latents(lat)
