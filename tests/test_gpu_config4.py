@@ -78,7 +78,9 @@ def _engine_forward(s2v, cfg, sd, lat, text, ref, t):
     return m, y
 
 
-def test_config4_fp8_engine_full_geometry(s2v):
+@pytest.mark.parametrize("fmt", ["fp8", "fp8-qk"])
+def test_config4_fp8_engine_full_geometry(s2v, fmt):
+    """fmt = "fp8": configs[4] as named; "fp8-qk": the option beyond it (MX e4m3 q / k, QK^T on the scaled fp8 MFMA) at the same geometry"""
     cfg = s2v.cogvideox_5b()
     cfg.num_layers = 2
     sd = s2v.weights.synthetic_state_dict(cfg, seed=43, device=DEV, parity=True)
@@ -90,7 +92,7 @@ def test_config4_fp8_engine_full_geometry(s2v):
     m16, y16 = _engine_forward(s2v, cfg, sd, lat, text, ref, 500.0)
     del m16
     cfg8 = copy.copy(cfg)
-    cfg8.weight_format = "fp8"
+    cfg8.weight_format = fmt
     m8, y8 = _engine_forward(s2v, cfg8, sd, lat, text, ref, 500.0)
     del sd
     assert y8.shape == (2, F4, 16, H4, W4)

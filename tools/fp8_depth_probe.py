@@ -35,7 +35,14 @@ for (F, H, W, T, tag) in ((3, 8, 12, 226, "322 tokens"), (13, 60, 90, 226, "1912
         lat = pipe(prompt_embeds=pe, negative_prompt_embeds=ne, ref_img_states=ref, height=H * 8, width=W * 8, num_frames=(F - 1) * 4 + 1,
                    num_inference_steps=3, guidance_scale=6.0, latents=lat0.clone(), output_type="latent", return_dict=False, use_graph=True)[0]
         torch.cuda.synchronize()
-        res[fmt] = (npred, lat.float().clone())
+        long_steps = 50 if F == 3 else 10   # a full 50-step run at 322 tokens, 10 of 50 (the schedule's first fifth) at 19126
+        sch = s2v.CogVideoXDDIMScheduler(snr_shift_scale=cfg.snr_shift_scale)
+        lat50 = pipe.__class__(m, sch, None)(prompt_embeds=pe, negative_prompt_embeds=ne, ref_img_states=ref, height=H * 8, width=W * 8,
+                                            num_frames=(F - 1) * 4 + 1, num_inference_steps=long_steps, guidance_scale=6.0, latents=lat0.clone(),
+                                            output_type="latent", return_dict=False, use_graph=True)[0]
+        torch.cuda.synchronize()
+        res[fmt] = (npred, lat.float().clone(), lat50.float().clone(), long_steps)
         del m, pipe, eng
     for fmt in ("fp8", "fp8-qk"):
-        print(f"{tag}: {fmt} vs bf16 rel-L2  one forward (42 layers) {rel(res[fmt][0], res['bf16'][0]):.3e}   latents after 3 DDIM steps {rel(res[fmt][1], res['bf16'][1]):.3e}", flush=True)
+        print(f"{tag}: {fmt} vs bf16 rel-L2  one forward (42 layers) {rel(res[fmt][0], res['bf16'][0]):.3e}   latents after 3 DDIM steps {rel(res[fmt][1], res['bf16'][1]):.3e}"
+              f"   after a {res[fmt][3]}-step DDIM run {rel(res[fmt][2], res['bf16'][2]):.3e}", flush=True)
