@@ -325,6 +325,8 @@ def main(argv=None):
 
     preset, F, H, W, T = WORKLOADS[args.workload]
     cfg = s2v.config.PRESETS[preset]()
+    if os.environ.get("S2V_ATTN_P"):   # same-box A/B of attn_p_format ("bf16" / "f16"); the line reports it in config.attn_p_format
+        cfg.attn_p_format = os.environ["S2V_ATTN_P"]
     fp8 = cfg.weight_format in ("fp8", "fp8-qk")
     dt = torch.bfloat16
     vae = None
@@ -548,7 +550,7 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("fp8 (e4m3 W8A8 block linears, MX e4m3 QK^T) + bf16" if cfg.weight_format == "fp8-qk" else "fp8 (e4m3 W8A8 block linears) + bf16") if fp8 else "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
             "config": {"workload": args.workload, "latent_frames": F, "latent_hw": [H, W], "tokens": T + (F + 1) * (H // 2) * (W // 2),
-                       "cfg_pair": 2, "scheduler": "ddim-trailing-50", "parallelism": f"replicas x{world}",
+                       "cfg_pair": 2, "scheduler": "ddim-trailing-50", "attn_p_format": cfg.attn_p_format, "parallelism": f"replicas x{world}",
                        "rccl_ranks": world, "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "launcher": "self-spawned" if os.environ.get("S2V_BENCH_SPAWNED") == "1" else ("torchrun env" if env_world is not None else "single process"),
                        "ranks": ranks_info,

@@ -19,7 +19,7 @@ class ModelConfigC(ctypes.Structure):
         ("out_channels", ctypes.c_int32), ("patch_size", ctypes.c_int32), ("time_embed_dim", ctypes.c_int32),
         ("text_embed_dim", ctypes.c_int32), ("use_rope", ctypes.c_int32), ("dtype", ctypes.c_int32),
         ("norm_eps", ctypes.c_float), ("force_simple", ctypes.c_int32), ("weight_format", ctypes.c_int32),
-        ("lora_adaln_scope", ctypes.c_int32), ("reserved", ctypes.c_int32 * 3),
+        ("lora_adaln_scope", ctypes.c_int32), ("attn_p_format", ctypes.c_int32), ("reserved", ctypes.c_int32 * 2),
     ]
 
 

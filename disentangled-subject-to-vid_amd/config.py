@@ -28,6 +28,9 @@ class TransformerConfig:
     # computes) or "intended" (base weights for video / text modulation, LoRA only for the reference-image chunks,
     # normalization.py:468-478)
     lora_adaln_scope: str = "shipped"
+    # softmax probabilities / V^T of the four-wave attention kernel: "bf16", or "f16" (packed fp16 row sums, P.V on the fp16 MFMA, deferred
+    # maximum 2^14 instead of 2^64: include/s2v_hip.h, attn_p_format)
+    attn_p_format: str = "bf16"
 
     @property
     def inner_dim(self):

@@ -51,6 +51,7 @@ struct s2v_ctx {
     float* lora_tmp = nullptr;   // fp32 scratch of s2v_merge_lora
     size_t lora_tmp_bytes = 0;
     bool fp8 = false;            // cfg.weight_format == 1 or 2
+    bool attn_p16 = false;       // cfg.attn_p_format == 1: P / V^T of the four-wave attention kernels in fp16 (AttnArgs::p16)
     bool fp8_qk = false;         // cfg.weight_format == 2: additionally q / k as MX e4m3 and QK^T on the scaled fp8 MFMA (attn_q4f)
     unsigned char *q8 = nullptr, *k8 = nullptr; unsigned short* q8s = nullptr; unsigned* k8s = nullptr;  // workspace (fp8_qk): AttnArgs::q8 ... k8s
     char* aq = nullptr;          // workspace: e4m3 activations [Mpad][4D] of the GEMM being fed
@@ -194,6 +195,8 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     // fp8 copies live in the same arena (one broadcast replicates everything a replica needs)
     c->fp8 = cfg->weight_format == 1 || cfg->weight_format == 2;
     c->fp8_qk = cfg->weight_format == 2;
+    c->attn_p16 = cfg->attn_p_format == 1;
+    if (cfg->attn_p_format != 0 && cfg->attn_p_format != 1) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "s2v_create: attn_p_format must be 0 (bf16) or 1 (fp16)", -1); }
     if (cfg->weight_format < 0 || cfg->weight_format > 2) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format must be 0, 1 or 2", -1); }
     if (c->fp8 && (!c->mfma || D % 128 != 0)) { s2v_destroy(c); return s2v_fail(__FILE__, __LINE__, "s2v_create: weight_format 1 / 2 (fp8) needs the bf16 MFMA path and inner_dim % 128 == 0", -1); }
     struct QOffs { int64_t q_qkv, q_o, q_1, q_2, s_qkv, s_o, s_1, s_2; };
@@ -654,15 +657,17 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
         if (c->fp8) S2V_TRY(linear_fp8(c, g, epi, w.q_qkv, w.s_qkv, st, prequant));
         else S2V_TRY(linear(c, g, epi, st));
     }
+    // fp16 P / V^T is the four-wave kernels' (attn_q4h / attn_q4fh); short sequences run attn_pp on bf16 V^T
+    const bool p16 = c->attn_p16 && c->mfma && (c->fp8_qk || attn_runs_q4(c->Ntok, attn_mx_out(c)));
     if (fused_qk) {
         ProfScope ps(c, PK_QKNORM, st);
-        S2V_TRY(launch_v_transpose(c->QKV, 3 * D, c->B, c->cfg.num_heads, c->Ntok, c->VT, c->ntok_pad, st));
+        S2V_TRY(launch_v_transpose(c->QKV, 3 * D, c->B, c->cfg.num_heads, c->Ntok, c->VT, c->ntok_pad, st, p16));
     } else {
         QkNormRopeArgs q{};
         q.qkv = c->QKV; q.ld_qkv = 3 * D; q.B = c->B; q.H = c->cfg.num_heads; q.Ntok = c->Ntok; q.text_len = c->T;
         q.nq_w = w.nq_w; q.nq_b = w.nq_b; q.nk_w = w.nk_w; q.nk_b = w.nk_b; q.eps = 1e-6f;
         q.cos = c->have_rope ? c->rope_cos : nullptr; q.sin = c->have_rope ? c->rope_sin : nullptr;
-        q.vt = c->mfma ? c->VT : nullptr; q.ntok_pad = c->ntok_pad;
+        q.vt = c->mfma ? c->VT : nullptr; q.ntok_pad = c->ntok_pad; q.vt_f16 = p16 ? 1 : 0;
         ProfScope ps(c, PK_QKNORM, st);
         S2V_TRY(launch_qk_norm_rope(q, c->dtype, st));
     }
@@ -670,6 +675,7 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     a.qkv = c->QKV; a.ld_qkv = 3 * D; a.vt = c->VT; a.ntok_pad = c->ntok_pad; a.out = c->Xn; a.ld_out = D;
     a.B = c->B; a.H = c->cfg.num_heads; a.Ntok = c->Ntok; a.scale = 0.125f;
     a.queue = c->attn_queue; a.num_cus = c->num_cus;  // launches of one context are ordered on its stream: one queue suffices
+    a.p16 = p16 ? 1 : 0;
     if (attn_mx_out(c)) { a.mx_q = (unsigned char*)c->aq; a.mx_s = c->hs; a.mx_rows = (int)c->Mpad; }
     if (c->fp8_qk) {  // weight_format 2: q (times scale * log2 e) and k as MX e4m3, QK^T on the scaled fp8 MFMA (the pass is timed with the V^T pass)
         {
@@ -1080,10 +1086,12 @@ extern "C" int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, in
     a.qkv = qkv; a.ld_qkv = 3 * D; a.out = out; a.ld_out = D; a.B = B; a.H = H; a.Ntok = Ntok; a.scale = 0.125f;
     a.ntok_pad = (int)rup(Ntok, 64);
     hipStream_t st = (hipStream_t)stream;
-    if (impl == 0) {
-        S2V_REQUIRE(dtype == S2V_DTYPE_BF16 && vt_scratch, "s2v_op_attention: impl 0 is bf16 and needs vt_scratch");
+    if (impl == 0 || impl == 3 || impl == 4) {  // 3: as 0 with P / V^T in fp16 where the four-wave kernel runs (attn_p_format 1); 4: attn_q4h at any length
+        S2V_REQUIRE(dtype == S2V_DTYPE_BF16 && vt_scratch, "s2v_op_attention: impl 0 / 3 / 4 are bf16 and need vt_scratch");
         a.vt = vt_scratch;
-        S2V_TRY(launch_v_transpose(qkv, 3 * D, B, H, Ntok, vt_scratch, a.ntok_pad, st));
+        a.p16 = (impl == 4 || (impl == 3 && attn_runs_q4(Ntok, false))) ? 1 : 0;
+        S2V_TRY(launch_v_transpose(qkv, 3 * D, B, H, Ntok, vt_scratch, a.ntok_pad, st, a.p16 != 0));
+        if (impl == 4) return launch_attn_q4h(a, false, st);
         return launch_attn_bf16(a, st);
     }
     return launch_attn_simple(a, dtype, st);

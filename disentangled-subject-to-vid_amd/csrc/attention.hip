@@ -577,6 +577,10 @@ int launch_attn_bf16(const AttnArgs& a_in, hipStream_t st) {
     // prologue (first-tile maxima, fragment pipeline fill) and walks its last five KV tiles through the rare-path handler, which is
     // nothing at 299 tiles (C3: attn_q4 5-6 % ahead) and a quarter of the iterations at 20 (C1 step 12.01 -> 11.27 ms on one box, DESIGN section 3;
     // tools/attn_small_probe.py).  Same deferred-maximum rule (2^64), results within bf16 rounding of attn_q4's, not bit-identical.
+    if (a.p16) {
+        S2V_REQUIRE(attn_runs_q4(a.Ntok, a.mx_q != nullptr), "attn_bf16: fp16 P / V^T is the four-wave kernel's; short sequences run attn_pp on bf16 V^T");
+        return launch_attn_q4h(a, persist, st);
+    }
     if (a.mx_q == nullptr && a.Ntok <= ATTN_PP_MAX_TOKENS) {
         const void* fn = persist ? (const void*)attn_pp_persist_k<false> : (const void*)attn_pp_k<false>;
         S2V_TRY(ensure_lds_attr(fn, 65536));

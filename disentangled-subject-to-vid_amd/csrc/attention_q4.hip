@@ -68,9 +68,11 @@ extern "C" __attribute__((visibility("default"))) int s2v_attn_slow_read(unsigne
 // F8 (JB = 2 only, attn_q4f): q and k are read as MX e4m3 images (AttnArgs::q8 / k8 + block scales, made by qk_quant_mx_k) and S^T = K.Q^T runs
 // on v_mfma_scale_f32_32x32x64_f8f6f4 -- 4 MFMA of 64 cycles per KV tile instead of 16 of 32; V^T, P.V, softmax and the epilogue are the bf16
 // kernel's.  No reference code for it (the reference has no fp8 path): parity unpinned, selected only by weight_format 2.
-template <int JB, bool F8 = false>
+// P16 (JB = 2 only, attn_q4h / attn_q4fh): P and V^T in fp16, row sums by packed fp16 adds, deferred maximum 2^14 (gen_attn_q4.py, P16); the
+// code around the body is the same -- the format lives in the V^T buffer (AttnArgs::p16) and in the generated instructions.
+template <int JB, bool F8 = false, bool P16 = false>
 __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg, char* smem) {
-    static_assert(!F8 || JB == 2, "the fp8 QK^T body exists for the four-wave form only");
+    static_assert((!F8 && !P16) || JB == 2, "the fp8 QK^T and fp16 P bodies exist for the four-wave form only");
     constexpr int NW = 8 / JB;  // waves per work item
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,11 +174,25 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
         u32x2 ksbp;
         ksbp[0] = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)ksb);
         ksbp[1] = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)ksb >> 32));
-        asm volatile(
+        if constexpr (P16) {
+            asm volatile(
+#include "attn_q4fh_body.inc"
+                : "=" Q4FH_OT0(OT[0]), "=" Q4FH_OT1(OT[JB - 1]), "=" Q4FH_LRUN(LR), "+" Q4FH_PTR(ptr), "=" Q4FH_CNT(slow_cnt), "+" Q4FH_KS(ks_ring)
+                : Q4FH_QF(qf), Q4FH_VIN(vin), Q4FH_SIN(sin), Q4FH_QS(qs), Q4FH_KIN(kin), Q4FH_KSB(ksbp)
+                : Q4FH_CLOBBERS);
+        } else {
+            asm volatile(
 #include "attn_q4f_body.inc"
-            : "=" Q4F_OT0(OT[0]), "=" Q4F_OT1(OT[JB - 1]), "=" Q4F_LRUN(LR), "+" Q4F_PTR(ptr), "=" Q4F_CNT(slow_cnt), "+" Q4F_KS(ks_ring)
-            : Q4F_QF(qf), Q4F_VIN(vin), Q4F_SIN(sin), Q4F_QS(qs), Q4F_KIN(kin), Q4F_KSB(ksbp)
-            : Q4F_CLOBBERS);
+                : "=" Q4F_OT0(OT[0]), "=" Q4F_OT1(OT[JB - 1]), "=" Q4F_LRUN(LR), "+" Q4F_PTR(ptr), "=" Q4F_CNT(slow_cnt), "+" Q4F_KS(ks_ring)
+                : Q4F_QF(qf), Q4F_VIN(vin), Q4F_SIN(sin), Q4F_QS(qs), Q4F_KIN(kin), Q4F_KSB(ksbp)
+                : Q4F_CLOBBERS);
+        }
+    } else if constexpr (P16) {
+        asm volatile(
+#include "attn_q4h_body.inc"
+            : "=" Q4H_OT0(OT[0]), "=" Q4H_OT1(OT[JB - 1]), "=" Q4H_LRUN(LR), "+" Q4H_PTR(ptr), "=" Q4H_CNT(slow_cnt)
+            : Q4H_QF(qf), Q4H_VIN(vin), Q4H_SIN(sin)
+            : Q4H_CLOBBERS);
     } else if constexpr (JB == 2) {
         asm volatile(
 #include "attn_q4_body.inc"
@@ -256,14 +272,14 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
         }
     }
 }
-template <int JB, bool F8 = false>
+template <int JB, bool F8 = false, bool P16 = false>
 __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_k(const AttnArgs a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 slots][K tile | VT tile]
     int first, cnt;
     attn_xcd_range((int)gridDim.x, blockIdx.x & 7, first, cnt);
-    attn_qx_item<JB, F8>(a, nqb, first + (int)(blockIdx.x >> 3), smem);
+    attn_qx_item<JB, F8, P16>(a, nqb, first + (int)(blockIdx.x >> 3), smem);
 }
-template <int JB, bool F8 = false>
+template <int JB, bool F8 = false, bool P16 = false>
 __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const AttnArgs a, int nqb, int total, int* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_item;
@@ -285,7 +301,7 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
         const int wg = s_item;
         __syncthreads();
         if (wg < 0) break;
-        attn_qx_item<JB, F8>(a, nqb, wg, smem);
+        attn_qx_item<JB, F8, P16>(a, nqb, wg, smem);
     }
     if (threadIdx.x == 0) {
         __threadfence();
@@ -296,21 +312,21 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
     }
 }
 
-template <int JB, bool F8 = false>
+template <int JB, bool F8 = false, bool P16 = false>
 static int launch_attn_qx(const AttnArgs& a, bool persistent, hipStream_t st) {
     const int nqb = (a.Ntok + 255) / 256;  // 256 query rows per item in both forms
     const int total = nqb * a.B * a.H;
     const size_t lds = 65536;
     const dim3 blk(64 * (8 / JB));
     if (persistent && a.queue != nullptr && a.num_cus >= 8) {
-        const void* fn = (const void*)attn_qx_persist_k<JB, F8>;
+        const void* fn = (const void*)attn_qx_persist_k<JB, F8, P16>;
         S2V_TRY(ensure_lds_attr(fn, 65536));
         int* queue = a.queue;
         void* args[] = {(void*)&a, (void*)&nqb, (void*)&total, (void*)&queue};
         S2V_CHECK_HIP(hipLaunchKernel(fn, dim3((a.num_cus / 8) * 8), blk, args, lds, st));
         return 0;
     }
-    const void* fn = (const void*)attn_qx_k<JB, F8>;
+    const void* fn = (const void*)attn_qx_k<JB, F8, P16>;
     S2V_TRY(ensure_lds_attr(fn, 65536));
     void* args[] = {(void*)&a, (void*)&nqb};
     S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(total), blk, args, lds, st));
@@ -320,5 +336,9 @@ int launch_attn_q4(const AttnArgs& a, bool persistent, hipStream_t st) { return 
 int launch_attn_q8(const AttnArgs& a, bool persistent, hipStream_t st) { return launch_attn_qx<1>(a, persistent, st); }
 int launch_attn_q4f(const AttnArgs& a, bool persistent, hipStream_t st) {
     S2V_REQUIRE(a.q8 && a.k8 && a.q8s && a.k8s && a.vt, "attn_q4f: the MX images of q / k (launch_qk_quant_mx) and V^T are required");
-    return launch_attn_qx<2, true>(a, persistent, st);
+    return a.p16 ? launch_attn_qx<2, true, true>(a, persistent, st) : launch_attn_qx<2, true>(a, persistent, st);
+}
+int launch_attn_q4h(const AttnArgs& a, bool persistent, hipStream_t st) {
+    S2V_REQUIRE(a.p16 && a.vt, "attn_q4h: the fp16 V^T (launch_v_transpose(..., to_f16)) is required");
+    return launch_attn_qx<2, false, true>(a, persistent, st);
 }

@@ -367,8 +367,9 @@ __global__ __launch_bounds__(256) void qk_norm_rope_k(const QkNormRopeArgs a) {
 // V [B*Ntok, .] (cols 2D + h*64 + d) -> V^T [B][H][64][ntok_pad]; inside every aligned 16-token group the
 // tokens are stored in the order [0-3, 8-11, 4-7, 12-15] (bits 2 and 3 of the token index swapped) which is the
 // k-slot order the PV MFMA of attn_bf16_k consumes.  64 tokens x 64 dims per block through LDS.
+// to_f16: the values are written as fp16 (attn_q4h: P.V on the fp16 MFMA; a bf16 value converts exactly unless it is below 2^-14 in magnitude).
 __global__ __launch_bounds__(256) void v_transpose_k(const bf16_t* qkv, int ld_qkv, int B, int H, int Ntok, bf16_t* vt,
-                                                     int ntok_pad) {
+                                                     int ntok_pad, int to_f16) {
     __shared__ bf16_t tile[64][64 + 2];
     const int n0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
     const int D = H * 64;
@@ -390,7 +391,11 @@ __global__ __launch_bounds__(256) void v_transpose_k(const bf16_t* qkv, int ld_q
     for (int i = tid; i < 64 * 64; i += 256) {
         const int d = i >> 6, pos = i & 63;
         const int tok = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);  // token stored at this position
-        if (n0 + tok < Ntok) dst[(size_t)d * ntok_pad + n0 + pos] = tile[tok][d];
+        if (n0 + tok < Ntok) {
+            bf16_t v = tile[tok][d];
+            if (to_f16) v = __builtin_bit_cast(unsigned short, (_Float16)__uint_as_float((unsigned)v << 16));
+            dst[(size_t)d * ntok_pad + n0 + pos] = v;
+        }
         else if (n0 + pos < ntok_pad) dst[(size_t)d * ntok_pad + n0 + pos] = 0;
     }
 }
@@ -463,13 +468,13 @@ int launch_qk_norm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t st) {
     S2V_CHECK_HIP(hipGetLastError());
     if (a.vt != nullptr) {
         S2V_REQUIRE(dtype == S2V_BF16, "V^T is only produced on the bf16 path");
-        S2V_TRY(launch_v_transpose(a.qkv, a.ld_qkv, a.B, a.H, a.Ntok, a.vt, a.ntok_pad, st));
+        S2V_TRY(launch_v_transpose(a.qkv, a.ld_qkv, a.B, a.H, a.Ntok, a.vt, a.ntok_pad, st, a.vt_f16 != 0));
     }
     return 0;
 }
-int launch_v_transpose(const void* qkv, int ld_qkv, int B, int H, int Ntok, void* vt, int ntok_pad, hipStream_t st) {
+int launch_v_transpose(const void* qkv, int ld_qkv, int B, int H, int Ntok, void* vt, int ntok_pad, hipStream_t st, bool to_f16) {
     dim3 g2((Ntok + 63) / 64, H, B);
-    hipLaunchKernelGGL(v_transpose_k, g2, dim3(256), 0, st, (const bf16_t*)qkv, ld_qkv, B, H, Ntok, (bf16_t*)vt, ntok_pad);
+    hipLaunchKernelGGL(v_transpose_k, g2, dim3(256), 0, st, (const bf16_t*)qkv, ld_qkv, B, H, Ntok, (bf16_t*)vt, ntok_pad, to_f16 ? 1 : 0);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }

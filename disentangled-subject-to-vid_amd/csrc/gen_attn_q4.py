@@ -44,12 +44,35 @@ JB = 2  # set by main() per output
 #   straight into a ring of four VGPRs three tiles ahead (the end-of-iteration vmcnt(4) covers it as it covers the LDS-DMA pieces);
 #   Q block scales: v[QS + j], byte 0.
 F8 = False
+# P16 (set by main() for attn_q4h_body.inc / attn_q4fh_body.inc, JB = 2 only): P and V^T in fp16 instead of bf16 -- the kernel is bound by what ONE
+# wave can issue (tools/probes/gap_order.hip, tools/q4_ablate.sh: every instruction of the stream costs its issue slot), the packed fp16 forms issue
+# at the plain VALU rate (tools/probes/filler_price.hip; v_pk_add_f32 and every dot2 form block the matrix pipe), and with P as fp16 PAIRS the row
+# sums are v_pk_add_f16 on the registers the P.V MFMA reads: 15 packed adds + 4 flush instructions per row block and KV tile instead of 32 adds + 2.
+#   * ps[set][j][0] is a PACKED fp16 accumulator (two partial sums of 16 probabilities); seg 2 adds its halves to the fp32 running sum l;
+#   * fp16 ends at 65504, so the deferred maximum falls from 2^64 to 2^14 on a partial sum: a row keeps its adopted maximum until a later score
+#     exceeds it by ~14 in the exp2 domain (9.7 natural units) -- then the slow path re-adopts the true maximum (an overflowing exp2 becomes +inf
+#     in the conversion and trips the same check before P.V or l see the tile).  Below the adopted maximum fp16 reaches 2^-24 (subnormals): a key
+#     is dropped only below 2^-25 of the weight of the row's maximum key, the whole tail of N <= 2^17 such keys weighs < 2^-8 of that key alone;
+#   * P keeps 11 significant bits (bf16: 8), V^T is converted bf16 -> fp16 by the transpose pass (exact above 2^-14).
+P16 = False
 # Deferred maximum: a row keeps the maximum its first tile adopted until a partial row sum of a later tile exceeds 2^64, i.e. until some
 # p = exp2(s - m) does -- fp32 and bf16 share the exponent range, sums and P.V stay below 2^64 * N * |v| << 2^127, and every quantity is
 # scale-free, so nothing is lost by letting m lag (keys 2^126 below the adopted maximum flush to zero, as they would below any maximum).
 # Round 2 used 2^13: with a score spread of 4 / 8 / 12 (natural units) 0.9 / 6 / 11 % of the (wave, tile) pairs took the slow path and
 # a launch cost 3 / 15 / 27 % more (profiles/r03_attn_slow_path.txt); at 2^64 the scores must rise 44 above the first tile's maximum.
 THR_BITS = 0x5F800000
+
+
+def thr_a():   # phase A threshold: 2^64 as fp32, or (P16) 2^14 as fp16 -- a partial sum of 16 probabilities
+    return "0x7400" if P16 else f"0x{THR_BITS:08x}"
+
+
+def thr_b():   # phase B: -1, every check fires
+    return "0xbc00" if P16 else "0xbf800000"
+
+
+def cmp_thr(s_thr):   # vcc <- v[VS] beyond the threshold in SGPR s_thr (or NaN)
+    return f"v_cmp_ngt_f16 vcc, s{s_thr}, {vr(VS)}" if P16 else f"v_cmp_nge_f32 vcc, s{s_thr}, {vr(VS)}"
 ORDER = os.environ.get("Q4_ORDER", "")  # placement experiments
 READPOS = os.environ.get("Q4_READPOS", "first")  # fragment read first in its gap: -3 % against last (A/B, profiles/r03_attn_q4_placement.txt)
 READS = os.environ.get("Q4_READS", "")
@@ -68,10 +91,11 @@ S_KPTR, S_VPTR, S_T, S_END, S_KADV, S_VADV, S_NT, S_KSTR, S_NTOK, S_M0W, S_THR, 
 S_KSB, S_KSX, S_NTM1, S_KSA = 54, 56, 57, 58  # F8: IN K block-scale base (64-bit); scratch; nt - 1; address of the tile being loaded (64-bit)
 
 
-def layout(jb, f8=False):
-    global JB, ST, NEGM, PK, TMP, PS, VIN, LRUN, VS, OT, QF, KF, VF, NM, F8, KS, QS, KIN
+def layout(jb, f8=False, p16=False):
+    global JB, ST, NEGM, PK, TMP, PS, VIN, LRUN, VS, OT, QF, KF, VF, NM, F8, KS, QS, KIN, P16
     JB = jb
     F8 = f8
+    P16 = p16
     ST, NEGM, PK, TMP = 0, 64 * jb, 80 * jb, 96 * jb
     PS = TMP + 8
     VIN = PS + 4 * jb
@@ -140,7 +164,46 @@ def soft_stream(sb, kb, sset):
             return f"v_pk_add_f32 {acc}, {vr(tmp(g, 0), 2)}, 0"
         return f"v_pk_add_f32 {acc}, {acc}, {vr(tmp(g, 2 * h), 2)}"
 
+    def cvth(g, c):
+        e0 = (g & 3) * 4
+        dst = pk(g >> 2, kb * 2 + (e0 >> 3)) + ((e0 & 7) >> 1) + c
+        return f"v_cvt_pk_f16_f32 {vr(dst)}, {vr(tmp(g, 2 * c))}, {vr(tmp(g, 2 * c + 1))}"
+
+    def hadd(g, c):  # the packed pair just converted joins the row block's packed fp16 accumulator (None: first register of the tile, folded into the next add)
+        e0 = (g & 3) * 4
+        src = pk(g >> 2, kb * 2 + (e0 >> 3)) + ((e0 & 7) >> 1) + c
+        acc = vr(ps(sset, g >> 2, c))   # two packed accumulators per row block: a dependent v_pk_add_f16 four instructions behind, not two
+        if kb == 0 and (g & 3) == 0:
+            return f"v_mov_b32 {acc}, {vr(src)}"
+        return f"v_pk_add_f16 {acc}, {acc}, {vr(src)}"
+
     ng = 4 * JB
+    if P16:
+        # Four per gap, two exp2 + one cvt_pk_f16 + its packed add wherever possible (tools/probes/gap_order.hip: a gap of [e e c a] costs its
+        # issue slots, 4 exp2 in one gap cost 8 cycles more).  Segment 1 (kb = 1): [e e e e] [e e c h] x 14 [c h c h].  Segment 2 (kb = 0) converts
+        # into P registers that P.V MFMAs of the same segment still read -- pk[j][s] is read last by MFMA 4 s + 2 j + 1 -- so its conversions run
+        # TWO groups behind the exp2: [e e e e] [e e e e] [c h e e] x 12 [c h c h] x 2, which writes pk[j][s] from gap 4 s + 8 j + 2 on (asserted):
+        # at least one whole gap after the last reader, the distance the bf16 stream keeps.  The two-group TMP ring suffices: a gap converts
+        # tmp[g - 2][2 c, 2 c + 1] before its exp2 overwrite the same two registers.
+        if kb == 1:
+            ops = [exp(0, x) for x in range(4)]
+            for g in range(1, ng):
+                ops += [exp(g, 0), exp(g, 1), cvth(g - 1, 0), hadd(g - 1, 0), exp(g, 2), exp(g, 3), cvth(g - 1, 1), hadd(g - 1, 1)]
+            ops += [cvth(ng - 1, 0), hadd(ng - 1, 0), cvth(ng - 1, 1), hadd(ng - 1, 1)]
+            ops += [f"v_pk_add_f16 {vr(ps(sset, j, 0))}, {vr(ps(sset, j, 0))}, {vr(ps(sset, j, 1))}" for j in range(JB)]  # the tile's sums in ps[.][j][0]
+        else:
+            ops = [exp(0, x) for x in range(4)] + [exp(1, x) for x in range(4)]
+            for g in range(2, ng):
+                ops += [cvth(g - 2, 0), hadd(g - 2, 0), exp(g, 0), exp(g, 1), cvth(g - 2, 1), hadd(g - 2, 1), exp(g, 2), exp(g, 3)]
+            for g in (ng - 2, ng - 1):
+                ops += [cvth(g, 0), hadd(g, 0), cvth(g, 1), hadd(g, 1)]
+            for pos, o in enumerate(ops):
+                if o.startswith("v_cvt_pk_f16_f32"):
+                    r = int(o.split()[1].rstrip(",")[1:]) - PK
+                    jj, ss = r // 16, (r % 16) // 4
+                    assert pos // 4 >= 4 * ss + 2 * jj + 2, (o, pos)
+        assert len(ops) == 32 * JB + (JB if kb == 1 else 0)
+        return ops
     if SUM == "pk":
         ops = [exp(0, x) for x in range(4)]
         for g in range(1, ng):
@@ -212,11 +275,16 @@ def qk_mfma(buf, i):
 def pv_mfma(i):
     db, j, s = i & 1, (i >> 1) % JB, i // (2 * JB)
     d = ar(OT + 32 * j + 16 * db, 16)
-    return f"v_mfma_f32_32x32x16_bf16 {d}, {ar(VF + 4 * (s * 2 + db), 4)}, {vr(pk(j, s), 4)}, {d}"
+    return f"v_mfma_f32_32x32x16_{'f16' if P16 else 'bf16'} {d}, {ar(VF + 4 * (s * 2 + db), 4)}, {vr(pk(j, s), 4)}, {d}"
 
 
 def max_ps(emit, cur):
     """v[VS] = maximum of the partial row sums of tile set `cur`"""
+    if P16:  # two packed fp16 accumulators: v[VS] (low half) = the largest of the four partial sums (an overflow is +inf)
+        assert JB == 2
+        emit(f"v_pk_max_f16 {vr(VS)}, {vr(ps(cur, 0, 0))}, {vr(ps(cur, 1, 0))}")
+        emit(f"v_max_f16_sdwa {vr(VS)}, {vr(VS)}, {vr(VS)} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1")
+        return
     regs = [ps(cur, j, x) for j in range(JB) for x in range(2)]
     if len(regs) == 2:
         emit(f"v_max_f32 {vr(VS)}, {vr(regs[0])}, {vr(regs[1])}")
@@ -264,11 +332,25 @@ def slow_path(emit, cur, first):
             for k in range(4):
                 emit(f"v_exp_f32 {vr(T + k)}, {vr(s[x0 + k])}")
             emit("s_nop 0")
+            kb, e = x0 >> 4, x0 & 15
+            dst = pk(j, kb * 2 + (e >> 3)) + ((e & 7) >> 1)
+            if P16:  # against the true maximum every probability is <= 1: no overflow.  The tile's sums are rebuilt in ps[.][j][0]; after the
+                # first tile's adoption segment 1 continues into both accumulators, so the second one starts at zero
+                acc = vr(ps(cur, j, 0))
+                if first and x0 == 0:
+                    emit(f"v_mov_b32 {vr(ps(cur, j, 1))}, 0")
+                emit(f"v_cvt_pk_f16_f32 {vr(dst)}, {vr(T)}, {vr(T + 1)}")
+                emit(f"v_cvt_pk_f16_f32 {vr(dst + 1)}, {vr(T + 2)}, {vr(T + 3)}")
+                emit("s_nop 0")
+                if x0 == 0:
+                    emit(f"v_pk_add_f16 {acc}, {vr(dst)}, {vr(dst + 1)}")
+                else:
+                    emit(f"v_pk_add_f16 {acc}, {acc}, {vr(dst)}")
+                    emit(f"v_pk_add_f16 {acc}, {acc}, {vr(dst + 1)}")
+                continue
             for k in range(4):
                 acc = vr(ps(cur, j, k & 1))
                 emit(f"v_mov_b32 {acc}, {vr(T + k)}" if x0 == 0 and k < 2 else f"v_add_f32 {acc}, {acc}, {vr(T + k)}")
-            kb, e = x0 >> 4, x0 & 15
-            dst = pk(j, kb * 2 + (e >> 3)) + ((e & 7) >> 1)
             emit(f"v_cvt_pk_bf16_f32 {vr(dst)}, {vr(T)}, {vr(T + 1)}")
             emit(f"v_cvt_pk_bf16_f32 {vr(dst + 1)}, {vr(T + 2)}, {vr(T + 3)}")
         if not first:
@@ -308,7 +390,7 @@ def gen():
             return
         if "noread" in ABLATE and op == "ds_read_b128":
             return
-        if "nosoft" in ABLATE and op in ("v_exp_f32", "v_add_f32", "v_mov_b32", "v_cvt_pk_bf16_f32"):
+        if "nosoft" in ABLATE and op in ("v_exp_f32", "v_add_f32", "v_mov_b32", "v_cvt_pk_bf16_f32", "v_cvt_pk_f16_f32", "v_pk_add_f16"):
             return
         if "movexp" in ABLATE and op == "v_exp_f32":
             ln = ln.replace("v_exp_f32", "v_mov_b32")
@@ -323,7 +405,7 @@ def gen():
         L.append(ln)
 
     def soft_lo(i):  # first softmax op of gap i: five per gap (four with the dot2 row sums), or (SPLIT = "64") six in gaps without a fragment read and four in those with one
-        if SUM in ("dot", "pk"):
+        if SUM in ("dot", "pk") or P16:
             return 4 * i
         if SPLIT == "64" and JB == 2:
             return 5 * i + (i & 1)
@@ -344,7 +426,7 @@ def gen():
         emit(f"v_mov_b32 {vr(LRUN + j)}, 0")
     emit(f"s_mov_b32 s{S_T}, 0")
     emit(f"s_mov_b32 s{S_CNT}, 0")               # OUT: slow paths taken by this wave (diagnostics)
-    emit(f"s_mov_b32 s{S_THR}, 0x{THR_BITS:08x}")      # 2^64
+    emit(f"s_mov_b32 s{S_THR}, {thr_a()}")      # 2^64 (P16: 2^14 as fp16)
     emit(f"s_mov_b32 s{S_ONES}, 0x3f803f80")         # bf16 (1.0, 1.0)
     emit(f"s_mov_b32 s{S_KADV}, s{S_KSTR}")
     emit(f"s_mov_b32 s{S_VADV}, 128")
@@ -354,7 +436,7 @@ def gen():
     emit(f"s_cmp_gt_i32 s{S_END}, 0")
     emit("s_cbranch_scc1 L_q4_pa_%=")
     emit(f"s_mov_b32 s{S_END}, s{S_NT}")         # ... or there is none: phase B from the start
-    emit(f"s_mov_b32 s{S_THR}, 0xbf800000")
+    emit(f"s_mov_b32 s{S_THR}, {thr_b()}")
     emit(f"s_mov_b32 s{S_KADV}, 0")
     emit("L_q4_pa_%=:")
     # ---------------- prologue: K(0) fragments, S(0) -> st[0], K(1) fragments, tail mask, adoption of tile 0's maxima
@@ -413,11 +495,11 @@ def gen():
                 head = [qk_mfma_f8(nxt, i // 4, (U + 1) & 3)] if i % 4 == 0 else []
             else:
                 head = [qk_mfma(nxt, i)]
-            for ln in head + first + soft[soft_lo(i):soft_lo(i + 1)] + last:
+            for ln in head + first + soft[soft_lo(i):(soft_lo(i + 1) if i + 1 < NM else len(soft))] + last:
                 emit(ln)
         # check of tile t: the partial row sums against the threshold (any lane)
         max_ps(emit, cur)
-        emit(f"v_cmp_nge_f32 vcc, s{S_THR}, {vr(VS)}")  # row sum > threshold, or NaN
+        emit(cmp_thr(S_THR))  # row sum > threshold, or NaN
         emit(f"s_cbranch_vccnz L_q4_x{U}_%=")
         # segment 2: O += V^T(t).P(t); first half of P(t+1); K(t+2) fragments; V^T(t+2) pieces; l += row sums of t
         emit(f"L_q4_e{4 + U}_%=:")
@@ -432,7 +514,15 @@ def gen():
                     (first if READPOS == "first" else last).append(frag_read_k8(i >> 1, slot2))
             elif i in read_gaps:
                 (first if READPOS == "first" else last).append(frag_read(KF, list(read_gaps).index(i), slot2, False))
-            if i in ladd:
+            if P16:  # l += the two halves of the packed fp16 accumulator of tile t (complete since segment 1): one instruction per gap
+                jj, st4 = i >> 3, (i & 7) >> 1
+                if (i & 1) == 1:
+                    acc, t0 = vr(ps(cur, jj, 0)), vr(VS + 10 + (st4 & 1))
+                    last.append({0: f"v_cvt_f32_f16 {t0}, {acc}",
+                                 1: f"v_cvt_f32_f16_sdwa {t0}, {acc} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1",
+                                 2: f"v_add_f32 {vr(LRUN + jj)}, {vr(LRUN + jj)}, {vr(VS + 10)}",
+                                 3: f"v_add_f32 {vr(LRUN + jj)}, {vr(LRUN + jj)}, {vr(VS + 11)}"}[st4])
+            elif i in ladd:
                 jj, x = ladd[i]
                 last.append(f"v_add_f32 {vr(LRUN + jj)}, {vr(LRUN + jj)}, {vr(ps(cur, jj, x))}")
             for p in range(JB):
@@ -461,7 +551,7 @@ def gen():
     emit(f"s_cmp_ge_u32 s{S_T}, s{S_NT}")
     emit("s_cbranch_scc1 L_q4_done_%=")
     emit(f"s_mov_b32 s{S_END}, s{S_NT}")
-    emit(f"s_mov_b32 s{S_THR}, 0xbf800000")
+    emit(f"s_mov_b32 s{S_THR}, {thr_b()}")
     emit(f"s_mov_b32 s{S_KADV}, 0")
     emit(f"s_and_b32 s{S_X0}, s{S_T}, 3")
     for U in range(1, 4):
@@ -489,8 +579,8 @@ def gen():
         mask_tile(emit, nxt, S_X0)
         emit(f"L_q4_nomask{1 + cur}_%=:")
         max_ps(emit, cur)
-        emit(f"s_mov_b32 s{S_X0}, 0x{THR_BITS:08x}")
-        emit(f"v_cmp_nge_f32 vcc, s{S_X0}, {vr(VS)}")
+        emit(f"s_mov_b32 s{S_X0}, {thr_a()}")
+        emit(cmp_thr(S_X0))
         emit(f"s_cbranch_vccz L_q4_ret{cur}_%=")
         emit(f"s_add_u32 s{S_CNT}, s{S_CNT}, 1")
         slow_path(emit, cur, False)
@@ -511,8 +601,8 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "attn_q4_regs.h"), "w") as f:
         f.write("// generated by gen_attn_q4.py: the physical registers the bodies of attn_q4 (JB = 2) / attn_q8 (JB = 1) own\n#pragma once\n")
-        for jb, name, f8 in ((2, "Q4", False), (1, "Q8", False), (2, "Q4F", True)):
-            layout(jb, f8)
+        for jb, name, f8, p16 in ((2, "Q4", False, False), (1, "Q8", False, False), (2, "Q4F", True, False), (2, "Q4H", False, True), (2, "Q4FH", True, True)):
+            layout(jb, f8, p16)
             with open(os.path.join(here, f"attn_{name.lower()}_body.inc"), "w") as g:
                 for ln in gen():
                     g.write('"' + ln + '\\n\\t"\n')

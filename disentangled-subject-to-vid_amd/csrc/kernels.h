@@ -125,12 +125,23 @@ struct AttnArgs {
     //   k8 [B][H][ntok_pad][64] bytes (rows past Ntok zero), k8s [B][H][ntok_pad / 64][64] dwords: dword (hi * 32 + r) of a 64-key tile holds in
     //   byte kb the E8M0 scale of (key 32 kb + r, block hi) -- the scale VGPR of the QK^T MFMA, loaded as is
     const unsigned char* q8; const unsigned short* q8s; const unsigned char* k8; const unsigned* k8s;
+    // attn_p_format 1 (attn_q4h / attn_q4fh): `vt` holds fp16 (launch_v_transpose(..., to_f16 = true)), P is built as fp16 pairs and summed by
+    // packed fp16 adds, P.V runs on v_mfma_f32_32x32x16_f16; deferred maximum 2^14 instead of 2^64 (gen_attn_q4.py, P16).  attn_q4 forms only.
+    int p16;
 };
+// sequences up to this length run attn_pp (launch_attn_bf16), longer ones attn_q4 (profiles/r03_attn_short_sequences.txt: attn_pp 9 % ahead at
+// 4000 tokens, attn_q4 2 % ahead at 6000, 7 % at 8192); the fp8 engine's MX output is attn_q4's at any length
+#ifndef ATTN_PP_MAX_TOKENS
+#define ATTN_PP_MAX_TOKENS 4608
+#endif
+static inline bool attn_runs_q4(int Ntok, bool mx_out) { return mx_out || Ntok > ATTN_PP_MAX_TOKENS; }
 // q / k of the (normalised, rotated) QKV buffer -> the MX e4m3 images above (elementwise.hip)
 int launch_qk_quant_mx(const void* qkv, int ld_qkv, int B, int H, int Ntok, int ntok_pad, float q_prescale, unsigned char* q8, unsigned short* q8s,
                        unsigned char* k8, unsigned* k8s, hipStream_t st);
 // attn_q4 with QK^T on the scaled fp8 MFMA (attention_q4.hip); needs a.q8 / q8s / k8 / k8s and a.vt
 int launch_attn_q4f(const AttnArgs& a, bool persistent, hipStream_t st);
+// attn_q4 with P / V^T in fp16 (AttnArgs::p16 = 1)
+int launch_attn_q4h(const AttnArgs& a, bool persistent, hipStream_t st);
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st);
 int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st);
 // four-wave form of the bf16 kernel (attention_q4.hip); persistent needs a.queue / a.num_cus
@@ -161,10 +172,11 @@ struct QkNormRopeArgs {
     const void* nq_w; const void* nq_b; const void* nk_w; const void* nk_b; float eps;
     const float* cos; const float* sin;
     void* vt; int ntok_pad;   // null => skip
+    int vt_f16;               // V^T as fp16 (AttnArgs::p16)
 };
 int launch_qk_norm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t st);
 // bf16 V [B*Ntok, ld] (cols 2D + h*64 + d) -> V^T [B][H][64][ntok_pad] in the k-slot order attn_bf16 consumes
-int launch_v_transpose(const void* qkv, int ld_qkv, int B, int H, int Ntok, void* vt, int ntok_pad, hipStream_t st);
+int launch_v_transpose(const void* qkv, int ld_qkv, int B, int H, int Ntok, void* vt, int ntok_pad, hipStream_t st, bool to_f16 = false);
 
 // timestep sinusoid -> Linear -> SiLU -> Linear  (embeddings.py:27-78, 864-876)
 int launch_time_embed(const float* t_dev, int B, int D, const void* w1, const void* b1, const void* w2, const void* b2,

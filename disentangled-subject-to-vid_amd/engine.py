@@ -39,6 +39,9 @@ class S2VEngine:
         if cfg.lora_adaln_scope not in ("shipped", "intended"):
             raise _lib.S2VError(f"unknown lora_adaln_scope {cfg.lora_adaln_scope!r} ('shipped' or 'intended')")
         c.lora_adaln_scope = 1 if cfg.lora_adaln_scope == "intended" else 0
+        if cfg.attn_p_format not in ("bf16", "f16"):
+            raise _lib.S2VError(f"unknown attn_p_format {cfg.attn_p_format!r} ('bf16' or 'f16')")
+        c.attn_p_format = 1 if cfg.attn_p_format == "f16" else 0
         self._h = ctypes.c_void_p()
         _lib.check(_lib.lib().s2v_create(ctypes.byref(c), ctypes.byref(self._h)))
         self.geometry = None

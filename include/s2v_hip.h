@@ -63,7 +63,13 @@ typedef struct s2v_model_config {
                                *     LoRA only for the reference-image chunks (cond_shift, cond_scale, cond_gate): the context keeps
                                *     a second copy of rows [0, 3D) of each norm{1,2}.linear, s2v_merge_lora on those names merges
                                *     into that copy only, and the reference-image rows are modulated / gated with it */
-    int32_t reserved[3];
+    int32_t attn_p_format;    /* softmax probabilities P and V^T of the four-wave attention kernel (sequences > 4608 tokens, and the fp8 engines):
+                               * 0 = bf16 (P.V on v_mfma_f32_32x32x16_bf16, row sums in fp32, deferred maximum 2^64);
+                               * 1 = fp16 (P.V on v_mfma_f32_32x32x16_f16; P keeps 11 significant bits instead of 8; row sums by packed fp16
+                               *     adds on the P registers, flushed to fp32 per KV tile; the deferred maximum falls to 2^14, i.e. the slow
+                               *     path re-adopts the row maximum when a later score exceeds it by ~9.7 natural units -- faster on smooth
+                               *     score distributions, slower on spiky ones; tests/test_gpu_parity.py holds both against fp64 SDPA) */
+    int32_t reserved[2];
 } s2v_model_config;
 
 S2V_API const char* s2v_last_error(void);
@@ -319,7 +325,7 @@ S2V_API int s2v_op_ff_fp8(const void* x, const void* w1, const void* b1, const v
 S2V_API int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias, void* out, int32_t B, int32_t temb_dim,
                             int64_t rows, int32_t dtype, int32_t impl, s2v_stream stream);
 S2V_API int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype,
-                     int32_t impl, s2v_stream stream);
+                     int32_t impl, s2v_stream stream);   /* impl: 0 product dispatch (bf16), 1 generic, 3 = 0 with attn_p_format 1, 4 = attn_q4h (fp16 P) at any length */
 /* The same joint attention (F.scaled_dot_product_attention at attention_processor.py:2083-2087, head_dim 64, scale 1/8) as weight_format 2
  * runs it: q (times scale * log2 e) and k of the bf16 qkv rows [B*Ntok, 3*H*64] are quantised to MX e4m3 (32-element blocks along the
  * head dimension, E8M0 scales) into `scratch` and QK^T runs on v_mfma_scale_f32_32x32x64_f8f6f4; V^T (vt_scratch: B*H*64*rup(Ntok,64)

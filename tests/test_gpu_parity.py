@@ -78,7 +78,11 @@ def test_op_linear_generic(s2v, dt_name):
 
 
 @pytest.mark.parametrize("B,H,N,impl,dt_name", [(1, 2, 200, 0, "bf16"), (2, 3, 1250, 0, "bf16"), (1, 1, 64, 0, "bf16"),
-                                                (1, 2, 129, 1, "f32"), (1, 2, 129, 1, "bf16"), (2, 2, 300, 1, "f32")])
+                                                (1, 2, 129, 1, "f32"), (1, 2, 129, 1, "bf16"), (2, 2, 300, 1, "f32"),
+                                                # impl 4 = attn_q4h (attn_p_format 1: fp16 P / V^T, packed fp16 row sums, deferred maximum 2^14) at
+                                                # any length: one tile, every tile through the rare-path handler, ragged tails, phase A + B
+                                                (1, 1, 64, 4, "bf16"), (1, 2, 200, 4, "bf16"), (2, 3, 449, 4, "bf16"), (2, 3, 1250, 4, "bf16"),
+                                                (1, 2, 5000, 4, "bf16"), (1, 2, 5000, 3, "bf16"), (1, 2, 5000, 0, "bf16")])
 def test_op_attention(s2v, B, H, N, impl, dt_name):
     dt = torch.float32 if dt_name == "f32" else torch.bfloat16
     g = torch.Generator().manual_seed(N)
@@ -360,7 +364,8 @@ def test_cogvideox_2b_width_c1_geometry_vs_oracle(s2v, dt_name):
     assert_close(x, exp, dt_name, "2B latents after one step")
 
 
-def test_op_attention_strongly_negative_and_positive_scores(s2v):
+@pytest.mark.parametrize("impl", [0, 4])
+def test_op_attention_strongly_negative_and_positive_scores(s2v, impl):
     """scores far outside [-128, 128] in the exp2 domain: the first-tile maximum must be adopted without forming exp2(+-big)
     (0 * inf = NaN otherwise); softmax is shift invariant, so the result is the plain softmax-weighted mean of V."""
     L = s2v._lib
@@ -376,7 +381,7 @@ def test_op_attention_strongly_negative_and_positive_scores(s2v):
         qkv_d = torch.cat([qkv, pad]).to(DEV)
         out = torch.full((B * N, D), float("nan"), dtype=torch.bfloat16, device=DEV)
         vt = torch.zeros(B * H * 64 * 256, dtype=torch.bfloat16, device=DEV)
-        L.check(L.lib().s2v_op_attention(L.ptr(qkv_d), L.ptr(vt), L.ptr(out), B, H, N, 1, 0, L.stream_ptr()))
+        L.check(L.lib().s2v_op_attention(L.ptr(qkv_d), L.ptr(vt), L.ptr(out), B, H, N, 1, impl, L.stream_ptr()))
         torch.cuda.synchronize()
         assert torch.isfinite(out.float()).all()
         qf, kf, vf = (x.float().reshape(B, N, H, 64).transpose(1, 2) for x in (qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]))
@@ -386,7 +391,8 @@ def test_op_attention_strongly_negative_and_positive_scores(s2v):
         assert rel <= 3e-2, (sign, rel)
 
 
-def test_op_attention_late_score_jump_takes_the_slow_path(s2v):
+@pytest.mark.parametrize("impl", [0, 4])
+def test_op_attention_late_score_jump_takes_the_slow_path(s2v, impl):
     """deferred maximum (attention_q4.hip / gen_attn_q4.py): a row keeps the maximum of its first KV tile until a later tile's row sum
     exceeds 2^64.  Forty keys far into the sequence are set to 12 x (query row 17): against that row (and its like) their scores jump by
     60-110 natural units (90-160 in the exp2 domain: one head's first exp2 pass overflows to inf, the other's stays finite) after O and
@@ -404,7 +410,8 @@ def test_op_attention_late_score_jump_takes_the_slow_path(s2v):
     qd = torch.cat([qkv, torch.zeros(64, 3 * D, dtype=torch.bfloat16)]).to(DEV)
     out = torch.full((B * N, D), float("nan"), dtype=torch.bfloat16, device=DEV)
     vt = torch.zeros(B * H * 64 * ((N + 63) // 64 * 64), dtype=torch.bfloat16, device=DEV)
-    L.check(L.lib().s2v_op_attention(L.ptr(qd), L.ptr(vt), L.ptr(out), B, H, N, L.DTYPE_BF16, 0, L.stream_ptr()))
+    # impl 4: the same jump through attn_q4h, where the first exp2 pass overflows fp16 (2^92 -> +inf in the conversion) and the packed sums carry the inf
+    L.check(L.lib().s2v_op_attention(L.ptr(qd), L.ptr(vt), L.ptr(out), B, H, N, L.DTYPE_BF16, impl, L.stream_ptr()))
     torch.cuda.synchronize()
     got = out.float().cpu().double()
     assert torch.isfinite(got).all()
@@ -564,3 +571,36 @@ def test_pipeline_callback_overrides_are_honoured(s2v, mode):
     assert (lat - t(g["final_ddim"])).abs().max().item() > 1e-2, "the overrides must change the result"
     with pytest.raises(ValueError, match="callback_on_step_end_tensor_inputs"):
         pipe(output_type="latent", callback_on_step_end=on_step, callback_on_step_end_tensor_inputs=["noise_pred"], **_pipe_args(g))
+
+
+@pytest.mark.parametrize("spread", [1.0, 4.0, 8.0])
+def test_op_attention_fp16_p_moderate_jumps_and_tails_vs_fp64(s2v, spread):
+    """attn_q4h (attn_p_format 1) where its fp16 range is exercised without overflowing to inf: score spread 1 / 4 / 8 natural units (at 4 and 8
+    later tiles exceed the adopted maximum by more than 9.7 -- the 2^14 threshold -- so rows re-adopt their maximum repeatedly, and most keys sit
+    2^-14 .. 2^-24 below it, in fp16's subnormal range), 5000 keys.  Reference: fp64 softmax on the bf16-rounded q * scale * log2 e the kernels use."""
+    L = s2v._lib
+    B, H, N = 1, 2, 5000
+    D = H * 64
+    g = torch.Generator().manual_seed(int(spread * 10))
+    qkv = torch.randn(B * N, 3 * D, generator=g)
+    qkv[:, :D] *= spread
+    qkv = qkv.bfloat16()
+    qd = torch.cat([qkv, torch.zeros(64, 3 * D, dtype=torch.bfloat16)]).to(DEV)
+    vt = torch.zeros(B * H * 64 * ((N + 63) // 64 * 64), dtype=torch.bfloat16, device=DEV)
+    outs = {}
+    for impl in (0, 4):
+        out = torch.full((B * N, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        L.check(L.lib().s2v_op_attention(L.ptr(qd), L.ptr(vt), L.ptr(out), B, H, N, L.DTYPE_BF16, impl, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs[impl] = out.float().cpu().double()
+        assert torch.isfinite(outs[impl]).all()
+    c0 = 0.125 * 1.4426950408889634
+    q, k, v = (qkv.float()[:, i * D:(i + 1) * D].reshape(N, H, 64).transpose(0, 1) for i in range(3))
+    s_ = (q * c0).bfloat16().double() @ k.double().transpose(-1, -2)
+    p = torch.exp2(s_ - s_.max(dim=-1, keepdim=True).values)
+    ref = ((p @ v.double()) / p.sum(dim=-1, keepdim=True)).transpose(0, 1).reshape(N, D)
+    e0, e4 = (outs[0] - ref).abs().max().item(), (outs[4] - ref).abs().max().item()
+    tol = 2e-2 * max(1.0, ref.abs().max().item())
+    assert e0 <= tol and e4 <= tol, (e0, e4)
+    r0, r4 = ((outs[0] - ref).norm() / ref.norm()).item(), ((outs[4] - ref).norm() / ref.norm()).item()
+    assert r4 <= max(1.5 * r0, 5e-3), (r0, r4)   # fp16 P (11 significant bits) is not less accurate than bf16 P (8)

@@ -32,7 +32,12 @@ for N in [int(x) for x in sys.argv[1:]] or [19126, 50626]:
     def run8():
         L.check(L.lib().s2v_op_attention_fp8qk(L.ptr(qkv), L.ptr(vt), L.ptr(scratch), need, L.ptr(o8), B, H, N, st))
 
-    for name, fn in (("bf16  ", run16), ("fp8-qk", run8), ("bf16  ", run16), ("fp8-qk", run8)):
+    oh = torch.empty_like(o16)
+
+    def runh():   # attn_p_format 1: fp16 P / V^T, packed fp16 row sums (attn_q4h)
+        L.check(L.lib().s2v_op_attention(L.ptr(qkv), L.ptr(vt), L.ptr(oh), B, H, N, L.DTYPE_BF16, 3, st))
+
+    for name, fn in (("bf16  ", run16), ("f16-P ", runh), ("fp8-qk", run8)) * int(__import__("os").environ.get("ROUNDS", "2")):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -41,5 +46,7 @@ for N in [int(x) for x in sys.argv[1:]] or [19126, 50626]:
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 5 * 1e3
         print(f"N={N} {name}: {ms:8.3f} ms per op (V^T / quantisation passes included)  {4 * B * H * N * N * 64 / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    relh = ((oh.float() - o16.float()).norm() / o16.float().norm()).item()
+    print(f"N={N} rel-L2 f16-P vs bf16 output: {relh:.3e}  finite {bool(torch.isfinite(oh.float()).all())}", flush=True)
     rel = ((o8.float() - o16.float()).norm() / o16.float().norm()).item()
     print(f"N={N} rel-L2 fp8-qk vs bf16 output (unit-variance q, k): {rel:.3e}  finite {bool(torch.isfinite(o8.float()).all())}", flush=True)
