@@ -1269,7 +1269,10 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     // faster on eight waves -- same-box A/B of the C1 step, 11.50 -> 11.12 ms (tools/c1_attn_kernel_probe.py, S2V_G4_EPI_MASK); same epilogue
     // code, bit-identical results
     if (epi == EPI_BIAS_GELU && a.splitk <= 1 && a.K <= 2048 && out_tiles <= 2 * cus) g4_epi = false;
-    const bool big_tiles = a.tile == 0 || a.conv || epi == EPI_BIAS_QKNORM;  // GemmArgs::tile: the caller asks for smaller tiles
+    // a convolution whose 256 x 256 tiles would leave half the CUs idle (the VAE's latent-resolution layers: M = 10800, N = 512 -> 86 tiles of
+    // 216 K-tiles, 0.52 PF, profiles/r04_vae_conv_rates.txt) runs on 256 x 128 tiles instead
+    const bool conv_few = a.conv && out_tiles * 2 <= cus && epi != EPI_BIAS_QKNORM;
+    const bool big_tiles = (a.tile == 0 && !conv_few) || (a.conv && !conv_few) || epi == EPI_BIAS_QKNORM;  // GemmArgs::tile: the caller asks for smaller tiles
     if (g_gemm_impl == 9 && g_gemm_g4t && big_tiles && w_tile_ok(a) && gemm_g4_ok(a, epi) && gemm_g4t_ok(a, epi, (int)cus)) return launch_gemm_g4t(a, epi, st);
     if (g_gemm_impl == 9 && big_tiles && g4_epi && w_tile_ok(a) && gemm_g4_ok(a, epi)) return launch_gemm_g4(a, epi, st);  // four-wave generated-asm K loop
     if ((g_gemm_impl == 7 || g_gemm_impl == 8 || g_gemm_impl == 9) && big_tiles && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
