@@ -6,6 +6,7 @@
 #define S2V_HOST
 #include "common.h"
 #include "kernels.h"
+#include <cstdlib>
 
 // ---------------------------------------------------------------------------------------------------
 // Row LayerNorm helpers: one wave per row, row cached in registers (D <= 4096, D % (16/sizeof(T)) == 0)
@@ -252,11 +253,74 @@ __global__ __launch_bounds__(256) void ln_modulate_k(const LnModArgs a) {
         row_modulate_store_p<T, NR>(v, a.D, lane, prm, (T*)a.y + (size_t)row * a.ldy);
     }
 }
+// The same rows with the four parameter vectors (LayerNorm weight / bias, modulation scale / shift) staged ONCE per workgroup in LDS: ln_modulate_k
+// keeps them in registers per row (96 of its 179 VGPRs at D = 3072: two waves per SIMD, 24 KiB of L1 / L2 reads per 6-KiB row); here a workgroup of
+// four waves handles 4 x RPW consecutive rows, reads the parameters from LDS where they are used and keeps ~100 registers.  The rows of a workgroup
+// share their parameter set unless a text / reference / video or sample boundary falls inside it: those workgroups read the parameters from global
+// memory per row, as before.  Arithmetic is row_layernorm / row_modulate_store's, i.e. ln_modulate_k's.
+template <typename T, int NR, int RPW>
+__global__ __launch_bounds__(256) void ln_modulate_lds_k(const LnModArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char ln_smem[];
+    constexpr int VN = Vec16<T>::N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rows = a.B * a.Ntok, r0 = blockIdx.x * (4 * RPW), rl = min(r0 + 4 * RPW, rows) - 1;
+    auto params_of = [&](int row, const T*& shift, const T*& scale) {
+        const int b = row / a.Ntok, r = row - b * a.Ntok;
+        const bool txt = r < a.text_len;
+        const bool ref = a.shift_ref != nullptr && !txt && r < a.text_len + a.ref_len;
+        shift = (const T*)(txt ? a.shift_txt : ref ? a.shift_ref : a.shift_vid) + (size_t)b * a.mod_stride;
+        scale = (const T*)(txt ? a.scale_txt : ref ? a.scale_ref : a.scale_vid) + (size_t)b * a.mod_stride;
+    };
+    const T *sh0, *sc0, *sh1, *sc1;
+    params_of(r0, sh0, sc0);
+    params_of(rl, sh1, sc1);
+    const bool uniform = sh0 == sh1 && sc0 == sc1;   // parameter sets are contiguous row ranges: equal ends = one set
+    T* lw = (T*)ln_smem;
+    T *lb = lw + a.D, *lsc = lb + a.D, *lsh = lsc + a.D;
+    if (uniform) {
+        const int chunks = a.D / VN;
+        for (int c = threadIdx.x; c < chunks; c += 256) {
+            *(typename Vec16<T>::raw_t*)(lw + c * VN) = Vec16<T>::ldraw((const T*)a.w + c * VN);
+            *(typename Vec16<T>::raw_t*)(lb + c * VN) = Vec16<T>::ldraw((const T*)a.b + c * VN);
+            *(typename Vec16<T>::raw_t*)(lsc + c * VN) = Vec16<T>::ldraw(sc0 + c * VN);
+            *(typename Vec16<T>::raw_t*)(lsh + c * VN) = Vec16<T>::ldraw(sh0 + c * VN);
+        }
+        __syncthreads();
+    }
+#pragma unroll 1
+    for (int k = 0; k < RPW; ++k) {
+        const int row = r0 + k * 4 + wave;
+        if (row >= rows) break;
+        const T *pw = lw, *pb = lb, *psc = lsc, *psh = lsh;
+        if (!uniform) { pw = (const T*)a.w; pb = (const T*)a.b; params_of(row, psh, psc); }
+        float v[NR * VN];
+        row_load<T, NR>((const T*)a.x + (size_t)row * a.ldx, a.D, lane, v);
+        row_layernorm<T, NR>(v, a.D, lane, pw, pb, a.eps);
+        if constexpr (sizeof(T) == 2) {
+            if (a.q8 != nullptr) {
+                row_modulate_quant_store<NR>(v, a.D, lane, psh, psc, (unsigned char*)a.q8 + (size_t)row * a.D, a.q8_scale + row);
+                continue;
+            }
+        }
+        row_modulate_store<T, NR>(v, a.D, lane, psh, psc, (T*)a.y + (size_t)row * a.ldy);
+    }
+}
 int launch_ln_modulate(const LnModArgs& a, int dtype, hipStream_t st) {
     S2V_REQUIRE(a.D <= 4096 && a.D % 8 == 0, "ln_modulate: D must be <= 4096 and a multiple of 8");
     S2V_REQUIRE(a.q8 == nullptr || (dtype == S2V_BF16 && a.q8_scale != nullptr), "ln_modulate: the fp8 output needs bf16 rows and a scale vector");
     const int rows = a.B * a.Ntok;
     dim3 grid((rows + 3) / 4);
+    // many rows (at least four workgroups of sixteen rows per CU): parameters staged in LDS per workgroup
+    static int lds_rows = -1;
+    if (lds_rows < 0) { const char* e = getenv("S2V_LN_LDS_ROWS"); lds_rows = e ? atoi(e) : 16384; }  // A/B knob of tools/; 0 = never
+    if (dtype == S2V_BF16 && lds_rows > 0 && rows >= lds_rows) {
+        constexpr int RPW = 4;
+        dim3 g16((rows + 4 * RPW - 1) / (4 * RPW));
+        const size_t lds = (size_t)4 * a.D * 2;
+        S2V_LN_DISPATCH(bf16_t, a.D, hipLaunchKernelGGL((ln_modulate_lds_k<bf16_t, NR, RPW>), g16, dim3(256), lds, st, a))
+        S2V_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (dtype == S2V_BF16) {
         S2V_LN_DISPATCH(bf16_t, a.D, hipLaunchKernelGGL((ln_modulate_k<bf16_t, NR>), grid, dim3(256), 0, st, a))
     } else {
