@@ -13,10 +13,13 @@ cp gpurun_out/prof_r04fp8/summary/* $E/; rm -rf gpurun_out/prof_r04fp8
 python bench.py --workload cogvideox-2b-9x256x256 --steps 50 --warmup 10 2> $E/bench_c1.err | tail -1 > $E/r04_bench_2b_9x256x256.json
 bash tools/profile.sh r04_c1 --workload cogvideox-2b-9x256x256 > $E/profile_c1.log 2>&1
 cp gpurun_out/prof_r04_c1/summary/* $E/; rm -rf gpurun_out/prof_r04_c1
-for w in cogvideox-5b-fp8-49x720x1280 cogvideox-5b-49x720x1280 cogvideox-5b-fp8-49x480x720 cogvideox-2b-49x480x720; do
+for w in cogvideox-5b-fp8-49x720x1280 cogvideox-5b-fp8qk-49x720x1280 cogvideox-5b-49x720x1280 cogvideox-5b-fp8-49x480x720 cogvideox-5b-fp8qk-49x480x720 cogvideox-2b-49x480x720; do
   python bench.py --steps 3 --warmup 1 --workload $w --no-cpu-baseline 2>/dev/null | tail -1 > $E/r04_bench_$w.json
 done
 S2V_IMPLS=9,7 S2V_NO_G4T=1 bash tools/pmc_gemm.sh gemm > $E/r04_pmc_sq_gemm_raw.txt 2>&1; rm -rf gpurun_out/pmc_gemm
+S2V_IMPLS=9 bash tools/pmc_gemm.sh gemm > $E/r04_pmc_sq_gemm_g4t_raw.txt 2>&1; rm -rf gpurun_out/pmc_gemm
+S2V_ATTN_P=f16 python bench.py --steps 3 --warmup 1 --workload cogvideox-5b-fp8qk-49x720x1280 --no-cpu-baseline 2>/dev/null | tail -1 > $E/r04_bench_cogvideox-5b-fp8qk-f16p-49x720x1280.json
+S2V_ATTN_P=f16 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-vae 2>/dev/null | tail -1 > $E/r04_bench_n1_f16p.json
 python tools/g4t_probe.py > $E/r04_gemm_g4t.txt 2>&1
 python tools/stall_g4.py > $E/r04_stall_g4.txt 2>&1
 python tools/probe_blaslt.py > $E/r04_probe_blaslt.txt 2>&1
