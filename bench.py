@@ -407,6 +407,12 @@ def main(argv=None):
             total = int(ts.item())
         return el, total
 
+    # attn_p_format "auto" (the default): the engine runs its first denoise step eagerly, reads the attention kernel's slow-path census and settles
+    # on fp16 or bf16 P for good (engine.py).  That step is taken here, before anything is timed, on a copy of the latents.
+    if getattr(eng, "_attn_auto_pending", False):
+        keep = latents.clone()
+        step(0, False)
+        latents.copy_(keep)
     # ---- the timed region of the contract: no event recording, no profiling inside it
     elapsed, total_steps = timed(bool(args.graph), args.steps, args.warmup)
     finite = bool(torch.isfinite(latents.float()).all().item())
@@ -550,7 +556,8 @@ def main(argv=None):
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("fp8 (e4m3 W8A8 block linears, MX e4m3 QK^T) + bf16" if cfg.weight_format == "fp8-qk" else "fp8 (e4m3 W8A8 block linears) + bf16") if fp8 else "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
             "config": {"workload": args.workload, "latent_frames": F, "latent_hw": [H, W], "tokens": T + (F + 1) * (H // 2) * (W // 2),
-                       "cfg_pair": 2, "scheduler": "ddim-trailing-50", "attn_p_format": cfg.attn_p_format, "parallelism": f"replicas x{world}",
+                       "cfg_pair": 2, "scheduler": "ddim-trailing-50", "attn_p_format": cfg.attn_p_format if cfg.attn_p_format != "auto" else f"auto -> {eng.attn_p_format}",
+                       "attn_slow_path_fraction": eng.attn_slow_fraction, "parallelism": f"replicas x{world}",
                        "rccl_ranks": world, "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "launcher": "self-spawned" if os.environ.get("S2V_BENCH_SPAWNED") == "1" else ("torchrun env" if env_world is not None else "single process"),
                        "ranks": ranks_info,

@@ -60,6 +60,8 @@ _SIGS = {
     "s2v_op_ff_fp8": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "s2v_op_mod_gemv": [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _P],
     "s2v_op_attention": [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _P],
+    "s2v_attn_slow_stats": [_P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), _I32],
+    "s2v_set_attn_p_format": [_P, _I32],
     "s2v_op_attention_fp8qk": [_P, _P, _P, _I64, _P, _I32, _I32, _I32, _P],
     "s2v_op_linear_fp8": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _P, _I64, _P],
 }

@@ -28,9 +28,11 @@ class TransformerConfig:
     # computes) or "intended" (base weights for video / text modulation, LoRA only for the reference-image chunks,
     # normalization.py:468-478)
     lora_adaln_scope: str = "shipped"
-    # softmax probabilities / V^T of the four-wave attention kernel: "bf16", or "f16" (packed fp16 row sums, P.V on the fp16 MFMA, deferred
-    # maximum 2^14 instead of 2^64: include/s2v_hip.h, attn_p_format)
-    attn_p_format: str = "bf16"
+    # softmax probabilities / V^T of the four-wave attention kernel: "bf16"; "f16" (packed fp16 row sums, P.V on the fp16 MFMA, deferred
+    # maximum 2^14 instead of 2^64: include/s2v_hip.h, attn_p_format; ~4 % faster on smooth score distributions, slower on spiky ones); or
+    # "auto": fp16, checked against the kernel's slow-path census after the first denoise step and switched to bf16 for good when more than
+    # 0.5 % of the (wave, KV tile) pairs took the slow path (S2VEngine.denoise_step)
+    attn_p_format: str = "auto"
 
     @property
     def inner_dim(self):

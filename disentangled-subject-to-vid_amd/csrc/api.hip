@@ -62,6 +62,7 @@ struct s2v_ctx {
     int num_cus = 256;
     int sk_tiles = 0; float* sk_ws = nullptr; unsigned* sk_cnt = nullptr;  // split-K workspace of the geometry (0: none)
     int* attn_queue = nullptr;               // nine counters of the persistent attention launch (zero between launches)
+    unsigned long long* attn_stats = nullptr;  // AttnArgs::stats: 256 x [slow paths, (wave, KV tile) pairs] of the attn_q4 launches (s2v_attn_slow_stats)
     hipStream_t side = nullptr;              // fork/join stream for the row-tail launches of split GEMMs
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     char* arena = nullptr;
@@ -158,6 +159,10 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
         return s2v_fail(__FILE__, __LINE__, "s2v_create: stream / event creation failed", -2);
     }
     c->mfma = (cfg->dtype == S2V_DTYPE_BF16) && !cfg->force_simple;
+    if (hipMalloc((void**)&c->attn_stats, 4096) != hipSuccess || hipMemset(c->attn_stats, 0, 4096) != hipSuccess) {
+        s2v_destroy(c);
+        return s2v_fail(__FILE__, __LINE__, "s2v_create: attention census allocation failed", -2);
+    }
     if (hipMalloc((void**)&c->attn_queue, 64) != hipSuccess || hipMemset(c->attn_queue, 0, 64) != hipSuccess) {
         s2v_destroy(c);
         return s2v_fail(__FILE__, __LINE__, "s2v_create: attention queue allocation failed", -2);
@@ -298,6 +303,7 @@ extern "C" void s2v_destroy(s2v_ctx* c) {
     if (c->t_dev) hipFree(c->t_dev);
     if (c->ws) hipFree(c->ws);
     if (c->attn_queue) hipFree(c->attn_queue);
+    if (c->attn_stats) hipFree(c->attn_stats);
     if (c->arena) hipFree(c->arena);
     if (c->lora_tmp) hipFree(c->lora_tmp);
     delete c;
@@ -676,6 +682,7 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     a.B = c->B; a.H = c->cfg.num_heads; a.Ntok = c->Ntok; a.scale = 0.125f;
     a.queue = c->attn_queue; a.num_cus = c->num_cus;  // launches of one context are ordered on its stream: one queue suffices
     a.p16 = p16 ? 1 : 0;
+    a.stats = c->attn_stats;
     if (attn_mx_out(c)) { a.mx_q = (unsigned char*)c->aq; a.mx_s = c->hs; a.mx_rows = (int)c->Mpad; }
     if (c->fp8_qk) {  // weight_format 2: q (times scale * log2 e) and k as MX e4m3, QK^T on the scaled fp8 MFMA (the pass is timed with the V^T pass)
         {
@@ -1048,6 +1055,32 @@ extern "C" int s2v_op_ff_fp8(const void* x, const void* w1, const void* b1, cons
     hipStreamSynchronize(st);
     hipFree(p);
     return rc;
+}
+
+// Census of the attention kernel's deferred-maximum slow path since the last reset: slow = slow paths taken, total = (wave, KV tile) pairs run by
+// the four-wave kernels (0 / 0 when only attn_pp ran).  Synchronises the device.  With attn_p_format 1 the threshold is 2^14 instead of 2^64: a
+// caller that sees more than a fraction of a percent of slow paths on its data switches back with s2v_set_attn_p_format.
+extern "C" int s2v_attn_slow_stats(s2v_ctx* c, uint64_t* slow, uint64_t* total, int32_t reset) {
+    S2V_REQUIRE(c && slow && total, "s2v_attn_slow_stats: null argument");
+    unsigned long long h[512];
+    S2V_CHECK_HIP(hipDeviceSynchronize());
+    S2V_CHECK_HIP(hipMemcpy(h, c->attn_stats, 4096, hipMemcpyDeviceToHost));
+    uint64_t s = 0, t = 0;
+    for (int i = 0; i < 256; ++i) { s += h[2 * i]; t += h[2 * i + 1]; }
+    *slow = s; *total = t;
+    if (reset) S2V_CHECK_HIP(hipMemset(c->attn_stats, 0, 4096));
+    return 0;
+}
+// Change attn_p_format (include/s2v_hip.h, s2v_model_config) of a live context; a captured step is dropped and re-captured at its next use.
+extern "C" int s2v_set_attn_p_format(s2v_ctx* c, int32_t fmt) {
+    S2V_REQUIRE(c, "s2v_set_attn_p_format: null context");
+    S2V_REQUIRE(fmt == 0 || fmt == 1, "s2v_set_attn_p_format: 0 (bf16) or 1 (fp16)");
+    if (c->attn_p16 != (fmt == 1)) {
+        S2V_CHECK_HIP(hipDeviceSynchronize());
+        c->attn_p16 = fmt == 1;
+        if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+    }
+    return 0;
 }
 
 extern "C" int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias, void* out, int32_t B, int32_t temb_dim,

@@ -71,7 +71,7 @@ extern "C" __attribute__((visibility("default"))) int s2v_attn_slow_read(unsigne
 // P16 (JB = 2 only, attn_q4h / attn_q4fh): P and V^T in fp16, row sums by packed fp16 adds, deferred maximum 2^14 (gen_attn_q4.py, P16); the
 // code around the body is the same -- the format lives in the V^T buffer (AttnArgs::p16) and in the generated instructions.
 template <int JB, bool F8 = false, bool P16 = false>
-__device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg, char* smem) {
+__device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg, char* smem, unsigned& slow_acc, unsigned& tile_acc) {
     static_assert((!F8 && !P16) || JB == 2, "the fp8 QK^T and fp16 P bodies exist for the four-wave form only");
     constexpr int NW = 8 / JB;  // waves per work item
     const int tid = threadIdx.x, lane = tid & 63;
@@ -207,6 +207,8 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
             : Q8_CLOBBERS);
     }
 
+    slow_acc += slow_cnt;   // census of this wave over its items (AttnArgs::stats), reported once per kernel
+    tile_acc += (unsigned)nt;
 #ifdef S2V_DIAG
     if (lane == 0) {  // slow-path census of tools/attn_harness: (wave, tile) pairs that took the slow path / that ran
         atomicAdd(&g_qx_slow[0], (unsigned long long)slow_cnt);
@@ -272,18 +274,29 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
         }
     }
 }
+// one pair of atomics per wave and KERNEL (the persistent launch: 1024 per launch, on 256 distinct slots)
+__device__ __forceinline__ void attn_report(const AttnArgs& a, unsigned slow, unsigned tiles) {
+    if (a.stats != nullptr && (threadIdx.x & 63) == 0) {
+        unsigned long long* s = a.stats + 2 * (blockIdx.x & 255);
+        atomicAdd(s, (unsigned long long)slow);
+        atomicAdd(s + 1, (unsigned long long)tiles);
+    }
+}
 template <int JB, bool F8 = false, bool P16 = false>
 __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_k(const AttnArgs a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 slots][K tile | VT tile]
     int first, cnt;
     attn_xcd_range((int)gridDim.x, blockIdx.x & 7, first, cnt);
-    attn_qx_item<JB, F8, P16>(a, nqb, first + (int)(blockIdx.x >> 3), smem);
+    unsigned slow = 0, tiles = 0;
+    attn_qx_item<JB, F8, P16>(a, nqb, first + (int)(blockIdx.x >> 3), smem, slow, tiles);
+    attn_report(a, slow, tiles);
 }
 template <int JB, bool F8 = false, bool P16 = false>
 __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const AttnArgs a, int nqb, int total, int* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_item;
     const int xcd = blockIdx.x & 7;
+    unsigned slow = 0, tiles = 0;
     for (;;) {
         if (threadIdx.x == 0) {
             int wg = -1;
@@ -301,8 +314,9 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
         const int wg = s_item;
         __syncthreads();
         if (wg < 0) break;
-        attn_qx_item<JB, F8, P16>(a, nqb, wg, smem);
+        attn_qx_item<JB, F8, P16>(a, nqb, wg, smem, slow, tiles);
     }
+    attn_report(a, slow, tiles);
     if (threadIdx.x == 0) {
         __threadfence();
         if (atomicAdd(&queue[8], 1) == (int)gridDim.x - 1) {

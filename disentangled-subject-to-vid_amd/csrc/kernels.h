@@ -128,6 +128,9 @@ struct AttnArgs {
     // attn_p_format 1 (attn_q4h / attn_q4fh): `vt` holds fp16 (launch_v_transpose(..., to_f16 = true)), P is built as fp16 pairs and summed by
     // packed fp16 adds, P.V runs on v_mfma_f32_32x32x16_f16; deferred maximum 2^14 instead of 2^64 (gen_attn_q4.py, P16).  attn_q4 forms only.
     int p16;
+    // optional census of the deferred-maximum slow path (attn_q4 forms): 256 slots of two counters, slot = workgroup & 255:
+    // [2 s] += slow paths taken, [2 s + 1] += (wave, KV tile) pairs run.  The engine reads it to decide whether fp16 P pays on the data at hand.
+    unsigned long long* stats;
 };
 // sequences up to this length run attn_pp (launch_attn_bf16), longer ones attn_q4 (profiles/r03_attn_short_sequences.txt: attn_pp 9 % ahead at
 // 4000 tokens, attn_q4 2 % ahead at 6000, 7 % at 8192); the fp8 engine's MX output is attn_q4's at any length

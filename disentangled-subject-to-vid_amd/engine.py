@@ -39,9 +39,14 @@ class S2VEngine:
         if cfg.lora_adaln_scope not in ("shipped", "intended"):
             raise _lib.S2VError(f"unknown lora_adaln_scope {cfg.lora_adaln_scope!r} ('shipped' or 'intended')")
         c.lora_adaln_scope = 1 if cfg.lora_adaln_scope == "intended" else 0
-        if cfg.attn_p_format not in ("bf16", "f16"):
-            raise _lib.S2VError(f"unknown attn_p_format {cfg.attn_p_format!r} ('bf16' or 'f16')")
-        c.attn_p_format = 1 if cfg.attn_p_format == "f16" else 0
+        if cfg.attn_p_format not in ("bf16", "f16", "auto"):
+            raise _lib.S2VError(f"unknown attn_p_format {cfg.attn_p_format!r} ('bf16', 'f16' or 'auto')")
+        c.attn_p_format = 0 if cfg.attn_p_format == "bf16" else 1
+        # "auto": start with fp16 P (faster on smooth score distributions) and look at the slow-path census after the first denoise step of a
+        # geometry; more than AUTO_SLOW_FRACTION of the (wave, KV tile) pairs on the slow path -> back to bf16 P (threshold 2^64) for good
+        self.attn_p_format = "f16" if c.attn_p_format else "bf16"
+        self._attn_auto_pending = cfg.attn_p_format == "auto"
+        self.attn_slow_fraction = None
         self._h = ctypes.c_void_p()
         _lib.check(_lib.lib().s2v_create(ctypes.byref(c), ctypes.byref(self._h)))
         self.geometry = None
@@ -229,12 +234,35 @@ class S2VEngine:
                                                _lib.ptr(oe), _lib.stream_ptr()))
         return oh, oe
 
+    AUTO_SLOW_FRACTION = 5e-3   # a slow path costs ~2.5 KV tiles of time, fp16 P saves ~4 %: break-even near 1.7 % of the pairs
+
+    def attn_slow_stats(self, reset=False):
+        """(slow paths taken, (wave, KV tile) pairs run) by the four-wave attention kernels since the last reset; synchronises the device"""
+        slow, total = ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(_lib.lib().s2v_attn_slow_stats(self._h, ctypes.byref(slow), ctypes.byref(total), int(reset)))
+        return slow.value, total.value
+
+    def set_attn_p_format(self, fmt):
+        if fmt not in ("bf16", "f16"):
+            raise _lib.S2VError(f"unknown attn_p_format {fmt!r} ('bf16' or 'f16')")
+        _lib.check(_lib.lib().s2v_set_attn_p_format(self._h, 1 if fmt == "f16" else 0))
+        self.attn_p_format = fmt
+
     def denoise_step(self, latents, timestep, coef, x0_hist=None, noise=None, use_graph=False):
         """one iteration of the denoise loop, latents [1,F,C,H,W] (model dtype) updated in place"""
         if latents.dtype != self.dtype or not latents.is_contiguous():
             raise _lib.S2VError("latents must be a contiguous model-dtype tensor (it is updated in place)")
+        auto = self._attn_auto_pending
+        if auto:
+            self.attn_slow_stats(reset=True)
         _lib.check(_lib.lib().s2v_denoise_step(self._h, _lib.ptr(latents), float(timestep), ctypes.byref(coef),
-                                               _lib.ptr(x0_hist), _lib.ptr(noise), int(use_graph), _lib.stream_ptr()))
+                                               _lib.ptr(x0_hist), _lib.ptr(noise), int(use_graph and not auto), _lib.stream_ptr()))
+        if auto:  # the first step of an "auto" engine runs eagerly; its census decides the format of every later step
+            slow, total = self.attn_slow_stats()
+            self.attn_slow_fraction = slow / total if total else 0.0
+            if self.attn_slow_fraction > self.AUTO_SLOW_FRACTION:
+                self.set_attn_p_format("bf16")
+            self._attn_auto_pending = False
 
     def last_noise_pred(self):
         B, T, F, H, W = self.geometry

@@ -324,6 +324,12 @@ S2V_API int s2v_op_ff_fp8(const void* x, const void* w1, const void* b1, const v
  * emb [B, temb_dim], W [rows, temb_dim], out [B, rows], B <= 4; impl 0 = the product dispatch, 1 = one wave per row */
 S2V_API int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias, void* out, int32_t B, int32_t temb_dim,
                             int64_t rows, int32_t dtype, int32_t impl, s2v_stream stream);
+/* Census of the deferred-maximum slow path of the four-wave attention kernels since the last reset (device counters; the call synchronises):
+ * slow = slow paths taken, total = (wave, KV tile) pairs run.  attn_p_format 1 lowers the threshold from 2^64 to 2^14; a caller whose data
+ * take the slow path in more than a fraction of a percent of the pairs switches back with s2v_set_attn_p_format (the engine's "auto"
+ * policy, engine.py, does that after the first step).  s2v_set_attn_p_format drops a captured step; it is re-captured at its next use. */
+S2V_API int s2v_attn_slow_stats(s2v_ctx* ctx, uint64_t* slow, uint64_t* total, int32_t reset);
+S2V_API int s2v_set_attn_p_format(s2v_ctx* ctx, int32_t attn_p_format);
 S2V_API int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype,
                      int32_t impl, s2v_stream stream);   /* impl: 0 product dispatch (bf16), 1 generic, 3 = 0 with attn_p_format 1, 4 = attn_q4h (fp16 P) at any length */
 /* The same joint attention (F.scaled_dot_product_attention at attention_processor.py:2083-2087, head_dim 64, scale 1/8) as weight_format 2

@@ -604,3 +604,57 @@ def test_op_attention_fp16_p_moderate_jumps_and_tails_vs_fp64(s2v, spread):
     assert e0 <= tol and e4 <= tol, (e0, e4)
     r0, r4 = ((outs[0] - ref).norm() / ref.norm()).item(), ((outs[4] - ref).norm() / ref.norm()).item()
     assert r4 <= max(1.5 * r0, 5e-3), (r0, r4)   # fp16 P (11 significant bits) is not less accurate than bf16 P (8)
+
+
+def test_attn_p_format_auto_settles_on_the_census_of_the_first_step(s2v):
+    """attn_p_format = "auto" (the default): an engine starts with fp16 P where the four-wave attention kernel runs (> 4608 tokens), its first
+    denoise step runs eagerly and reads the kernel's slow-path census (s2v_attn_slow_stats); smooth scores keep fp16, spiky ones (q / k LayerNorm
+    weights x 12: score jumps far beyond the 2^14 threshold in most tiles) switch the engine to bf16 P for good.  Either way graph replay == eager
+    afterwards, and the result stays within the bf16 tolerance of a bf16-P engine on the same weights."""
+    import copy
+
+    cfg = s2v.tiny(use_rope=True, heads=4, layers=1, text_dim=128, temb=64)
+    cfg.max_text_seq_length = 7
+    g = torch.Generator().manual_seed(31)
+    F, H, W = 4, 64, 64                                  # 7 + 5 * 1024 = 5127 tokens: attn_q4 / attn_q4h
+    lat0 = torch.randn(1, F, 16, H, W, generator=g).bfloat16().to(DEV)
+    text = torch.randn(2, 7, 128, generator=g).bfloat16()
+    ref = (torch.randn(1, 1, 16, H, W, generator=g) * 0.7).bfloat16()
+    sch = s2v.CogVideoXDDIMScheduler(snr_shift_scale=1.0)
+    sch.set_timesteps(50)
+    for spiky in (False, True):
+        sd = s2v.weights.synthetic_state_dict(cfg, seed=5, parity=True)
+        if spiky:
+            for k in list(sd):
+                if k.endswith("norm_q.weight") or k.endswith("norm_k.weight"):
+                    sd[k] = sd[k] * 12.0
+        outs = {}
+        for fmt in ("auto", "bf16"):
+            c = copy.copy(cfg)
+            c.attn_p_format = fmt
+            m = s2v.HipCogVideoXTransformer3DModel(c, torch.bfloat16, DEV)
+            m.load_state_dict(sd)
+            eng = m.engine
+            eng.set_geometry(2, 7, F, H, W)
+            eng.prepare_tables(H * 8, W * 8)
+            eng.set_conditioning(text, ref)
+            a, b = lat0.clone(), lat0.clone()
+            for x, graph in ((a, True), (b, False)):   # `a` settles the format in its first step; `b` repeats the three steps eagerly
+                for i in range(3):
+                    t = sch.timesteps[i]
+                    eng.denoise_step(x, float(t), sch.coef(t, torch.bfloat16, 6.0), use_graph=graph)
+            torch.cuda.synchronize()
+            assert torch.isfinite(a.float()).all()
+            if fmt == "auto":
+                assert eng.attn_slow_fraction is not None
+                assert eng.attn_p_format == ("bf16" if spiky else "f16"), (spiky, eng.attn_slow_fraction)
+                assert (eng.attn_slow_fraction > eng.AUTO_SLOW_FRACTION) == spiky, eng.attn_slow_fraction
+                if not spiky:
+                    assert torch.equal(a, b)   # fp16 throughout: graph replay == eager
+            else:
+                assert eng.attn_p_format == "bf16" and torch.equal(a, b)
+            outs[fmt] = a.float().cpu()
+            slow, total = eng.attn_slow_stats()
+            assert total > 0
+        rel = ((outs["auto"] - outs["bf16"]).norm() / outs["bf16"].norm()).item()
+        assert rel <= 2e-2, (spiky, rel)
