@@ -217,7 +217,9 @@ def pmc_traffic_bytes(kernel_class, workload):
         tot = cnt = 0.0
         for row in csv.reader(open(path)):
             got = row[0].replace("void ", "").replace(", 0, false>", ">").replace(", 0>", ">").replace(" ", "") if row else ""
-            if got == name.replace(" ", ""):  # default template arguments and the return type are printed too
+            # default template arguments and the return type are printed too; the attention kernel's name carries its format flags
+            # (<2, false, false> bf16 P, <2, false, true> fp16 P, <2, true, ...> fp8 QK^T): any four-wave form of the pass counts
+            if got == name.replace(" ", "") or (name.startswith("attn_qx_persist_k<2") and got.startswith("attn_qx_persist_k<2")):
                 tot += float(row[2]) * float(row[1])
                 cnt += float(row[1])
         return tot / cnt if cnt else None
