@@ -47,12 +47,6 @@ __device__ __forceinline__ int64_t a_k_off(const GemmArgs& a, int k) {
     return (((int64_t)dt * a.Hp + dy) * a.Wp + dx) * a.cin + ci;
 }
 
-// conv_tpf: frame-fastest walk of the row tiles (kernels.h)
-__device__ __forceinline__ int conv_row_tile(const GemmArgs& a, int mt, int tiles_m) {
-    if (a.conv_tpf <= 0) return mt;
-    const int F = tiles_m / a.conv_tpf;   // whole frames by construction (the launcher checks)
-    return (mt % F) * a.conv_tpf + mt / F;
-}
 // A operand: per-thread row bases (fixed for the whole K loop) + a per-k-step displacement
 __device__ __forceinline__ void stage_tile_a(const bf16_t* __restrict__ g, const int64_t rb[4], int64_t koff, char* lds,
                                              int tid) {
@@ -211,7 +205,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_stag(const GemmArgs a, int t
     const int first_m = group * GM;
     const int gsz = min(tiles_m - first_m, GM);
     const int in_g = wg - group * per_group;
-    const int m0 = conv_row_tile(a, first_m + in_g % gsz, tiles_m) * RBM, n0 = (in_g / gsz) * RBN;
+    const int m0 = (first_m + in_g % gsz) * RBM, n0 = (in_g / gsz) * RBN;
 
     // saddr-form LDS-DMA (see glds16_saddr): wave-uniform tile base + loop-invariant 32-bit lane offsets
     const int64_t rbase0 = a_row_base(a, m0);
@@ -364,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_w8(const GemmArgs a, int til
     const int first_m = group * GM;
     const int gsz = min(tiles_m - first_m, GM);
     const int in_g = wg - group * per_group;
-    const int m0 = conv_row_tile(a, first_m + in_g % gsz, tiles_m) * WBM, n0 = (in_g / gsz) * WBN;
+    const int m0 = (first_m + in_g % gsz) * WBM, n0 = (in_g / gsz) * WBN;
 
     // staging: 1024 chunks per operand per half-step, 2 per thread: gi = i*512 + tid -> row = i*128 + (tid>>2)
     const int srow = tid >> 2;
@@ -534,7 +528,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
     const int first_m = group * GM;
     const int gsz = min(tiles_m - first_m, GM);
     const int in_g = wg - group * per_group;
-    const int m0 = conv_row_tile(a, first_m + in_g % gsz, tiles_m) * WBM, n0 = (in_g / gsz) * WBN;
+    const int m0 = (first_m + in_g % gsz) * WBM, n0 = (in_g / gsz) * WBN;
 
     // staging: piece i (0..3) of this wave covers rows g*128 + i*32 + w4*8 + (lane>>3), 8 chunks of 16 B each
     const int srow = g * 128 + w4 * 8 + (lane >> 3);

@@ -32,10 +32,6 @@ struct GemmArgs {
     // dt in [0,kt), dy,dx in [0,3): A[m][k] = in[f + dt][y + dy][x + dx][ci].  kt = 3: causal conv (frames 0,1 of the
     // buffer hold the conv cache); kt = 1: per-frame 3x3 conv.  (CogVideoXCausalConv3d, autoencoder_kl_cogvideox.py:120-137)
     int conv, cin, Hp, Wp, oH, oW, kt;
-    int conv_tpf;       // conv mode, kt = 3: 256-row tiles per output frame when a frame is a whole number of them (0: off).  The row tiles are then
-                        // walked frame-FASTEST (tile i -> frame i % F, block i / F): the three temporal taps of a pixel block are read by tiles that run
-                        // together, instead of a whole frame of tiles apart (at 480 x 720 x 128 channels a frame of operand + output + residual is
-                        // 264 MB: past the 256-MB MALL, profiles/r04_vae_conv_rates.txt)
     int cstride;        // conv mode: spatial stride of the output grid (0 or 1 = dense; 2 = CogVideoXDownsample3D, downsampling.py:322-353)
     int gm;             // 256-row kernel: row tiles per group of the tile order (0: chosen by the launcher)
     int tile;           // plain bf16 GEMMs: 0 = the launcher's choice (256 x 256 tiles where the shape fits them); 1 = 256 x 128 tiles, 2 = 128 x 128

@@ -477,8 +477,6 @@ static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int e
     g.R = resid; g.ldr = c.cout;
     g.conv = 1; g.cin = c.cin; g.Hp = H + 2; g.Wp = W + 2; g.oH = H; g.oW = W; g.kt = c.kt;
     g.w_rows_padded = (int)rup64(c.cout, 256);
-    static const int tpf_on = [] { const char* e = getenv("S2V_VAE_CONV_TPF"); return e ? atoi(e) : 1; }();  // A/B knob of tools/
-    if (c.kt == 3 && F > 1 && (H * W) % 256 == 0 && tpf_on) g.conv_tpf = H * W / 256;
 #ifdef S2V_DIAG
     if (const char* lg = getenv("S2V_VAE_CONV_LOG")) {  // tools/vae_conv_rates.py: the convolutions in launch order, to be zipped with a kernel trace
         if (FILE* f = fopen(lg, "a")) { fprintf(f, "%d %d %d %d %d\n", g.M, g.N, g.K, epi, (int)(v->mfma && c.cin % 64 == 0)); fclose(f); }
