@@ -478,6 +478,10 @@ static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int e
     g.conv = 1; g.cin = c.cin; g.Hp = H + 2; g.Wp = W + 2; g.oH = H; g.oW = W; g.kt = c.kt;
     g.w_rows_padded = (int)rup64(c.cout, 256);
 #ifdef S2V_DIAG
+    if (const char* e = getenv("S2V_VAE_ADD_EXPERIMENT")) {  // timing experiments on the residual-add epilogue (results are wrong): 1 = no add, 2 = residual from another buffer
+        if (epi == EPI_BIAS_ADD && atoi(e) == 1) { epi = EPI_BIAS; g.R = nullptr; }
+        if (epi == EPI_BIAS_ADD && atoi(e) == 2) g.R = (const char*)c.pad;  // some other resident buffer of at least M x cout elements
+    }
     if (const char* lg = getenv("S2V_VAE_CONV_LOG")) {  // tools/vae_conv_rates.py: the convolutions in launch order, to be zipped with a kernel trace
         if (FILE* f = fopen(lg, "a")) { fprintf(f, "%d %d %d %d %d\n", g.M, g.N, g.K, epi, (int)(v->mfma && c.cin % 64 == 0)); fclose(f); }
     }
