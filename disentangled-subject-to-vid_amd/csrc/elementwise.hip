@@ -311,8 +311,10 @@ int launch_ln_modulate(const LnModArgs& a, int dtype, hipStream_t st) {
     const int rows = a.B * a.Ntok;
     dim3 grid((rows + 3) / 4);
     // many rows (at least four workgroups of sixteen rows per CU): parameters staged in LDS per workgroup
-    static int lds_rows = -1;
-    if (lds_rows < 0) { const char* e = getenv("S2V_LN_LDS_ROWS"); lds_rows = e ? atoi(e) : 16384; }  // A/B knob of tools/; 0 = never
+    int lds_rows = 16384;
+#ifdef S2V_DIAG
+    if (const char* e = getenv("S2V_LN_LDS_ROWS")) lds_rows = atoi(e);  // tools/ln_lds_probe.py (diagnostics library): 0 = never
+#endif
     if (dtype == S2V_BF16 && lds_rows > 0 && rows >= lds_rows) {
         constexpr int RPW = 4;
         dim3 g16((rows + 4 * RPW - 1) / (4 * RPW));

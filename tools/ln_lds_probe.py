@@ -1,6 +1,7 @@
 """A/B of the LayerNorm + modulate pass: parameters in registers per row (ln_modulate_k, S2V_LN_LDS_ROWS=0) against parameters staged in LDS per
 workgroup of sixteen rows (ln_modulate_lds_k, the default from 16384 rows): sha256 of one forward's output (5B width, 2 layers, 19126 tokens; bf16 and
 fp8 engines) -- the two must agree bit for bit -- and the pass's time from the engine's per-kernel profile.  Run once per setting:
+    export S2V_LIB=$PWD/disentangled-subject-to-vid_amd/libs2v_hip_diag.so   (the knob exists in the diagnostics library only)
     S2V_LN_LDS_ROWS=0 python tools/ln_lds_probe.py; python tools/ln_lds_probe.py"""
 import copy, hashlib, importlib, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
