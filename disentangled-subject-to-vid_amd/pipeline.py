@@ -148,6 +148,15 @@ class S2VPipeline:
                     if fused:
                         eng.set_conditioning(text, ref)  # the hoisted text projection follows the new embeddings
                 negative_prompt_embeds = outs.get("negative_prompt_embeds", negative_prompt_embeds)
+        # attn_p_format "auto" settled on the census of the FIRST step; the whole run's census is kept for the caller and, should later (less
+        # noisy, sharper) steps have taken the fp16 kernel's slow path too often, the next video of this engine runs on bf16 probabilities
+        self.attn_slow_fraction = None
+        eng_ = getattr(tr, "engine", None)
+        if fused and eng_ is not None and eng_.cfg.attn_p_format == "auto" and eng_.attn_p_format == "f16":
+            slow, total = eng_.attn_slow_stats(reset=True)
+            self.attn_slow_fraction = slow / total if total else 0.0
+            if self.attn_slow_fraction > eng_.AUTO_SLOW_FRACTION:
+                eng_.set_attn_p_format("bf16")
         if output_type == "latent":
             video = latents
         else:
