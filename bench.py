@@ -192,7 +192,8 @@ KERNEL_OF_CLASS = {"attention": "attn_qx_persist_k<2>", "gemm_qkv": "gemm_g4<4>"
 
 # which committed rocprofv3 PMC passes belong to which workload (profiles/README.md): rNN_ = the default workload,
 # rNNfp8_ = the fp8 engine at the same geometry, rNN_c1_ = the C1 geometry; the other workloads have no PMC pass
-PMC_PREFIX = {"cogvideox-5b-49x480x720": r"r\d+_pmc", "cogvideox-5b-fp8-49x480x720": r"r\d+fp8_pmc", "cogvideox-2b-9x256x256": r"r\d+_c1_pmc"}
+PMC_PREFIX = {"cogvideox-5b-49x480x720": r"r\d+_pmc", "cogvideox-5b-fp8-49x480x720": r"r\d+fp8_pmc", "cogvideox-2b-9x256x256": r"r\d+_c1_pmc",
+              "cogvideox-5b-fp8-49x720x1280": r"r\d+_c5fp8_pmc"}  # rNN_c5fp8_ = BASELINE configs[4]
 
 
 def pmc_traffic_bytes(kernel_class, workload):
