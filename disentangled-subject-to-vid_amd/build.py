@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libs2v_hip.so")
-SOURCES = ["api.hip", "gemm.hip", "gemm_g4.hip", "gemm_g4t.hip", "gemm_g4f.hip", "attention.hip", "attention_q4.hip", "elementwise.hip", "vae.hip", "vae_api.hip", "t5.hip", "rccl.hip"]
+SOURCES = ["api.hip", "gemm.hip", "gemm_g4.hip", "gemm_g4t.hip", "gemm_g4f.hip", "gemm_f32m.hip", "attention.hip", "attention_f32m.hip", "attention_q4.hip", "elementwise.hip", "vae.hip", "vae_api.hip", "t5.hip", "rccl.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wno-unused-result", "-Wno-unused-value", "-Wno-inline-asm"]
 # the HBM-bound kernels mirror the reference's separately-rounded elementwise ops: no fma contraction there
 # (hipcc defaults to -ffp-contract=fast); the scheduler step is bit-exact against the CPU reference because of it

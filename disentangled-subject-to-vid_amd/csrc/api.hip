@@ -572,6 +572,7 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
         }
         return launch_gemm_bf16(g, epi, st);
     }
+    g.valu_only = c->cfg.force_simple;  // fp32: the matrix-pipe kernel (gemm_f32m, same bits) unless the cross-check path is asked for
     return launch_gemm_simple(g, epi, c->dtype, st);
 }
 
@@ -683,6 +684,7 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     a.queue = c->attn_queue; a.num_cus = c->num_cus;  // launches of one context are ordered on its stream: one queue suffices
     a.p16 = p16 ? 1 : 0;
     a.stats = c->attn_stats;
+    a.valu_only = c->cfg.force_simple;
     if (attn_mx_out(c)) { a.mx_q = (unsigned char*)c->aq; a.mx_s = c->hs; a.mx_rows = (int)c->Mpad; }
     if (c->fp8_qk) {  // weight_format 2: q (times scale * log2 e) and k as MX e4m3, QK^T on the scaled fp8 MFMA (the pass is timed with the V^T pass)
         {
@@ -989,6 +991,11 @@ extern "C" int s2v_op_linear(const void* A, const void* W, const void* bias, voi
         hipFree(ws);
         return rc;
     }
+    if (impl == 3) {  // fp32 operands on the fp32 matrix pipe (what the fp32 engine runs; bit-identical to impl 1)
+        S2V_REQUIRE(dtype == S2V_DTYPE_F32, "s2v_op_linear: impl 3 is fp32 only");
+        return launch_gemm_f32m(g, epilogue, (hipStream_t)stream);
+    }
+    g.valu_only = 1;
     return launch_gemm_simple(g, epilogue, dtype, (hipStream_t)stream);
 }
 
@@ -1127,5 +1134,10 @@ extern "C" int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, in
         if (impl == 4) return launch_attn_q4h(a, false, st);
         return launch_attn_bf16(a, st);
     }
+    if (impl == 5) {  // fp32 on the fp32 matrix pipe (what the fp32 engine runs)
+        S2V_REQUIRE(dtype == S2V_DTYPE_F32, "s2v_op_attention: impl 5 is fp32 only");
+        return launch_attn_f32m(a, st);
+    }
+    a.valu_only = 1;
     return launch_attn_simple(a, dtype, st);
 }

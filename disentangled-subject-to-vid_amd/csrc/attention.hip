@@ -637,6 +637,7 @@ __global__ __launch_bounds__(256) void attn_simple_k(const AttnArgs a) {
 }
 
 int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st) {
+    if (dtype == S2V_F32 && !a.valu_only) return launch_attn_f32m(a, st);
     dim3 grid((a.Ntok + 3) / 4, a.H, a.B);
     if (dtype == S2V_BF16)
         hipLaunchKernelGGL(attn_simple_k<bf16_t>, grid, dim3(256), 0, st, a);

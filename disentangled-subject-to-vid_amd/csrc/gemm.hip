@@ -1399,6 +1399,7 @@ static int launch_simple_t(const GemmArgs& a, int epi, hipStream_t st) {
 }
 
 int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st) {
+    if (dtype == S2V_F32 && gemm_f32m_ok(a)) return launch_gemm_f32m(a, epi, st);
     S2V_REQUIRE((a.M + 63) / 64 <= 65535, "gemm_simple: M too large for the generic kernel");
     return dtype == S2V_BF16 ? launch_simple_t<bf16_t>(a, epi, st) : launch_simple_t<float>(a, epi, st);
 }

@@ -37,6 +37,7 @@ struct GemmArgs {
     int tile;           // plain bf16 GEMMs: 0 = the launcher's choice (256 x 256 tiles where the shape fits them); 1 = 256 x 128 tiles, 2 = 128 x 128
                         // (few-tile GEMMs: more, smaller workgroups fill the CUs that a single partial round of 256 x 256 tiles leaves idle)
     int ablate;         // diagnostics only
+    int valu_only;      // fp32 only: stay on the VALU kernel gemm_simple_k (cfg.force_simple; the A/B reference of gemm_f32m, which returns the same bits)
     int a_rows_padded;  // plain mode: rows physically present behind A (>= M); the 256-row kernel needs ceil256(M)
     int m_begin;        // first output row of this launch (row-tail launches of a split GEMM; 128-row kernel only)
     int w_rows_padded;  // rows physically present behind W (>= N, zero or don't-care beyond N); 0 = exactly N
@@ -84,7 +85,11 @@ enum { EPI_BIAS_QKNORM = 4 };
 
 __host__ __device__ __forceinline__ int64_t mx_perm_row(int64_t m) { return (m & ~(int64_t)127) | ((m & 31) << 2) | ((m >> 5) & 3); }
 int launch_gemm_bf16(const GemmArgs& a, int epi, hipStream_t st);              // MFMA path, bf16 only
-int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st);  // any dtype, any shape
+// any dtype, any shape.  fp32 calls that qualify (gemm_f32m_ok) run on the fp32 matrix pipe (gemm_f32m.hip) unless a.valu_only -- same bits
+int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st);
+// gemm_f32m.hip: fp32 operands on v_mfma_f32_32x32x2_f32, bit-identical to gemm_simple_k<float>
+bool gemm_f32m_ok(const GemmArgs& a);
+int launch_gemm_f32m(const GemmArgs& a, int epi, hipStream_t st);
 // gemm_g4.hip: 256 x 256 tiles, four waves, generated-asm K loop (plain bf16 operands; gemm_g4_ok says whether a call qualifies)
 bool gemm_g4_ok(const GemmArgs& a, int epi);
 int launch_gemm_g4(const GemmArgs& a, int epi, hipStream_t st);
@@ -131,6 +136,7 @@ struct AttnArgs {
     // optional census of the deferred-maximum slow path (attn_q4 forms): 256 slots of two counters, slot = workgroup & 255:
     // [2 s] += slow paths taken, [2 s + 1] += (wave, KV tile) pairs run.  The engine reads it to decide whether fp16 P pays on the data at hand.
     unsigned long long* stats;
+    int valu_only;             // fp32 only: stay on attn_simple_k (cfg.force_simple) instead of the fp32-MFMA kernel attn_f32m_k
 };
 // sequences up to this length run attn_pp (launch_attn_bf16), longer ones attn_q4 (profiles/r03_attn_short_sequences.txt: attn_pp 9 % ahead at
 // 4000 tokens, attn_q4 2 % ahead at 6000, 7 % at 8192); the fp8 engine's MX output is attn_q4's at any length
@@ -146,7 +152,9 @@ int launch_attn_q4f(const AttnArgs& a, bool persistent, hipStream_t st);
 // attn_q4 with P / V^T in fp16 (AttnArgs::p16 = 1)
 int launch_attn_q4h(const AttnArgs& a, bool persistent, hipStream_t st);
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st);
+// generic kernel, any dtype; fp32 calls run attn_f32m (attention_f32m.hip: QK^T and P.V on v_mfma_f32_32x32x2_f32) unless a.valu_only
 int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st);
+int launch_attn_f32m(const AttnArgs& a, hipStream_t st);
 // four-wave form of the bf16 kernel (attention_q4.hip); persistent needs a.queue / a.num_cus
 int launch_attn_q4(const AttnArgs& a, bool persistent, hipStream_t st);
 // eight waves x 32 rows running the same fine-grained stream, two waves per SIMD

@@ -484,6 +484,7 @@ static int t5_linear(s2v_t5* t, const void* A, int lda, const void* W, void* C, 
         }
         return launch_gemm_bf16(g, epi, st);
     }
+    g.valu_only = t->cfg.force_simple;
     return launch_gemm_simple(g, epi, t->dtype, st);
 }
 

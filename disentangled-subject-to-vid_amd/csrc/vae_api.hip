@@ -487,7 +487,7 @@ static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int e
     }
 #endif
     if (v->mfma && c.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, epi, st));  // cout = 3 (conv_out) runs one padded 128-column tile
-    else S2V_TRY(launch_gemm_simple(g, epi, v->dtype, st));
+    else { g.valu_only = v->cfg.force_simple; S2V_TRY(launch_gemm_simple(g, epi, v->dtype, st)); }
     if (c.kt == 3) {  // conv cache: the last two frames of the operand become frames 0, 1 of the next batch (adjacent on both sides: one copy unless they overlap)
         if (F >= 2) S2V_CHECK_HIP(hipMemcpyAsync(c.pad, c.pad + (int64_t)F * fb, 2 * fb, hipMemcpyDeviceToDevice, st));
         else {
@@ -526,7 +526,7 @@ static int decode_batch(s2v_vae* v, int Fz, int h, int w, bool first, char* dst,
                 g.C = v->dense[t2]; g.ldc = r.cout; g.M = F * H * W; g.N = r.cout; g.K = r.cin;
                 g.a_rows_padded = (int)rup64(g.M, 256);  // dense buffers carry a 256-row slack
                 if (v->mfma && r.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, EPI_BIAS, st));
-                else S2V_TRY(launch_gemm_simple(g, EPI_BIAS, v->dtype, st));
+                else { g.valu_only = v->cfg.force_simple; S2V_TRY(launch_gemm_simple(g, EPI_BIAS, v->dtype, st)); }
                 S2V_TRY(run_conv(v, r.c2, F, H, W, first, EPI_BIAS_ADD, v->dense[t2], v->dense[t2], st));
                 std::swap(cur, t2);
             } else {
@@ -851,6 +851,7 @@ static int run_conv_down(s2v_vae* v, ConvL& c, int H, int W, void* out, hipStrea
     g.conv = 1; g.cin = c.cin; g.Hp = H + 2; g.Wp = W + 2; g.oH = H / 2; g.oW = W / 2; g.kt = 1; g.cstride = 2;
     g.w_rows_padded = (int)rup64(c.cout, 256);
     if (v->mfma && c.cin % 64 == 0) return launch_gemm_bf16(g, EPI_BIAS, st);
+    g.valu_only = v->cfg.force_simple;
     return launch_gemm_simple(g, EPI_BIAS, v->dtype, st);
 }
 
@@ -873,7 +874,7 @@ static int encode_window(s2v_vae* v, const void* image, int Himg, int Wimg, int 
                 g.C = v->dense[t2]; g.ldc = r.cout; g.M = H * W; g.N = r.cout; g.K = r.cin;
                 g.a_rows_padded = (int)rup64(g.M, 256);
                 if (v->mfma && r.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, EPI_BIAS, st));
-                else S2V_TRY(launch_gemm_simple(g, EPI_BIAS, v->dtype, st));
+                else { g.valu_only = v->cfg.force_simple; S2V_TRY(launch_gemm_simple(g, EPI_BIAS, v->dtype, st)); }
                 S2V_TRY(run_conv(v, r.c2, 1, H, W, true, EPI_BIAS_ADD, v->dense[t2], v->dense[t2], st));
                 std::swap(cur, t2);
             } else {

@@ -47,7 +47,7 @@ typedef struct s2v_model_config {
     int32_t use_rope;         /* use_rotary_positional_embeddings: 0 (2B) / 1 (5B) */
     int32_t dtype;            /* S2V_DTYPE_* : storage + rounding points of the model */
     float norm_eps;           /* 1e-5 */
-    int32_t force_simple;     /* 1 = run the bf16 model on the generic (non-MFMA) kernels; cross-check only */
+    int32_t force_simple;     /* 1 = run the model on the generic VALU kernels (bf16: instead of the bf16 MFMA path; fp32: instead of the fp32-MFMA kernels, which return the same GEMM bits); cross-check only */
     int32_t weight_format;    /* 0 = the model dtype; 1 = W8A8 fp8 (BASELINE configs[4]): the four big linears of every block
                                * (fused QKV, attention out, FF1, FF2) keep OCP e4m3 weights with per-output-channel scales
                                * (quantised by s2v_finalize_weights after any LoRA merge) and take per-token e4m3 activations,
@@ -297,7 +297,8 @@ S2V_API int s2v_t5_set_position_bias(s2v_t5* t5, const void* bias_dev, int32_t B
 S2V_API int s2v_t5_encode(s2v_t5* t5, const int64_t* input_ids_dev, int32_t B, int32_t T, void* out, s2v_stream stream);
 
 /* ---- operator-level entry points (used by the parity tests and micro-benchmarks) ------------------------- */
-/* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic,
+/* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic (VALU),
+ * 3 = fp32 operands on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; what the fp32 engine runs, bit-identical to impl 1),
  * 2 = MFMA bf16 with K split over several workgroups per output tile, as the engine runs GEMMs with few tiles and a long
  * reduction (M, N multiples of 256; fails if the shape does not qualify; allocates its workspace, synchronous) */
 S2V_API int s2v_op_linear(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
@@ -331,7 +332,7 @@ S2V_API int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias, vo
 S2V_API int s2v_attn_slow_stats(s2v_ctx* ctx, uint64_t* slow, uint64_t* total, int32_t reset);
 S2V_API int s2v_set_attn_p_format(s2v_ctx* ctx, int32_t attn_p_format);
 S2V_API int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype,
-                     int32_t impl, s2v_stream stream);   /* impl: 0 product dispatch (bf16), 1 generic, 3 = 0 with attn_p_format 1, 4 = attn_q4h (fp16 P) at any length */
+                     int32_t impl, s2v_stream stream);   /* impl: 0 product dispatch (bf16), 1 generic (VALU), 3 = 0 with attn_p_format 1, 4 = attn_q4h (fp16 P) at any length, 5 = fp32 on the fp32 matrix pipe (what the fp32 engine runs) */
 /* The same joint attention (F.scaled_dot_product_attention at attention_processor.py:2083-2087, head_dim 64, scale 1/8) as weight_format 2
  * runs it: q (times scale * log2 e) and k of the bf16 qkv rows [B*Ntok, 3*H*64] are quantised to MX e4m3 (32-element blocks along the
  * head dimension, E8M0 scales) into `scratch` and QK^T runs on v_mfma_scale_f32_32x32x64_f8f6f4; V^T (vt_scratch: B*H*64*rup(Ntok,64)

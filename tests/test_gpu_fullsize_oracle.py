@@ -3,7 +3,7 @@
   * one CogVideoXBlock at N = 226 + 1350 + 17550 = 19126 tokens, B = 2 (M = 38252 rows: the row-tail split of the 256-row
     GEMM tiles, api.hip), through s2v_block_forward, against oracle.transformer_ref.block_forward
     (cogvideox_transformer_3d.py:122-186) -- 5B width (D = 3072, 48 heads, RoPE; configs[2]) on the bf16 MFMA path and on
-    the fp32 generic path, and 2B width (D = 1920, 30 heads, no RoPE; configs[1]: padded 256-column tiles at M = 38252);
+    the fp32 path (VALU kernels, and the fp32 matrix-pipe kernels gemm_f32m / attn_f32m that the fp32 engine runs by default), and 2B width (D = 1920, 30 heads, no RoPE; configs[1]: padded 256-column tiles at M = 38252);
   * attention alone at the geometry of configs[4] (49 x 720 x 1280 -> N = 50626 tokens), two heads, against fp32 SDPA.
 
 Tolerances: fp32 generic path max-abs <= 1e-3 (north_star); bf16 path relative L2 <= 2e-2 and max-abs <= 6e-2 * max|ref|
@@ -60,8 +60,8 @@ def one_block_case(s2v, preset, dt, force_simple, B):
     return got, exp, t_cpu
 
 
-@pytest.mark.parametrize("preset,dt_name,simple", [("cogvideox_5b", "bf16", False), ("cogvideox_5b", "f32", True),
-                                                   ("cogvideox_2b", "bf16", False)])
+@pytest.mark.parametrize("preset,dt_name,simple", [("cogvideox_5b", "bf16", False), ("cogvideox_5b", "f32", True), ("cogvideox_5b", "f32", False),
+                                                   ("cogvideox_2b", "bf16", False)], ids=["5b-bf16", "5b-f32-valu", "5b-f32-mfma", "2b-bf16"])
 def test_one_block_full_tokens_vs_oracle(s2v, preset, dt_name, simple):
     dt = torch.float32 if dt_name == "f32" else torch.bfloat16
     B = 2 if dt_name == "bf16" else 1  # B = 2: M = 38252 (partial last row tile split off, api.hip); fp32 generic: one sample
