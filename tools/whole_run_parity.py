@@ -34,11 +34,7 @@ GEOMETRY = {"c3": (13, 60, 90, 226), "c5": (13, 90, 160, 226), "small": (3, 8, 1
 FORMATS = {"bf16": (None, "bf16"), "bf16-p16": (None, "f16"), "fp8": ("fp8", "bf16"), "fp8-qk": ("fp8-qk", "bf16"), "fp8-qk-p16": ("fp8-qk", "f16")}
 
 
-class _Stop(Exception):
-    pass
-
-
-def _run(s2v, cfg, sd, dt, geometry, steps, schedule, inputs, sink, guidance=6.0, use_graph=True):
+def _run(s2v, cfg, sd, dt, geometry, steps, schedule, inputs, sink, guidance=6.0, use_graph=True, round_latents=False):
     F, H, W, T = geometry
     lat0, pe, ne, ref = inputs
     m = s2v.HipCogVideoXTransformer3DModel(cfg, dt, DEV)
@@ -46,10 +42,13 @@ def _run(s2v, cfg, sd, dt, geometry, steps, schedule, inputs, sink, guidance=6.0
     pipe = s2v.S2VPipeline(m, s2v.CogVideoXDDIMScheduler(snr_shift_scale=cfg.snr_shift_scale), None)
 
     def cb(p, i, t, kw):
-        sink(i, kw["latents"])
+        x = kw["latents"]
+        if round_latents:  # fp32 arithmetic, but the latents stored in bf16 between steps as the bf16 pipeline stores them (custom_cogvideox_pipe.py:296)
+            x = x.bfloat16().to(x.dtype)
+        sink(i, x)
         if i + 1 >= steps:
             p.interrupt = True
-        return {}
+        return {"latents": x} if round_latents else {}
 
     t0 = time.time()
     pipe(prompt_embeds=pe, negative_prompt_embeds=ne, ref_img_states=ref, height=H * 8, width=W * 8, num_frames=(F - 1) * 4 + 1,
@@ -64,8 +63,10 @@ def _run(s2v, cfg, sd, dt, geometry, steps, schedule, inputs, sink, guidance=6.0
 
 
 def whole_run(s2v, preset="cogvideox_5b", geometry="c3", steps=10, schedule=50, formats=("bf16", "bf16-p16", "fp8", "fp8-qk"), seed=71,
-              layers=None, log=print):
-    """returns {format: [(step, max_abs, rel_l2, ref_max_abs), ...]} and the wall-clock of every run"""
+              layers=None, log=print, arith_ref=True):
+    """returns {format: [(step, max_abs, rel_l2, ref_max_abs, arith_max_abs, arith_rel_l2), ...]} and the wall-clock of every run.
+    max_abs / rel_l2: against the pure fp32 run; arith_*: against the fp32 run whose latents are rounded to bf16 after every step
+    (the bf16 pipeline's own storage rounding taken out: what is left is the transformer arithmetic)."""
     cfg0 = getattr(s2v, preset)()
     if layers:
         cfg0.num_layers = layers
@@ -79,12 +80,19 @@ def whole_run(s2v, preset="cogvideox_5b", geometry="c3", steps=10, schedule=50, 
     ref = (torch.randn(1, 1, 16, H, W, generator=g, device=DEV) * 0.7).bfloat16().float()
     inputs = (lat0, pe, ne, ref)
 
-    ref_lat = {}
+    ref_lat, ref_rl = {}, {}
     c = copy.copy(cfg0)
     c.attn_p_format = "bf16"
     secs = {"f32": _run(s2v, c, sd, torch.float32, geo, steps, schedule, inputs, lambda i, x: ref_lat.__setitem__(i, x.float().cpu()), use_graph=False)}
     log(f"fp32 reference run: {steps} steps of a {schedule}-step DDIM schedule, {T + (F + 1) * (H // 2) * (W // 2)} tokens, {cfg0.num_layers} layers: "
         f"{secs['f32']:.1f} s wall-clock (incl. weight load)")
+    if arith_ref:
+        secs["f32-bf16lat"] = _run(s2v, c, sd, torch.float32, geo, steps, schedule, inputs, lambda i, x: ref_rl.__setitem__(i, x.float().cpu()), use_graph=False,
+                                   round_latents=True)
+        for i in sorted(ref_rl):
+            a, b = ref_rl[i].double(), ref_lat[i].double()
+            log(f"{'f32-bf16lat':10s} step {i + 1:2d}: latents max-abs {(a - b).abs().max().item():.3e} (max|ref| {b.abs().max().item():.2f})  rel-L2 {((a - b).norm() / b.norm()).item():.3e}"
+                "   <- fp32 arithmetic, latents stored in bf16 between steps: the storage share of every figure below")
     res = {}
     for name in formats:
         wf, pf = FORMATS[name]
@@ -94,14 +102,19 @@ def whole_run(s2v, preset="cogvideox_5b", geometry="c3", steps=10, schedule=50, 
 
         def sink(i, x, rows=rows):
             a, b = x.float().cpu().double(), ref_lat[i].double()
-            rows.append((i, (a - b).abs().max().item(), ((a - b).norm() / b.norm()).item(), b.abs().max().item()))
+            row = [i, (a - b).abs().max().item(), ((a - b).norm() / b.norm()).item(), b.abs().max().item(), float("nan"), float("nan")]
+            if arith_ref:
+                b2 = ref_rl[i].double()
+                row[4], row[5] = (a - b2).abs().max().item(), ((a - b2).norm() / b2.norm()).item()
+            rows.append(tuple(row))
 
         secs[name] = _run(s2v, c, sd, torch.bfloat16, geo, steps, schedule, inputs, sink)
         res[name] = rows
-        for (i, ma, rl, rm) in rows:
-            log(f"{name:10s} step {i + 1:2d}: latents max-abs {ma:.3e} (max|ref| {rm:.2f})  rel-L2 {rl:.3e}")
+        for (i, ma, rl, rm, ama, arl) in rows:
+            log(f"{name:10s} step {i + 1:2d}: latents max-abs {ma:.3e} (max|ref| {rm:.2f})  rel-L2 {rl:.3e}   | vs f32-bf16lat: max-abs {ama:.3e}  rel-L2 {arl:.3e}")
         log(f"{name:10s} SUMMARY over {len(rows)} steps: worst max-abs {max(r[1] for r in rows):.3e}, worst rel-L2 {max(r[2] for r in rows):.3e}, "
-            f"final rel-L2 {rows[-1][2]:.3e}  ({secs[name]:.1f} s)")
+            f"final rel-L2 {rows[-1][2]:.3e}   | vs f32-bf16lat: worst max-abs {max(r[4] for r in rows):.3e}, worst rel-L2 {max(r[5] for r in rows):.3e}, "
+            f"final rel-L2 {rows[-1][5]:.3e}  ({secs[name]:.1f} s)")
     return res, secs
 
 
@@ -113,8 +126,10 @@ if __name__ == "__main__":
     ap.add_argument("--preset", default="cogvideox_5b")
     ap.add_argument("--layers", type=int, default=0)
     ap.add_argument("--formats", default="bf16,bf16-p16,fp8,fp8-qk")
+    ap.add_argument("--no-arith-ref", action="store_true", help="skip the second fp32 run (latents rounded to bf16 between steps)")
     a = ap.parse_args()
     s2v = importlib.import_module("disentangled-subject-to-vid_amd")
     print(f"# tools/whole_run_parity.py --steps {a.steps} --schedule {a.schedule} --geometry {a.geometry} --preset {a.preset} --formats {a.formats}"
           + (f" --layers {a.layers}" if a.layers else ""), flush=True)
-    whole_run(s2v, a.preset, a.geometry, a.steps, a.schedule, tuple(a.formats.split(",")), layers=a.layers or None, log=lambda s: print(s, flush=True))
+    whole_run(s2v, a.preset, a.geometry, a.steps, a.schedule, tuple(a.formats.split(",")), layers=a.layers or None, log=lambda s: print(s, flush=True),
+              arith_ref=not a.no_arith_ref)
