@@ -8,9 +8,9 @@ import torch  # noqa: F401  (must be imported first so the process-wide HIP runt
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("S2V_LIB") or os.path.join(_HERE, "libs2v_hip.so")  # S2V_LIB: an experiment build of the SAME library (tools/ab_step.sh)
 
-DTYPE_F32, DTYPE_BF16 = 0, 1
-TORCH_DTYPE = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16}
-DTYPE_OF = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16}
+DTYPE_F32, DTYPE_BF16, DTYPE_F16 = 0, 1, 2
+TORCH_DTYPE = {DTYPE_F32: torch.float32, DTYPE_BF16: torch.bfloat16, DTYPE_F16: torch.float16}
+DTYPE_OF = {torch.float32: DTYPE_F32, torch.bfloat16: DTYPE_BF16, torch.float16: DTYPE_F16}
 
 
 class ModelConfigC(ctypes.Structure):

@@ -46,6 +46,7 @@ struct s2v_ctx {
     s2v_model_config cfg;
     int D = 0, L = 0, dtype = 0, esz = 0, temb = 0;
     bool mfma = false;
+    bool h16 = false;            // fp16 model dtype: linears on v_mfma_f32_32x32x16_f16 (gemm_f16), attention on attn_f32m<f16_t>
     int mc = 6;                  // modulation chunks per norm{1,2}.linear in the stack: 6, or 9 under lora_adaln_scope = 1 (+ the
                                  // reference-image copy of chunks 0-2: cond_shift, cond_scale, cond_gate)
     float* lora_tmp = nullptr;   // fp32 scratch of s2v_merge_lora
@@ -136,7 +137,7 @@ static Slot* add_slot(s2v_ctx* c, const std::string& name, char* dst, int64_t ro
 
 extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     S2V_REQUIRE(cfg && out, "s2v_create: null argument");
-    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_create: unsupported dtype");
+    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16 || cfg->dtype == S2V_DTYPE_F16, "s2v_create: unsupported dtype");
     S2V_REQUIRE(cfg->patch_size == 2, "s2v_create: patch_size must be 2");
     S2V_REQUIRE(cfg->num_layers > 0 && cfg->num_heads > 0, "s2v_create: bad model size");
     S2V_REQUIRE(cfg->in_channels * 4 <= 4096 && cfg->out_channels > 0, "s2v_create: bad channel count");
@@ -145,7 +146,7 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     c->D = cfg->num_heads * 64;
     c->L = cfg->num_layers;
     c->dtype = cfg->dtype;
-    c->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
+    c->esz = cfg->dtype == S2V_DTYPE_F32 ? 4 : 2;
     c->temb = cfg->time_embed_dim;
     {
         int dev = 0, ncu = 0;
@@ -159,6 +160,7 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
         return s2v_fail(__FILE__, __LINE__, "s2v_create: stream / event creation failed", -2);
     }
     c->mfma = (cfg->dtype == S2V_DTYPE_BF16) && !cfg->force_simple;
+    c->h16 = (cfg->dtype == S2V_DTYPE_F16) && !cfg->force_simple;
     if (hipMalloc((void**)&c->attn_stats, 4096) != hipSuccess || hipMemset(c->attn_stats, 0, 4096) != hipSuccess) {
         s2v_destroy(c);
         return s2v_fail(__FILE__, __LINE__, "s2v_create: attention census allocation failed", -2);
@@ -319,7 +321,7 @@ extern "C" int s2v_load_weight(s2v_ctx* c, const char* name, const void* dev_ptr
                                int32_t src_dtype, s2v_stream stream) {
     S2V_REQUIRE(c && name && dev_ptr && shape, "s2v_load_weight: null argument");
     S2V_REQUIRE(!c->finalized, "s2v_load_weight: weights already finalized");
-    S2V_REQUIRE(src_dtype == S2V_DTYPE_F32 || src_dtype == S2V_DTYPE_BF16, "s2v_load_weight: unsupported source dtype");
+    S2V_REQUIRE(src_dtype == S2V_DTYPE_F32 || src_dtype == S2V_DTYPE_BF16 || src_dtype == S2V_DTYPE_F16, "s2v_load_weight: unsupported source dtype");
     auto it = c->slots.find(name);
     if (it == c->slots.end()) {
         std::string m = std::string("s2v_load_weight: unknown tensor name: ") + name;
@@ -572,6 +574,7 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
         }
         return launch_gemm_bf16(g, epi, st);
     }
+    if (c->h16 && gemm_f16_ok(g, epi)) return launch_gemm_f16(g, epi, st);
     g.valu_only = c->cfg.force_simple;  // fp32: the matrix-pipe kernel (gemm_f32m, same bits) unless the cross-check path is asked for
     return launch_gemm_simple(g, epi, c->dtype, st);
 }
@@ -877,7 +880,7 @@ extern "C" int s2v_sched_step(s2v_ctx* c, const s2v_sched_coef* coef_host, const
     S2V_REQUIRE(coef_host && noise_pred && latents_in && latents_out, "s2v_sched_step: null argument");
     S2V_REQUIRE(coef_host->kind == 0 || noise, "s2v_sched_step: DPM step needs a noise tensor");
     S2V_REQUIRE(coef_host->kind != 2 || x0_hist, "s2v_sched_step: DPM multistep needs x0_hist");
-    S2V_REQUIRE(dtype == S2V_DTYPE_F32 || dtype == S2V_DTYPE_BF16, "s2v_sched_step: unsupported dtype");
+    S2V_REQUIRE(dtype == S2V_DTYPE_F32 || dtype == S2V_DTYPE_BF16 || dtype == S2V_DTYPE_F16, "s2v_sched_step: unsupported dtype");
     (void)c;
     SchedArgs a{};
     a.noise_pred = noise_pred; a.latents_in = latents_in; a.latents_out = latents_out; a.x0_hist = x0_hist;
@@ -991,6 +994,12 @@ extern "C" int s2v_op_linear(const void* A, const void* W, const void* bias, voi
         hipFree(ws);
         return rc;
     }
+    if (impl == 4) {  // fp16 operands on v_mfma_f32_32x32x16_f16 (what the fp16 engine runs); M, N padded to 128 by the caller
+        S2V_REQUIRE(dtype == S2V_DTYPE_F16, "s2v_op_linear: impl 4 is fp16 only");
+        S2V_REQUIRE(M % 128 == 0 && N % 128 == 0, "s2v_op_linear: impl 4 needs M and N padded to 128 by the caller");
+        g.a_rows_padded = M; g.w_rows_padded = N;
+        return launch_gemm_f16(g, epilogue, (hipStream_t)stream);
+    }
     if (impl == 3) {  // fp32 operands on the fp32 matrix pipe (what the fp32 engine runs; bit-identical to impl 1)
         S2V_REQUIRE(dtype == S2V_DTYPE_F32, "s2v_op_linear: impl 3 is fp32 only");
         return launch_gemm_f32m(g, epilogue, (hipStream_t)stream);
@@ -1093,7 +1102,7 @@ extern "C" int s2v_set_attn_p_format(s2v_ctx* c, int32_t fmt) {
 extern "C" int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias, void* out, int32_t B, int32_t temb_dim,
                                int64_t rows, int32_t dtype, int32_t impl, s2v_stream stream) {
     S2V_REQUIRE(emb && W && out, "s2v_op_mod_gemv: null argument");
-    S2V_REQUIRE(dtype == S2V_DTYPE_BF16 || dtype == S2V_DTYPE_F32, "s2v_op_mod_gemv: dtype must be bf16 or f32");
+    S2V_REQUIRE(dtype == S2V_DTYPE_BF16 || dtype == S2V_DTYPE_F32 || dtype == S2V_DTYPE_F16, "s2v_op_mod_gemv: dtype must be f32, bf16 or f16");
     return launch_mod_gemv(emb, B, temb_dim, W, bias, rows, out, dtype, (hipStream_t)stream, impl == 1);
 }
 
@@ -1135,8 +1144,8 @@ extern "C" int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, in
         return launch_attn_bf16(a, st);
     }
     if (impl == 5) {  // fp32 on the fp32 matrix pipe (what the fp32 engine runs)
-        S2V_REQUIRE(dtype == S2V_DTYPE_F32, "s2v_op_attention: impl 5 is fp32 only");
-        return launch_attn_f32m(a, st);
+        S2V_REQUIRE(dtype == S2V_DTYPE_F32 || dtype == S2V_DTYPE_F16, "s2v_op_attention: impl 5 is fp32 / fp16 only");
+        return launch_attn_f32m(a, dtype, st);
     }
     a.valu_only = 1;
     return launch_attn_simple(a, dtype, st);

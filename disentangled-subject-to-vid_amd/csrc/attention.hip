@@ -637,12 +637,9 @@ __global__ __launch_bounds__(256) void attn_simple_k(const AttnArgs a) {
 }
 
 int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st) {
-    if (dtype == S2V_F32 && !a.valu_only) return launch_attn_f32m(a, st);
+    if ((dtype == S2V_F32 || dtype == S2V_F16) && !a.valu_only) return launch_attn_f32m(a, dtype, st);
     dim3 grid((a.Ntok + 3) / 4, a.H, a.B);
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(attn_simple_k<bf16_t>, grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL(attn_simple_k<float>, grid, dim3(256), 0, st, a);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(attn_simple_k<T>, grid, dim3(256), 0, st, a))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -16,12 +16,18 @@
 #define S2V_HOST
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 #define AQ_ROWS 128   // query rows per workgroup
 #define AK_TILE 32    // keys per KV tile
 #define AKT_PITCH 40  // floats per d-row of the K^T image (32 keys + 8: the two d-rows of a fragment read differ by 40 = 8 mod 32 banks)
 #define AV_PITCH 72   // floats per key row of the V image (rows k and k + 4 of a fragment read: 288 = 32 mod 64 banks)
 
+// T = float, or f16_t: the fp16 model dtype (src/inference.py:191,209).  fp16 values convert exactly to fp32 and so do their products, so
+// QK^T is what an fp16 MFMA with fp32 accumulation would return; the probabilities are rounded to fp16 before P.V (the row sum is taken
+// before that rounding) -- the points at which torch's CPU flash kernel rounds for a reduced-precision dtype -- and the output is stored
+// as fp16.
+template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_f32m_k(const AttnArgs a) {
     __shared__ float sKT[2][64][AKT_PITCH];
     __shared__ float sV[2][AK_TILE][AV_PITCH];
@@ -29,27 +35,37 @@ __global__ __launch_bounds__(256, 2) void attn_f32m_k(const AttnArgs a) {
     const int fr = lane & 31, hi = lane >> 5;
     const int h = blockIdx.y, b = blockIdx.z;
     const int D = a.H * 64;
-    const float* base = (const float*)a.qkv + (size_t)b * a.Ntok * a.ld_qkv;
+    const T* base = (const T*)a.qkv + (size_t)b * a.Ntok * a.ld_qkv;
     const int q = blockIdx.x * AQ_ROWS + wave * 32 + fr;
     const int ql = min(q, a.Ntok - 1);
     // B operand of the QK^T MFMA number s: Qs[q][2 s + hi]
     float qreg[32];
     {
-        const float* qp = base + (size_t)ql * a.ld_qkv + h * 64;
+        const T* qp = base + (size_t)ql * a.ld_qkv + h * 64;
 #pragma unroll
-        for (int s = 0; s < 32; ++s) qreg[s] = qp[2 * s + hi] * a.scale;
+        for (int s = 0; s < 32; ++s) qreg[s] = ET<T>::ld(qp + 2 * s + hi) * a.scale;
     }
     // staging of a KV tile: 32 keys x 64 floats of K and of V = 512 + 512 chunks of 16 bytes, two of each per thread
-    const int skey = tid >> 3, sc = tid & 7;  // key 0..31, chunks sc and sc + 8 of its 16
+    const int skey = tid >> 3, sc = tid & 7;  // key 0..31, chunks sc and sc + 8 of its 16 (fp32: 4 floats = 16 bytes; fp16: 4 halves = 8 bytes)
     f32x4 rk[2], rv[2];
+    auto ld4 = [](const T* p) -> f32x4 {
+        if constexpr (std::is_same<T, float>::value) {
+            return *(const f32x4*)p;
+        } else {
+            const u32x2 t = *(const u32x2*)p;
+            const unsigned w0 = t.x, w1 = t.y;  // copies: __builtin_bit_cast of a vector element expression reads element 0 (clang)
+            const f16x2_t lo = __builtin_bit_cast(f16x2_t, w0), hi2 = __builtin_bit_cast(f16x2_t, w1);
+            return f32x4{(float)lo[0], (float)lo[1], (float)hi2[0], (float)hi2[1]};
+        }
+    };
     auto gload = [&](int kv0) {
         const int key = min(kv0 + skey, a.Ntok - 1);
-        const float* kp = base + (size_t)key * a.ld_qkv + D + h * 64;
-        const float* vp = kp + D;
+        const T* kp = base + (size_t)key * a.ld_qkv + D + h * 64;
+        const T* vp = kp + D;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            rk[j] = *(const f32x4*)(kp + (sc + 8 * j) * 4);
-            rv[j] = *(const f32x4*)(vp + (sc + 8 * j) * 4);
+            rk[j] = ld4(kp + (sc + 8 * j) * 4);
+            rv[j] = ld4(vp + (sc + 8 * j) * 4);
         }
     };
     auto lstore = [&](int buf) {
@@ -98,6 +114,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32m_k(const AttnArgs a) {
         for (int e = 0; e < 16; ++e) {
             s[e] = expf(s[e] - mn);
             ps += s[e];
+            s[e] = ET<T>::rnd(s[e]);  // fp16 dtype: P.V takes fp16 probabilities
         }
         l = l * alpha + ps;
 #pragma unroll
@@ -116,24 +133,29 @@ __global__ __launch_bounds__(256, 2) void attn_f32m_k(const AttnArgs a) {
         l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
     }
     if (q < a.Ntok) {
-        const float inv = 1.0f / l;
-        float* op = (float*)a.out + (size_t)(b * a.Ntok + q) * a.ld_out + h * 64;
+        T* op = (T*)a.out + (size_t)(b * a.Ntok + q) * a.ld_out + h * 64;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             const int d = 8 * g + 4 * hi;
-            *(f32x4*)(op + d) = f32x4{o0[4 * g] / l, o0[4 * g + 1] / l, o0[4 * g + 2] / l, o0[4 * g + 3] / l};
-            *(f32x4*)(op + 32 + d) = f32x4{o1[4 * g] / l, o1[4 * g + 1] / l, o1[4 * g + 2] / l, o1[4 * g + 3] / l};
+            if constexpr (std::is_same<T, float>::value) {
+                *(f32x4*)(op + d) = f32x4{o0[4 * g] / l, o0[4 * g + 1] / l, o0[4 * g + 2] / l, o0[4 * g + 3] / l};
+                *(f32x4*)(op + 32 + d) = f32x4{o1[4 * g] / l, o1[4 * g + 1] / l, o1[4 * g + 2] / l, o1[4 * g + 3] / l};
+            } else {
+                *(u32x2*)(op + d) = u32x2{pack2h(o0[4 * g] / l, o0[4 * g + 1] / l), pack2h(o0[4 * g + 2] / l, o0[4 * g + 3] / l)};
+                *(u32x2*)(op + 32 + d) = u32x2{pack2h(o1[4 * g] / l, o1[4 * g + 1] / l), pack2h(o1[4 * g + 2] / l, o1[4 * g + 3] / l)};
+            }
         }
-        (void)inv;
     }
 }
 
-int launch_attn_f32m(const AttnArgs& a, hipStream_t st) {
+int launch_attn_f32m(const AttnArgs& a, int dtype, hipStream_t st) {
+    S2V_REQUIRE(dtype == S2V_F32 || dtype == S2V_F16, "attn_f32m: fp32 or fp16 storage");
     S2V_REQUIRE(a.ld_qkv % 4 == 0 && a.ld_out % 4 == 0 && ((uintptr_t)a.qkv & 15) == 0 && ((uintptr_t)a.out & 15) == 0,
-                "attn_f32m: qkv / out must be 16-byte aligned with leading dimensions that are multiples of 4 floats");
+                "attn_f32m: qkv / out must be 16-byte aligned with leading dimensions that are multiples of 4 elements");
     S2V_REQUIRE(a.Ntok > 0 && a.H <= 65535 && a.B <= 65535, "attn_f32m: bad shape");
     const dim3 grid((a.Ntok + AQ_ROWS - 1) / AQ_ROWS, a.H, a.B);
-    hipLaunchKernelGGL(attn_f32m_k, grid, dim3(256), 0, st, a);
+    if (dtype == S2V_F16) hipLaunchKernelGGL(attn_f32m_k<f16_t>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(attn_f32m_k<float>, grid, dim3(256), 0, st, a);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }

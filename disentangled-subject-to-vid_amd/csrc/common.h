@@ -39,6 +39,24 @@ template <> struct ET<bf16_t> {
     static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
 };
 
+// fp16 storage (round 5): the model dtype the reference selects for every non-5B checkpoint (src/inference.py:191,209).  A distinct C++ type
+// (bf16_t is an integer typedef), converted by v_cvt_f16_f32 / v_cvt_f32_f16: round-to-nearest-even, overflow to infinity past 65504 as
+// torch's conversion does.
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <> struct ET<f16_t> {
+    static __device__ __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    static __device__ __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }
+    static __device__ __forceinline__ float rnd(float v) { return (float)(f16_t)v; }
+};
+__device__ __forceinline__ unsigned int pack2h(float lo, float hi) {
+    f16x2_t v;
+    v[0] = (_Float16)lo;
+    v[1] = (_Float16)hi;
+    return __builtin_bit_cast(unsigned int, v);
+}
+
 // Wave-wide butterfly v (op) v[lane ^ 32], ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 -- the operand order of the __shfl_xor loop this replaces, so sums
 // keep their bits -- without the LDS crossbar: __shfl_xor lowers to ds_bpermute_b32 behind five VALU of index arithmetic and an
 // s_waitcnt lgkmcnt(0) per step.  ^ 32 / ^ 16: v_permlane32_swap / v_permlane16_swap of two copies (gfx950); ^ 8: DPP row_ror:8;
@@ -106,6 +124,28 @@ template <> struct Vec16<bf16_t> {
         u32x4 t;
 #pragma unroll
         for (int i = 0; i < 4; ++i) t[i] = pack2bf(v[2 * i], v[2 * i + 1]);
+        *(u32x4*)p = t;
+    }
+};
+
+template <> struct Vec16<f16_t> {
+    static constexpr int N = 8;
+    typedef u32x4 raw_t;
+    static __device__ __forceinline__ raw_t ldraw(const f16_t* p) { return *(const u32x4*)p; }
+    static __device__ __forceinline__ void dec(const raw_t& t, float* v) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned int w = t[i];  // a copy: __builtin_bit_cast of a vector ELEMENT expression reads element 0 whatever the index (clang)
+            const f16x2_t h = __builtin_bit_cast(f16x2_t, w);
+            v[2 * i] = (float)h[0];
+            v[2 * i + 1] = (float)h[1];
+        }
+    }
+    static __device__ __forceinline__ void ld(const f16_t* p, float* v) { dec(*(const u32x4*)p, v); }
+    static __device__ __forceinline__ void st(f16_t* p, const float* v) {
+        u32x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = pack2h(v[2 * i], v[2 * i + 1]);
         *(u32x4*)p = t;
     }
 };

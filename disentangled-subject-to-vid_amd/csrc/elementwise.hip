@@ -7,6 +7,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <cstdlib>
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------------
 // Row LayerNorm helpers: one wave per row, row cached in registers (D <= 4096, D % (16/sizeof(T)) == 0)
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(256) void ln_modulate_k(const LnModArgs a) {
     const T* shift = (const T*)(txt ? a.shift_txt : ref ? a.shift_ref : a.shift_vid) + (size_t)b * a.mod_stride;
     const T* scale = (const T*)(txt ? a.scale_txt : ref ? a.scale_ref : a.scale_vid) + (size_t)b * a.mod_stride;
     float v[NR * Vec16<T>::N];
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (std::is_same<T, bf16_t>::value) {
         if (a.q8 != nullptr) {  // fp8 engine: per-row e4m3 image instead of the bf16 store
             row_load<T, NR>((const T*)a.x + (size_t)row * a.ldx, a.D, lane, v);
             row_layernorm<T, NR>(v, a.D, lane, (const T*)a.w, (const T*)a.b, a.eps);
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(256) void ln_modulate_lds_k(const LnModArgs a) {
         float v[NR * VN];
         row_load<T, NR>((const T*)a.x + (size_t)row * a.ldx, a.D, lane, v);
         row_layernorm<T, NR>(v, a.D, lane, pw, pb, a.eps);
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (std::is_same<T, bf16_t>::value) {
             if (a.q8 != nullptr) {
                 row_modulate_quant_store<NR>(v, a.D, lane, psh, psc, (unsigned char*)a.q8 + (size_t)row * a.D, a.q8_scale + row);
                 continue;
@@ -325,6 +326,8 @@ int launch_ln_modulate(const LnModArgs& a, int dtype, hipStream_t st) {
     }
     if (dtype == S2V_BF16) {
         S2V_LN_DISPATCH(bf16_t, a.D, hipLaunchKernelGGL((ln_modulate_k<bf16_t, NR>), grid, dim3(256), 0, st, a))
+    } else if (dtype == S2V_F16) {
+        S2V_LN_DISPATCH(f16_t, a.D, hipLaunchKernelGGL((ln_modulate_k<f16_t, NR>), grid, dim3(256), 0, st, a))
     } else {
         S2V_LN_DISPATCH(float, a.D, hipLaunchKernelGGL((ln_modulate_k<float, NR>), grid, dim3(256), 0, st, a))
     }
@@ -353,6 +356,8 @@ int launch_tail_norm(const TailNormArgs& a, int dtype, hipStream_t st) {
     dim3 grid((a.B * a.V + 3) / 4);
     if (dtype == S2V_BF16) {
         S2V_LN_DISPATCH(bf16_t, a.D, hipLaunchKernelGGL((tail_norm_k<bf16_t, NR>), grid, dim3(256), 0, st, a))
+    } else if (dtype == S2V_F16) {
+        S2V_LN_DISPATCH(f16_t, a.D, hipLaunchKernelGGL((tail_norm_k<f16_t, NR>), grid, dim3(256), 0, st, a))
     } else {
         S2V_LN_DISPATCH(float, a.D, hipLaunchKernelGGL((tail_norm_k<float, NR>), grid, dim3(256), 0, st, a))
     }
@@ -527,10 +532,7 @@ int launch_qk_quant_mx(const void* qkv, int ld_qkv, int B, int H, int Ntok, int 
 
 int launch_qk_norm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t st) {
     dim3 grid((unsigned)(a.B * a.Ntok), (unsigned)((2 * a.H * 8 + 255) / 256));
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(qk_norm_rope_k<bf16_t>, grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL(qk_norm_rope_k<float>, grid, dim3(256), 0, st, a);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(qk_norm_rope_k<T>, grid, dim3(256), 0, st, a))
     S2V_CHECK_HIP(hipGetLastError());
     if (a.vt != nullptr) {
         S2V_REQUIRE(dtype == S2V_BF16, "V^T is only produced on the bf16 path");
@@ -683,28 +685,21 @@ int launch_time_embed(const float* t_dev, int B, int D, const void* w1, const vo
                       int temb_dim, void* tmp, void* emb_out, int dtype, hipStream_t st) {
     // tmp holds [B, D] sinusoid followed by [B, temb] hidden
     const int n = B * D;
-    if (dtype == S2V_BF16) {
-        bf16_t* sc = (bf16_t*)tmp;
-        bf16_t* h1 = sc + n;
-        hipLaunchKernelGGL(timestep_sincos_k<bf16_t>, dim3((n + 255) / 256), dim3(256), 0, st, t_dev, B, D, sc);
+    S2V_DT_DISPATCH(dtype, {
+        T* sc = (T*)tmp;
+        T* h1 = sc + n;
+        hipLaunchKernelGGL(timestep_sincos_k<T>, dim3((n + 255) / 256), dim3(256), 0, st, t_dev, B, D, sc);
         S2V_CHECK_HIP(hipGetLastError());
-        S2V_TRY(gemv_rows<bf16_t>(sc, B, D, w1, b1, temb_dim, h1, false, st));
-        S2V_TRY(gemv_rows<bf16_t>(h1, B, temb_dim, w2, b2, temb_dim, emb_out, true, st));
-    } else {
-        float* sc = (float*)tmp;
-        float* h1 = sc + n;
-        hipLaunchKernelGGL(timestep_sincos_k<float>, dim3((n + 255) / 256), dim3(256), 0, st, t_dev, B, D, sc);
-        S2V_CHECK_HIP(hipGetLastError());
-        S2V_TRY(gemv_rows<float>(sc, B, D, w1, b1, temb_dim, h1, false, st));
-        S2V_TRY(gemv_rows<float>(h1, B, temb_dim, w2, b2, temb_dim, emb_out, true, st));
-    }
+        S2V_TRY(gemv_rows<T>(sc, B, D, w1, b1, temb_dim, h1, false, st));
+        S2V_TRY(gemv_rows<T>(h1, B, temb_dim, w2, b2, temb_dim, emb_out, true, st));
+    })
     return 0;
 }
 
 int launch_mod_gemv(const void* emb, int B, int temb_dim, const void* W, const void* bias, int64_t rows_total,
                     void* out, int dtype, hipStream_t st, bool rowwise) {
-    return dtype == S2V_BF16 ? gemv_rows<bf16_t>(emb, B, temb_dim, W, bias, rows_total, out, true, st, rowwise)
-                             : gemv_rows<float>(emb, B, temb_dim, W, bias, rows_total, out, true, st, rowwise);
+    S2V_DT_DISPATCH(dtype, return gemv_rows<T>(emb, B, temb_dim, W, bias, rows_total, out, true, st, rowwise))
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -729,12 +724,7 @@ int launch_patchify(const void* lat, int64_t lat_bstride, int Bn, int F, int C, 
                     hipStream_t st) {
     const int64_t total = (int64_t)Bn * F * (H / 2) * (W / 2) * C * 4;
     dim3 grid((unsigned)((total + 255) / 256));
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(patchify_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)lat, lat_bstride, Bn, F, C, H, W,
-                           (bf16_t*)out);
-    else
-        hipLaunchKernelGGL(patchify_k<float>, grid, dim3(256), 0, st, (const float*)lat, lat_bstride, Bn, F, C, H, W,
-                           (float*)out);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(patchify_k<T>, grid, dim3(256), 0, st, (const T*)lat, lat_bstride, Bn, F, C, H, W, (T*)out))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -759,12 +749,7 @@ int launch_unpatchify(const void* y, int ldy, int64_t y_bstride, void* out, int 
                       hipStream_t st) {
     const int64_t total = (int64_t)B * F * C * H * W;
     dim3 grid((unsigned)((total + 255) / 256));
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(unpatchify_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)y, ldy, y_bstride, (bf16_t*)out,
-                           B, F, C, H, W);
-    else
-        hipLaunchKernelGGL(unpatchify_k<float>, grid, dim3(256), 0, st, (const float*)y, ldy, y_bstride, (float*)out, B,
-                           F, C, H, W);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(unpatchify_k<T>, grid, dim3(256), 0, st, (const T*)y, ldy, y_bstride, (T*)out, B, F, C, H, W))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -783,12 +768,7 @@ int launch_copy_rows(const void* src, int lds_, const void* add, int ldadd, void
     const int64_t total = (int64_t)rows * D;
     if (total == 0) return 0;
     dim3 grid((unsigned)((total + 255) / 256));
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(copy_rows_k<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)src, lds_, (const bf16_t*)add,
-                           ldadd, (bf16_t*)dst, ldd, rows, D);
-    else
-        hipLaunchKernelGGL(copy_rows_k<float>, grid, dim3(256), 0, st, (const float*)src, lds_, (const float*)add, ldadd,
-                           (float*)dst, ldd, rows, D);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(copy_rows_k<T>, grid, dim3(256), 0, st, (const T*)src, lds_, (const T*)add, ldadd, (T*)dst, ldd, rows, D))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -835,10 +815,7 @@ __global__ void sched_step_k(const SchedArgs a) {
 }
 int launch_sched_step(const SchedArgs& a, int dtype, hipStream_t st) {
     dim3 grid((unsigned)((a.n + 255) / 256));
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(sched_step_k<bf16_t>, grid, dim3(256), 0, st, a);
-    else
-        hipLaunchKernelGGL(sched_step_k<float>, grid, dim3(256), 0, st, a);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(sched_step_k<T>, grid, dim3(256), 0, st, a))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -857,10 +834,18 @@ int launch_convert2d(const void* src, int sdt, int64_t lds_, void* dst, int ddt,
     if (total == 0) return 0;
     dim3 grid((unsigned)((total + 255) / 256));
 #define CV(TS, TD) hipLaunchKernelGGL((convert2d_k<TS, TD>), grid, dim3(256), 0, st, (const TS*)src, lds_, (TD*)dst, ldd, rows, cols)
-    if (sdt == S2V_F32 && ddt == S2V_F32) CV(float, float);
-    else if (sdt == S2V_F32 && ddt == S2V_BF16) CV(float, bf16_t);
-    else if (sdt == S2V_BF16 && ddt == S2V_F32) CV(bf16_t, float);
-    else CV(bf16_t, bf16_t);
+    S2V_REQUIRE(sdt >= 0 && sdt <= 2 && ddt >= 0 && ddt <= 2, "convert: unknown dtype");
+    switch (sdt * 3 + ddt) {
+        case S2V_F32 * 3 + S2V_F32: CV(float, float); break;
+        case S2V_F32 * 3 + S2V_BF16: CV(float, bf16_t); break;
+        case S2V_F32 * 3 + S2V_F16: CV(float, f16_t); break;
+        case S2V_BF16 * 3 + S2V_F32: CV(bf16_t, float); break;
+        case S2V_BF16 * 3 + S2V_BF16: CV(bf16_t, bf16_t); break;
+        case S2V_BF16 * 3 + S2V_F16: CV(bf16_t, f16_t); break;
+        case S2V_F16 * 3 + S2V_F32: CV(f16_t, float); break;
+        case S2V_F16 * 3 + S2V_BF16: CV(f16_t, bf16_t); break;
+        default: CV(f16_t, f16_t); break;
+    }
 #undef CV
     S2V_CHECK_HIP(hipGetLastError());
     return 0;

@@ -85,7 +85,9 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + off);
 }
 
-template <int EPI>
+// T16 = bf16_t (v_mfma_f32_32x32x16_bf16) or f16_t (v_mfma_f32_32x32x16_f16: the fp16 model dtype, round 5 -- the staging, the swizzle and the
+// fragment reads move 16-bit elements whatever they encode; the fp16 form takes the lane-local epilogue4 below)
+template <int EPI, typename T16 = bf16_t>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -144,15 +146,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int ti
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (std::is_same<T16, f16_t>::value)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[i]), __builtin_bit_cast(f16x8, af[j]), acc[i][j], 0, 0, 0);
+                    else
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+                }
         }
         __syncthreads();
     }
 
-    if (epi_vec_ok(a, EPI)) {  // the k-loop ended with a barrier: the operand stages are free
-        epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
-        return;
+    if constexpr (std::is_same<T16, bf16_t>::value) {
+        if (epi_vec_ok(a, EPI)) {  // the k-loop ended with a barrier: the operand stages are free
+            epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
+            return;
+        }
     }
     // epilogue: D[i = n][j = m]; lane: m = fr, n = (reg&3) + 8*(reg>>2) + 4*hi
 #pragma unroll
@@ -164,9 +172,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int ti
             for (int rq = 0; rq < 4; ++rq) {
                 const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
                 float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
-                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
+                if (n < a.N) epilogue4<T16, EPI>(a, m, n, v);
             }
         }
+}
+
+// the fp16 model dtype's linears: K % 64 == 0, 16-byte aligned rows, operands with the rows of whole 128-row tiles present behind them
+bool gemm_f16_ok(const GemmArgs& a, int epi) {
+    if (epi == EPI_BIAS_QKNORM || a.splitk > 1 || a.m_begin != 0) return false;
+    if (a.K % BK != 0 || a.ldw % 8 != 0 || (a.conv ? a.cin % 64 != 0 : a.lda % 8 != 0)) return false;
+    const int64_t mp = (int64_t)((a.M + BM - 1) / BM) * BM, np = (int64_t)((a.N + BN - 1) / BN) * BN;
+    return (a.conv || a.a_rows_padded >= mp) && (a.w_rows_padded >= np || a.N % BN == 0);
+}
+int launch_gemm_f16(const GemmArgs& a, int epi, hipStream_t st) {
+    S2V_REQUIRE(gemm_f16_ok(a, epi), "gemm_f16: shape / padding not supported");
+    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
+    const dim3 grid(tiles_m * tiles_n);
+    const size_t shmem = 4 * TILE_BYTES;
+    switch (epi) {
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS, f16_t>), grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS_GELU, f16_t>), grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_GATE_RES: hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS_GATE_RES, f16_t>), grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_ADD: hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS_ADD, f16_t>), grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
+        default: return s2v_fail(__FILE__, __LINE__, "gemm_f16: bad epilogue", -1);
+    }
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1401,7 +1432,8 @@ static int launch_simple_t(const GemmArgs& a, int epi, hipStream_t st) {
 int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st) {
     if (dtype == S2V_F32 && gemm_f32m_ok(a)) return launch_gemm_f32m(a, epi, st);
     S2V_REQUIRE((a.M + 63) / 64 <= 65535, "gemm_simple: M too large for the generic kernel");
-    return dtype == S2V_BF16 ? launch_simple_t<bf16_t>(a, epi, st) : launch_simple_t<float>(a, epi, st);
+    S2V_DT_DISPATCH(dtype, return launch_simple_t<T>(a, epi, st))
+    return 0;
 }
 
 // generic strided fp32 GEMM-accumulate (load-time only; LoRA merge W += alpha * B.A)

@@ -3,6 +3,7 @@
 #pragma once
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 // No fma contraction in the epilogues: they restate separately-rounded elementwise ops (LayerNorm, rotary embedding, gate, residual) and
 // are compiled into more than one translation unit -- with -ffp-contract=fast hipcc fused `a * b + c` in gemm_g4.hip where it had not in
@@ -51,10 +52,15 @@ __device__ __forceinline__ void epilogue4(const GemmArgs& a, int m, int n, const
     }
     T* c = (T*)a.C + (size_t)m * a.ldc + n;
     if (n + 3 < a.N && (a.ldc & 3) == 0) {
-        if (sizeof(T) == 2) {
+        if constexpr (std::is_same<T, bf16_t>::value) {
             u32x2 p;
             p.x = pack2bf(y[0], y[1]);
             p.y = pack2bf(y[2], y[3]);
+            *(u32x2*)c = p;
+        } else if constexpr (std::is_same<T, f16_t>::value) {
+            u32x2 p;
+            p.x = pack2h(y[0], y[1]);
+            p.y = pack2h(y[2], y[3]);
             *(u32x2*)c = p;
         } else {
             *(f32x4*)c = (f32x4){y[0], y[1], y[2], y[3]};

@@ -3,7 +3,14 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-enum { S2V_F32 = 0, S2V_BF16 = 1 };
+enum { S2V_F32 = 0, S2V_BF16 = 1, S2V_F16 = 2 };
+// T = the storage type of `dtype`
+#define S2V_DT_DISPATCH(dtype, ...)                                        \
+    switch (dtype) {                                                       \
+        case S2V_BF16: { using T = bf16_t; __VA_ARGS__; } break;           \
+        case S2V_F16: { using T = f16_t; __VA_ARGS__; } break;             \
+        default: { using T = float; __VA_ARGS__; } break;                  \
+    }
 enum { EPI_BIAS = 0, EPI_BIAS_GELU = 1, EPI_BIAS_GATE_RES = 2 };
 
 // C[m][n] = sum_k A[m][k] * W[n][k] (+ bias[n]) followed by an epilogue.
@@ -87,6 +94,9 @@ __host__ __device__ __forceinline__ int64_t mx_perm_row(int64_t m) { return (m &
 int launch_gemm_bf16(const GemmArgs& a, int epi, hipStream_t st);              // MFMA path, bf16 only
 // any dtype, any shape.  fp32 calls that qualify (gemm_f32m_ok) run on the fp32 matrix pipe (gemm_f32m.hip) unless a.valu_only -- same bits
 int launch_gemm_simple(const GemmArgs& a, int epi, int dtype, hipStream_t st);
+// fp16 operands (the fp16 model dtype) on v_mfma_f32_32x32x16_f16: the 128 x 128 x 64 kernel of gemm.hip with its lane-local epilogue
+bool gemm_f16_ok(const GemmArgs& a, int epi);
+int launch_gemm_f16(const GemmArgs& a, int epi, hipStream_t st);
 // gemm_f32m.hip: fp32 operands on v_mfma_f32_32x32x2_f32, bit-identical to gemm_simple_k<float>
 bool gemm_f32m_ok(const GemmArgs& a);
 int launch_gemm_f32m(const GemmArgs& a, int epi, hipStream_t st);
@@ -152,9 +162,9 @@ int launch_attn_q4f(const AttnArgs& a, bool persistent, hipStream_t st);
 // attn_q4 with P / V^T in fp16 (AttnArgs::p16 = 1)
 int launch_attn_q4h(const AttnArgs& a, bool persistent, hipStream_t st);
 int launch_attn_bf16(const AttnArgs& a, hipStream_t st);
-// generic kernel, any dtype; fp32 calls run attn_f32m (attention_f32m.hip: QK^T and P.V on v_mfma_f32_32x32x2_f32) unless a.valu_only
+// generic kernel, any dtype; fp32 and fp16 calls run attn_f32m (attention_f32m.hip: QK^T and P.V on v_mfma_f32_32x32x2_f32) unless a.valu_only
 int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st);
-int launch_attn_f32m(const AttnArgs& a, hipStream_t st);
+int launch_attn_f32m(const AttnArgs& a, int dtype, hipStream_t st);  // dtype S2V_F32 or S2V_F16 (storage; the arithmetic is fp32 either way)
 // four-wave form of the bf16 kernel (attention_q4.hip); persistent needs a.queue / a.num_cus
 int launch_attn_q4(const AttnArgs& a, bool persistent, hipStream_t st);
 // eight waves x 32 rows running the same fine-grained stream, two waves per SIMD

@@ -19,7 +19,7 @@ class _ArenaView:
 class S2VEngine:
     def __init__(self, cfg: TransformerConfig, dtype=torch.bfloat16, device="cuda:0", force_simple=False):
         if dtype not in _lib.DTYPE_OF:
-            raise _lib.S2VError(f"unsupported model dtype {dtype} (float32 and bfloat16 are implemented)")
+            raise _lib.S2VError(f"unsupported model dtype {dtype} (float32, bfloat16 and float16 are implemented)")
         if cfg.attention_head_dim != 64:
             raise _lib.S2VError("attention_head_dim must be 64")
         self.cfg, self.dtype, self.device = cfg, dtype, torch.device(device)
@@ -268,6 +268,6 @@ class S2VEngine:
         B, T, F, H, W = self.geometry
         p = ctypes.c_void_p()
         _lib.check(_lib.lib().s2v_last_noise_pred(self._h, ctypes.byref(p)))
-        n = B * F * self.cfg.out_channels * H * W * (2 if self.dtype == torch.bfloat16 else 4)
+        n = B * F * self.cfg.out_channels * H * W * (4 if self.dtype == torch.float32 else 2)
         raw = torch.as_tensor(_ArenaView(p.value, n), device=self.device)
         return raw.view(self.dtype).view(B, F, self.cfg.out_channels, H, W).clone()

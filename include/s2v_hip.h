@@ -32,7 +32,9 @@ extern "C" {
 typedef struct s2v_ctx s2v_ctx;
 typedef void* s2v_stream; /* hipStream_t */
 
-enum { S2V_DTYPE_F32 = 0, S2V_DTYPE_BF16 = 1 };
+/* F16 (round 5): the dtype the reference selects for every non-5B checkpoint (src/inference.py:191,209).  Transformer contexts
+ * (s2v_create), the scheduler step and the operator-level entry points take it; the VAE / T5 contexts are fp32 / bf16. */
+enum { S2V_DTYPE_F32 = 0, S2V_DTYPE_BF16 = 1, S2V_DTYPE_F16 = 2 };
 
 /* CogVideoXTransformer3DModel.__init__ hyper-parameters
  * (diffusers/src/diffusers/models/transformers/cogvideox_transformer_3d.py:253-280) */
@@ -299,6 +301,7 @@ S2V_API int s2v_t5_encode(s2v_t5* t5, const int64_t* input_ids_dev, int32_t B, i
 /* ---- operator-level entry points (used by the parity tests and micro-benchmarks) ------------------------- */
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic (VALU),
  * 3 = fp32 operands on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; what the fp32 engine runs, bit-identical to impl 1),
+ * 4 = fp16 operands on v_mfma_f32_32x32x16_f16 (what the fp16 engine runs; M, N multiples of 128),
  * 2 = MFMA bf16 with K split over several workgroups per output tile, as the engine runs GEMMs with few tiles and a long
  * reduction (M, N multiples of 256; fails if the shape does not qualify; allocates its workspace, synchronous) */
 S2V_API int s2v_op_linear(const void* A, const void* W, const void* bias, void* C, int32_t M, int32_t N, int32_t K,
@@ -332,7 +335,7 @@ S2V_API int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias, vo
 S2V_API int s2v_attn_slow_stats(s2v_ctx* ctx, uint64_t* slow, uint64_t* total, int32_t reset);
 S2V_API int s2v_set_attn_p_format(s2v_ctx* ctx, int32_t attn_p_format);
 S2V_API int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype,
-                     int32_t impl, s2v_stream stream);   /* impl: 0 product dispatch (bf16), 1 generic (VALU), 3 = 0 with attn_p_format 1, 4 = attn_q4h (fp16 P) at any length, 5 = fp32 on the fp32 matrix pipe (what the fp32 engine runs) */
+                     int32_t impl, s2v_stream stream);   /* impl: 0 product dispatch (bf16), 1 generic (VALU), 3 = 0 with attn_p_format 1, 4 = attn_q4h (fp16 P) at any length, 5 = fp32 / fp16 storage on the fp32 matrix pipe (what the fp32 and fp16 engines run) */
 /* The same joint attention (F.scaled_dot_product_attention at attention_processor.py:2083-2087, head_dim 64, scale 1/8) as weight_format 2
  * runs it: q (times scale * log2 e) and k of the bf16 qkv rows [B*Ntok, 3*H*64] are quantised to MX e4m3 (32-element blocks along the
  * head dimension, E8M0 scales) into `scratch` and QK^T runs on v_mfma_scale_f32_32x32x64_f8f6f4; V^T (vt_scratch: B*H*64*rup(Ntok,64)

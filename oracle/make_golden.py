@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 REF = os.environ.get("S2V_REFERENCE", "/root/reference")
-OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+OUT = os.environ.get("S2V_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
 
 
 def import_reference():
@@ -103,7 +103,9 @@ def gen_sched():
 
     gen = torch.Generator().manual_seed(7)
     shape = (1, 3, 16, 6, 10)
-    for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+    # fp16 (round 5: the model dtype src/inference.py:191,209 selects for every non-5B checkpoint) comes LAST: the files of the other two
+    # dtypes keep their bits (one generator feeds all three in turn)
+    for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
         for kind, cls in (("ddim", CogVideoXDDIMScheduler), ("dpm", CogVideoXDPMScheduler)):
             for n_steps, snr in ((10, 3.0), (50, 1.0)):
                 s = cls(**sched_kwargs(snr))
@@ -179,7 +181,7 @@ def gen_transformer():
         if variant == "rope":
             out.update(npsd(weights))
             out.update(rope_cos=cos.numpy(), rope_sin=sin.numpy())
-        for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        for dt_name, dt in (("f32", torch.float32), ("bf16", torch.bfloat16), ("f16", torch.float16)):
             mm = m.to(dt)
             kw = dict(image_rotary_emb=tuple(x for x in vid_rope), ref_image_rotary_emb=tuple(x for x in ref_rope)) \
                 if use_rope else dict(image_rotary_emb=None, ref_image_rotary_emb=None)

@@ -29,6 +29,11 @@ def rel_l2(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
 
 
+DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
+# fp16 (round 5; src/inference.py:191,209 runs every non-5B checkpoint in it): same rounding points as bf16, 8 x finer ulps -> bars / 8
+BARS = {"bf16": (2e-2, 6e-2), "f16": (2.5e-3, 7.5e-3)}
+
+
 def assert_close(got, exp, dt_name, what=""):
     got, exp = got.float().cpu(), exp.float().cpu()
     assert torch.isfinite(got).all(), f"{what}: non-finite output"
@@ -37,7 +42,8 @@ def assert_close(got, exp, dt_name, what=""):
         assert err <= 1e-3, f"{what}: max-abs {err}"
     else:
         r = rel_l2(got, exp)
-        assert r <= 2e-2 and err <= 6e-2 * exp.abs().max().item(), f"{what}: rel-l2 {r}, max-abs {err}"
+        br, ba = BARS[dt_name]
+        assert r <= br and err <= ba * exp.abs().max().item(), f"{what}: rel-l2 {r}, max-abs {err} (max|ref| {exp.abs().max().item()})"
 
 
 # ------------------------------------------------------------------------------------------------ operators
@@ -104,6 +110,52 @@ def test_op_attention(s2v, B, H, N, impl, dt_name):
     assert (got - ref).abs().max() <= tol * max(1.0, ref.abs().max().item()), (got - ref).abs().max()
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(128, 128, 64, 0), (384, 256, 3072, 0), (256, 512, 1024, 1), (1280, 1920 + 128, 1920, 0)])
+def test_op_linear_mfma_f16(s2v, M, N, K, epi):
+    """fp16 operands on v_mfma_f32_32x32x16_f16 (impl 4: what the fp16 engine's linears run) against fp64 on the same fp16 values"""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).half()
+    W = (torch.randn(N, K, generator=g) * 0.5).half()  # asymmetric, non-identity
+    b = torch.randn(N, generator=g).half()
+    ref = (A.double() @ W.double().T + b.double()).float()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref.half().float(), approximate="tanh")
+    Ad, Wd, bd = A.to(DEV), W.to(DEV), b.to(DEV)
+    C = torch.full((M, N), float("nan"), dtype=torch.float16, device=DEV)
+    L = s2v._lib
+    L.check(L.lib().s2v_op_linear(L.ptr(Ad), L.ptr(Wd), L.ptr(bd), L.ptr(C), M, N, K, epi, L.DTYPE_F16, 4, L.stream_ptr()))
+    torch.cuda.synchronize()
+    got = C.float().cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) < 5e-4, rel_l2(got, ref)
+    assert (got - ref).abs().max() <= 2.5e-3 * ref.abs().max() + 1.25e-3
+    # the generic VALU kernel on the same operands (impl 1) agrees to fp16 rounding of the same fp32-accumulated sums
+    C1 = torch.empty_like(C)
+    L.check(L.lib().s2v_op_linear(L.ptr(Ad), L.ptr(Wd), L.ptr(bd), L.ptr(C1), M, N, K, epi, L.DTYPE_F16, 1, L.stream_ptr()))
+    torch.cuda.synchronize()
+    assert (C1.float().cpu() - got).abs().max() <= 2e-3 * ref.abs().max() + 1e-3
+
+
+@pytest.mark.parametrize("B,H,N,impl", [(1, 2, 129, 5), (2, 3, 300, 5), (1, 1, 32, 5), (1, 2, 1000, 5), (1, 2, 129, 1)])
+def test_op_attention_f16(s2v, B, H, N, impl):
+    """fp16 storage: attn_f32m<f16_t> (impl 5; exact fp16 x fp16 products on the fp32 matrix pipe, fp16 probabilities into P.V, fp16 output)
+    and the VALU kernel (impl 1) against fp64 SDPA on the same fp16 values"""
+    g = torch.Generator().manual_seed(N)
+    D = H * 64
+    qkv = torch.randn(B * N, 3 * D, generator=g).half()
+    qkv[5, D:D + 64] *= 6.0
+    q, k, v = (qkv.double()[:, i * D:(i + 1) * D].reshape(B, N, H, 64).transpose(1, 2) for i in range(3))
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B * N, D)
+    qd = torch.cat([qkv, torch.zeros(64, 3 * D, dtype=torch.float16)]).to(DEV)
+    out = torch.full((B * N, D), float("nan"), dtype=torch.float16, device=DEV)
+    L = s2v._lib
+    L.check(L.lib().s2v_op_attention(L.ptr(qd), None, L.ptr(out), B, H, N, L.DTYPE_F16, impl, L.stream_ptr()))
+    torch.cuda.synchronize()
+    got = out.float().cpu().double()
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() <= 2.5e-3 * max(1.0, ref.abs().max().item()), (got - ref).abs().max()
+
+
 # ------------------------------------------------------------------------------------------------ golden: tiny model
 def _tiny_model(s2v, variant, dt, g, force_simple=False):
     cfg = s2v.tiny(use_rope=variant == "rope")
@@ -113,11 +165,11 @@ def _tiny_model(s2v, variant, dt, g, force_simple=False):
 
 
 @pytest.mark.parametrize("variant", ["rope", "sincos"])
-@pytest.mark.parametrize("dt_name,simple", [("f32", False), ("bf16", False), ("bf16", True)])
+@pytest.mark.parametrize("dt_name,simple", [("f32", False), ("bf16", False), ("bf16", True), ("f16", False), ("f16", True)])
 def test_transformer_tiny_vs_reference_golden(s2v, variant, dt_name, simple):
     gw = load_golden("transformer_tiny_rope.npz")
     g = load_golden(f"transformer_tiny_{variant}.npz")
-    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    dt = DT[dt_name]
     m = _tiny_model(s2v, variant, dt, gw, simple)
     kw = {}
     if variant == "rope":
@@ -134,10 +186,10 @@ def test_transformer_tiny_vs_reference_golden(s2v, variant, dt_name, simple):
           ref_img_states=t(g["ref"], dt).to(DEV), timestep=t(g["timestep"], torch.int64)[:1], eval=True, **kw)
 
 
-@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+@pytest.mark.parametrize("dt_name", ["f32", "bf16", "f16"])
 def test_block_and_attnprocessor_seams_vs_reference_golden(s2v, dt_name):
     g = load_golden("transformer_tiny_rope.npz")
-    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    dt = DT[dt_name]
     m = _tiny_model(s2v, "rope", dt, g)
     cos, sin = t(g["rope_cos"]).to(DEV), t(g["rope_sin"]).to(DEV)
     rope, ref_rope = (cos[16:], sin[16:]), (cos[:16], sin[:16])
@@ -182,10 +234,10 @@ def test_block_and_attnprocessor_seams_vs_reference_golden(s2v, dt_name):
 
 # ------------------------------------------------------------------------------------------------ schedulers
 @pytest.mark.parametrize("kind", ["ddim", "dpm"])
-@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+@pytest.mark.parametrize("dt_name", ["f32", "bf16", "f16"])
 def test_scheduler_step_bit_exact_vs_reference_golden(s2v, kind, dt_name):
     g = load_golden(f"sched_{kind}_{dt_name}_10.npz")
-    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    dt = DT[dt_name]
     cls = s2v.CogVideoXDDIMScheduler if kind == "ddim" else s2v.CogVideoXDPMScheduler
     sch = cls(snr_shift_scale=float(g["snr"]))
     sch.set_timesteps(10)
@@ -293,11 +345,11 @@ def test_pipeline_frames_with_tiled_vae_vs_reference_golden(s2v):
 
 
 # ------------------------------------------------------------------------------------------------ on-box oracle
-@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+@pytest.mark.parametrize("dt_name", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("use_rope", [True, False])
 def test_medium_model_vs_oracle(s2v, dt_name, use_rope):
     """heads=3 (D=192: exercises the 128-tile padding), 2 layers, 3 frames of 16x24 latents, T=7: N = 7+96+288."""
-    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    dt = DT[dt_name]
     cfg = s2v.tiny(use_rope=use_rope, heads=3, layers=2, text_dim=128, temb=64)
     cfg.max_text_seq_length = 7
     sd = s2v.weights.synthetic_state_dict(cfg, seed=5, parity=True)
@@ -326,12 +378,12 @@ def test_medium_model_vs_oracle(s2v, dt_name, use_rope):
 
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs[0]
-@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+@pytest.mark.parametrize("dt_name", ["f32", "bf16", "f16"])
 def test_cogvideox_2b_width_c1_geometry_vs_oracle(s2v, dt_name):
     """BASELINE.json configs[0] geometry (CogVideoX-2B width D = 1920, non-RoPE, 9 frames 256x256 -> latents 3x32x32,
     N = 226 + 256 + 768 = 1250 tokens), 2 of the 30 layers, one full denoise step (CFG + DDIM) against the CPU oracle.
     D = 1920 is not a multiple of 256: exercises the padded-tile GEMM paths."""
-    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    dt = DT[dt_name]
     cfg = s2v.cogvideox_2b()
     cfg.num_layers = 2
     sd = s2v.weights.synthetic_state_dict(cfg, seed=11, parity=True)

@@ -8,6 +8,7 @@ from conftest import load_golden, weights_of
 from oracle import sched_ref, transformer_ref as tr, vae_ref
 
 TINY_CFG = dict(num_heads=2, num_layers=2, norm_eps=1e-5)
+DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
 
 
 def t(x, dt=torch.float32):
@@ -70,11 +71,11 @@ def test_alphas_and_timesteps():
 
 # ---------------------------------------------------------------------------------------------------- schedulers
 @pytest.mark.parametrize("kind", ["ddim", "dpm"])
-@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+@pytest.mark.parametrize("dt_name", ["f32", "bf16", "f16"])
 @pytest.mark.parametrize("n_steps", [10, 50])
 def test_scheduler_steps_bit_exact(kind, dt_name, n_steps):
     g = load_golden(f"sched_{kind}_{dt_name}_{n_steps}.npz")
-    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    dt = DT[dt_name]
     ac = sched_ref.alphas_cumprod(float(g["snr"]))
     ts = g["timesteps"]
     ids = list(g["step_ids"])
@@ -100,11 +101,11 @@ def _tiny_inputs(g, dt):
 
 
 @pytest.mark.parametrize("variant", ["rope", "sincos"])
-@pytest.mark.parametrize("dt_name,tol", [("f32", 2e-5), ("bf16", 0.0)])
+@pytest.mark.parametrize("dt_name,tol", [("f32", 2e-5), ("bf16", 0.0), ("f16", 0.0)])
 def test_transformer_tiny(variant, dt_name, tol):
     gw = load_golden("transformer_tiny_rope.npz")
     g = load_golden(f"transformer_tiny_{variant}.npz")
-    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    dt = DT[dt_name]
     sd = weights_of(gw, dt)
     lat, text, ref, ts = _tiny_inputs(g, dt)
     cfg = dict(TINY_CFG, use_rope=variant == "rope")
@@ -121,14 +122,17 @@ def test_transformer_tiny(variant, dt_name, tol):
         # op fusion order inside torch kernels is identical, so allow only a couple of bf16 ulps
         err = np.abs(y.float().numpy() - exp).max()
         assert err <= 0.05 * np.abs(exp).max(), err
+    elif dt_name == "f16":  # the same in fp16 (src/inference.py:191,209: the dtype of every non-5B checkpoint): 8 times finer ulps
+        err = np.abs(y.float().numpy() - exp).max()
+        assert err <= 0.00625 * np.abs(exp).max(), err
     else:
         np.testing.assert_allclose(y.numpy(), exp, atol=tol * max(1.0, np.abs(exp).max()), rtol=0)
 
 
-@pytest.mark.parametrize("dt_name", ["f32", "bf16"])
+@pytest.mark.parametrize("dt_name", ["f32", "bf16", "f16"])
 def test_block_and_attention_seams(dt_name):
     g = load_golden("transformer_tiny_rope.npz")
-    dt = torch.float32 if dt_name == "f32" else torch.bfloat16
+    dt = DT[dt_name]
     sd = weights_of(g, dt)
     cos, sin = t(g["rope_cos"]), t(g["rope_sin"])
     n, T = 16, 5
@@ -137,7 +141,7 @@ def test_block_and_attention_seams(dt_name):
     with torch.no_grad():
         oh, oe0, oe1 = tr.block_forward(sd, "transformer_blocks.1.", 2, h, e0, e1, temb, rope, ref_rope)
         ah, ae = tr.attn_forward(sd, "transformer_blocks.1.attn1.", 2, h, torch.cat([e0, e1], 1), rope, ref_rope, T, T + n)
-    tol = 2e-5 if dt_name == "f32" else 0.03
+    tol = {"f32": 2e-5, "bf16": 0.03, "f16": 0.00375}[dt_name]
     for got, key in ((oh, "blk_out_h"), (oe0, "blk_out_e0"), (oe1, "blk_out_e1"), (ah, "attn_out_h"), (ae, "attn_out_e")):
         exp = g[f"{key}_{dt_name}"]
         assert np.abs(got.float().numpy() - exp).max() <= tol * max(1.0, np.abs(exp).max()), key
