@@ -56,6 +56,7 @@ _SIGS = {
     "s2v_last_noise_pred": [_P, ctypes.POINTER(_P)],
     "s2v_profile_enable": [_P, _I32],
     "s2v_profile_read": [_P, ctypes.POINTER(_F), ctypes.POINTER(_I32), _I32],
+    "s2v_profile_read_clocks": [_P, ctypes.POINTER(_F), _I32],
     "s2v_op_linear": [_P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32, _P],
     "s2v_op_ff_fp8": [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _P],
     "s2v_op_mod_gemv": [_P, _P, _P, _P, _I32, _I32, _I64, _I32, _I32, _P],

@@ -96,11 +96,19 @@ struct s2v_ctx {
     hipGraphExec_t gexec = nullptr;
     GraphKey gkey{nullptr, nullptr, nullptr};
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py's live roofline figure)
+    // + shader-clock stamps (s_memtime / s_memrealtime pairs written by a one-lane kernel right before and right after every profiled launch)
+    long long* clk_buf = nullptr;                    // device: CLK_SLOTS x [memtime0, realtime0, memtime1, realtime1]
+    long long* clk_cur = nullptr;                    // the slot of the launch a ProfScope is open around (null outside the profile pass)
+    std::vector<std::pair<int, int>> clk_rec;         // (class, slot) of every stamped launch since the last s2v_profile_read_clocks
     bool prof_on = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev[8];
     size_t prof_used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
+static const int CLK_SLOTS = 8192;
+// shader clock of the profiled launches: ProfScope hands the launch a slot of clk_buf (s2v_ctx::clk_cur -> GemmArgs::clk / AttnArgs::clk); one
+// designated workgroup of the kernel stamps s_memtime / s_memrealtime at its entry and exit (common.h clk_stamp).  Kernels without stamps (or
+// launches whose designated workgroup left early) leave the slot zero and are skipped.
 enum { PK_QKV = 0, PK_ATTN = 1, PK_OUT = 2, PK_FF1 = 3, PK_FF2 = 4, PK_LNMOD = 5, PK_QKNORM = 6, PK_OTHER = 7, PK_NUM = 8 };
 
 struct ProfScope {
@@ -113,13 +121,20 @@ struct ProfScope {
             if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
             c->prof_ev[k].push_back({a, b});
         }
+        if (c->clk_buf && (int)c->clk_rec.size() < CLK_SLOTS) {
+            slot = (int)c->clk_rec.size();
+            c->clk_rec.push_back({k, slot});
+            c->clk_cur = c->clk_buf + 4 * slot;
+        }
         (void)hipEventRecord(c->prof_ev[k][c->prof_used[k]].first, st);
     }
     ~ProfScope() {
         if (!on) return;
         (void)hipEventRecord(c->prof_ev[k][c->prof_used[k]].second, st);
+        c->clk_cur = nullptr;
         c->prof_used[k]++;
     }
+    int slot = -1;
 };
 
 static const int RING = 256;
@@ -306,6 +321,7 @@ extern "C" void s2v_destroy(s2v_ctx* c) {
     if (c->ws) hipFree(c->ws);
     if (c->attn_queue) hipFree(c->attn_queue);
     if (c->attn_stats) hipFree(c->attn_stats);
+    if (c->clk_buf) hipFree(c->clk_buf);
     if (c->arena) hipFree(c->arena);
     if (c->lora_tmp) hipFree(c->lora_tmp);
     delete c;
@@ -540,6 +556,7 @@ extern "C" int s2v_set_pos_embed(s2v_ctx* c, const void* table_dev, s2v_stream s
 
 static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
     GemmArgs g = g0;
+    g.clk = c->clk_cur;
     // every GEMM operand of the transformer lives in a workspace buffer with >= 256 rows of slack behind it
     g.a_rows_padded = (int)(rup(g.M, 256));
     g.w_rows_padded = (int)(rup(g.N, 256));  // every weight of the arena is carved with its rows padded to 256
@@ -561,6 +578,7 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
         const int rem = (int)(g.M % 256);
         if (rem > 0 && tm > 1 && g.N >= 256 && (tm * tn + ncu - 1) / ncu > ((tm - 1) * tn + ncu - 1) / ncu) {
             GemmArgs gm = g, gt = g;
+            gt.clk = nullptr;  // the row tail runs beside the main launch on the side stream: one stamp per profiled launch
             gm.M = (int)((tm - 1) * 256);
             gt.m_begin = gm.M;
             // fork: the tail runs on the side stream beside the main launch (event fork/join, valid under stream capture)
@@ -584,6 +602,7 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
 // g0.mx_a_s set: A is already an MX image (g0.A bytes, block scales g0.mx_a_s) left by the producing GEMM's epilogue
 static int linear_fp8(s2v_ctx* c, const GemmArgs& g0, int epi, const char* wq, const float* wscale, hipStream_t st, bool prequant = false) {
     GemmArgs g = g0;
+    g.clk = c->clk_cur;
     if (g.mx_a_s) {
         g.lda = g.K; g.W = wq; g.ldw = g.K; g.a_scale = nullptr; g.w_scale = wscale;
         g.a_rows_padded = (int)rup(g.M, 256);
@@ -697,9 +716,11 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
         }
         a.q8 = c->q8; a.q8s = c->q8s; a.k8 = c->k8; a.k8s = c->k8s;
         ProfScope ps(c, PK_ATTN, st);
+        a.clk = c->clk_cur;
         return launch_attn_q4f(a, true, st);
     }
     ProfScope ps(c, PK_ATTN, st);
+    a.clk = c->clk_cur;
     if (c->mfma) S2V_TRY(launch_attn_bf16(a, st));
     else S2V_TRY(launch_attn_simple(a, c->dtype, st));
     return 0;
@@ -936,6 +957,25 @@ extern "C" int s2v_profile_enable(s2v_ctx* c, int32_t on) {
     S2V_REQUIRE(c, "null context");
     c->prof_on = on != 0;
     for (int k = 0; k < PK_NUM; ++k) c->prof_used[k] = 0;
+    c->clk_rec.clear();
+    if (on && !c->clk_buf) S2V_CHECK_HIP(hipMalloc((void**)&c->clk_buf, sizeof(long long) * 4 * CLK_SLOTS));
+    if (on) S2V_CHECK_HIP(hipMemset(c->clk_buf, 0, sizeof(long long) * 4 * CLK_SLOTS));
+    return 0;
+}
+// Average shader clock (MHz) under the launches of every class since s2v_profile_enable(1): sum of s_memtime spans / sum of s_memrealtime spans
+// (100 MHz ticks) of the stamp pairs around them; 0 for a class without stamped launches.  Synchronises; clears the records.
+extern "C" int s2v_profile_read_clocks(s2v_ctx* c, float* mhz_by_class, int32_t nclass) {
+    S2V_REQUIRE(c && mhz_by_class, "s2v_profile_read_clocks: null argument");
+    S2V_CHECK_HIP(hipDeviceSynchronize());
+    std::vector<long long> h((size_t)4 * c->clk_rec.size());
+    if (!h.empty()) S2V_CHECK_HIP(hipMemcpy(h.data(), c->clk_buf, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+    double cyc[PK_NUM] = {0}, ticks[PK_NUM] = {0};
+    for (auto& r : c->clk_rec) {
+        const long long* s = h.data() + 4 * r.second;
+        if (s[2] > s[0] && s[3] > s[1]) { cyc[r.first] += (double)(s[2] - s[0]); ticks[r.first] += (double)(s[3] - s[1]); }
+    }
+    for (int k = 0; k < nclass && k < PK_NUM; ++k) mhz_by_class[k] = ticks[k] > 0 ? (float)(cyc[k] / ticks[k] * 100.0) : 0.f;
+    c->clk_rec.clear();
     return 0;
 }
 // Synchronises, then returns total milliseconds and launch counts per class since the last read; resets.

@@ -286,10 +286,12 @@ template <int JB, bool F8 = false, bool P16 = false>
 __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_k(const AttnArgs a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 slots][K tile | VT tile]
     int first, cnt;
+    clk_stamp(a.clk, gridDim.x >> 1, 0);
     attn_xcd_range((int)gridDim.x, blockIdx.x & 7, first, cnt);
     unsigned slow = 0, tiles = 0;
     attn_qx_item<JB, F8, P16>(a, nqb, first + (int)(blockIdx.x >> 3), smem, slow, tiles);
     attn_report(a, slow, tiles);
+    clk_stamp(a.clk, gridDim.x >> 1, 1);
 }
 template <int JB, bool F8 = false, bool P16 = false>
 __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const AttnArgs a, int nqb, int total, int* __restrict__ queue) {
@@ -297,6 +299,7 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
     __shared__ int s_item;
     const int xcd = blockIdx.x & 7;
     unsigned slow = 0, tiles = 0;
+    clk_stamp(a.clk, 0, 0);  // persistent: workgroup 0 pulls work until the queues are empty
     for (;;) {
         if (threadIdx.x == 0) {
             int wg = -1;
@@ -317,6 +320,7 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
         attn_qx_item<JB, F8, P16>(a, nqb, wg, smem, slow, tiles);
     }
     attn_report(a, slow, tiles);
+    clk_stamp(a.clk, 0, 1);
     if (threadIdx.x == 0) {
         __threadfence();
         if (atomicAdd(&queue[8], 1) == (int)gridDim.x - 1) {

@@ -210,6 +210,17 @@ __device__ __forceinline__ void glds16_saddr_m0_imm(const char* sbase, unsigned 
                  : "memory", "m0", "scc");
 }
 
+// Shader-clock stamp of a launch (bench.py's roofline.shader_clock_mhz): ONE designated workgroup writes s_memtime (shader-clock cycles)
+// and s_memrealtime (constant 100 MHz) at its entry (which = 0) and exit (which = 1) into four int64 of a caller-owned slot -- both pairs
+// from the same CU (the counters are per CU / XCD, not chip-synchronous: stamps from neighbouring launches disagree by millions of cycles).
+// clk == nullptr (every launch but the profile pass): one scalar compare.
+__device__ __forceinline__ void clk_stamp(long long* clk, unsigned designated_wg, int which) {
+    if (clk != nullptr && blockIdx.x == designated_wg && threadIdx.x == 0) {
+        clk[2 * which] = (long long)__builtin_amdgcn_s_memtime();
+        clk[2 * which + 1] = (long long)__builtin_amdgcn_s_memrealtime();
+    }
+}
+
 // ---- host side ------------------------------------------------------------
 #ifdef S2V_HOST
 #include <string>

@@ -36,6 +36,7 @@ template <int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_g4(const GemmArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x [A 256 rows x 128 B | W 256 rows x 128 B]
     const int tid = threadIdx.x, lane = tid & 63;
+    clk_stamp(a.clk, gridDim.x >> 1, 0);
     G4_STAMP(0);
 #ifdef S2V_DIAG
     const long long g4_r0 = (long long)__builtin_amdgcn_s_memrealtime();
@@ -169,6 +170,7 @@ __global__ __launch_bounds__(256, 1) void gemm_g4(const GemmArgs a, int tiles_m,
         }
     }
 #endif
+    clk_stamp(a.clk, gridDim.x >> 1, 1);
 }
 
 template <int EPI>

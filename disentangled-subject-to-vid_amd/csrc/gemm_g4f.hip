@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256, 1) void gemm_g4f(const GemmArgs a, int tiles_m
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int A_STRIDE = G4F_A3_A_STRIDE, W_BASE = G4F_A3_W_BASE, W_STRIDE = G4F_A3_W_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63;
+    clk_stamp(a.clk, gridDim.x >> 1, 0);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 31, hi = lane >> 5;
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256, 1) void gemm_g4f(const GemmArgs a, int tiles_m
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = AC[2 * (2 * h + i) + (j >> 1)][(j & 1) * 16 + e];
         epilogue_wave<EPI, 4, true>(a, acc, m0 + wm * 128, n0 + wn * 128 + h * 64, patch, lane);
     }
+    clk_stamp(a.clk, gridDim.x >> 1, 1);
 }
 
 template <int EPI, bool MX>

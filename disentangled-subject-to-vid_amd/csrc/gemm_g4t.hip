@@ -28,6 +28,7 @@ template <int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_g4t(const GemmArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 operand stages 128 KiB | 4 patches x 4 KiB | tile records]
     const int tid = threadIdx.x, lane = tid & 63;
+    clk_stamp(a.clk, 0, 0);  // persistent: workgroup 0 lives for the whole launch
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int fr = lane & 31, hi = lane >> 5;
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256, 1) void gemm_g4t(const GemmArgs a, int tiles_m
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = AC[2 * (2 * h + i) + (j >> 1)][(j & 1) * 16 + e];
         epilogue_wave<EPI, 4>(a, acc, m0 + wm * 128, n0 + wn * 128 + h * 64, patch, lane);
     }
+    clk_stamp(a.clk, 0, 1);
 }
 
 template <int EPI>

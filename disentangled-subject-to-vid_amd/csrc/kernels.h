@@ -44,6 +44,7 @@ struct GemmArgs {
     int tile;           // plain bf16 GEMMs: 0 = the launcher's choice (256 x 256 tiles where the shape fits them); 1 = 256 x 128 tiles, 2 = 128 x 128
                         // (few-tile GEMMs: more, smaller workgroups fill the CUs that a single partial round of 256 x 256 tiles leaves idle)
     int ablate;         // diagnostics only
+    long long* clk;     // profile pass only: shader-clock stamp slot (common.h clk_stamp; gemm_g4 / g4t / g4f), else null
     int valu_only;      // fp32 only: stay on the VALU kernel gemm_simple_k (cfg.force_simple; the A/B reference of gemm_f32m, which returns the same bits)
     int a_rows_padded;  // plain mode: rows physically present behind A (>= M); the 256-row kernel needs ceil256(M)
     int m_begin;        // first output row of this launch (row-tail launches of a split GEMM; 128-row kernel only)
@@ -146,6 +147,7 @@ struct AttnArgs {
     // optional census of the deferred-maximum slow path (attn_q4 forms): 256 slots of two counters, slot = workgroup & 255:
     // [2 s] += slow paths taken, [2 s + 1] += (wave, KV tile) pairs run.  The engine reads it to decide whether fp16 P pays on the data at hand.
     unsigned long long* stats;
+    long long* clk;            // profile pass only: shader-clock stamp slot (common.h clk_stamp; the four-wave kernels), else null
     int valu_only;             // fp32 only: stay on attn_simple_k (cfg.force_simple) instead of the fp32-MFMA kernel attn_f32m_k
 };
 // sequences up to this length run attn_pp (launch_attn_bf16), longer ones attn_q4 (profiles/r03_attn_short_sequences.txt: attn_pp 9 % ahead at

@@ -169,6 +169,12 @@ S2V_API int s2v_last_noise_pred(s2v_ctx* ctx, void** dev_ptr);
  * device, returns total ms and launch counts per class since the previous read, and resets the counters. */
 S2V_API int s2v_profile_enable(s2v_ctx* ctx, int32_t on);
 S2V_API int s2v_profile_read(s2v_ctx* ctx, float* ms_by_class, int32_t* launches_by_class, int32_t nclass);
+/* Average SHADER CLOCK (MHz) under the profiled launches of every class since s2v_profile_enable(1): one designated workgroup of the
+ * profiled kernel (the four-wave GEMM / attention kernels; workgroup 0 of a persistent launch, the middle one otherwise) reads s_memtime
+ * (shader-clock cycles) and s_memrealtime (constant 100 MHz) at its entry and exit; clock = sum of cycle spans / sum of tick spans x 100;
+ * 0 for a class whose kernels carry no stamps.  The part is power-managed (1.1-1.9 GHz under the MFMA loops against the 2.4 GHz
+ * the datasheet peak assumes): this is the figure that relates a measured TFLOP/s to the matrix pipe's cycles.  Synchronises. */
+S2V_API int s2v_profile_read_clocks(s2v_ctx* ctx, float* mhz_by_class, int32_t nclass);
 /* Marks every tensor as loaded on a replica whose arena was filled by a broadcast of s2v_weight_arena. */
 S2V_API int s2v_mark_weights_loaded(s2v_ctx* ctx);
 
