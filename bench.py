@@ -428,7 +428,7 @@ def main(argv=None):
             total = int(ts.item())
         return el, total
 
-    # attn_p_format "auto" (the default): the engine runs its first denoise step eagerly, reads the attention kernel's slow-path census and settles
+    # attn_p_format "auto" (opt-in, S2V_ATTN_P=auto; the default is bf16 P): the engine runs its first denoise step eagerly, reads the attention kernel's slow-path census and settles
     # on fp16 or bf16 P for good (engine.py).  That step is taken here, before anything is timed, on a copy of the latents.
     if getattr(eng, "_attn_auto_pending", False):
         keep = latents.clone()

@@ -59,7 +59,11 @@ def build_library(force=False, verbose=True, diag=False):
     objdir = os.path.join(HERE, "build_diag" if diag else "build")
     LIB = DIAG_LIB if diag else globals()["LIB"]
     FLAGS = globals()["FLAGS"] + (["-DS2V_DIAG"] if diag else [])
-    gens = [("gen_attn_q4.py", "attn_q4_body.inc"), ("gen_gemm_g4.py", "gemm_g4_body.inc"), ("gen_gemm_g4t.py", "gemm_g4t_body_gelu.inc"), ("gen_gemm_g4f.py", "gemm_g4f_body_a3.inc")]  # generated asm (outputs are committed)
+    # generated asm (outputs are committed): generator -> EVERY file it writes (a missing one of them re-runs the generator)
+    gens = [("gen_attn_q4.py", ["attn_q4_body.inc", "attn_q4h_body.inc", "attn_q4f_body.inc", "attn_q4fh_body.inc", "attn_q8_body.inc", "attn_q4_regs.h"]),
+            ("gen_gemm_g4.py", ["gemm_g4_body.inc", "gemm_g4_sk_sum.inc", "gemm_g4_regs.h"]),
+            ("gen_gemm_g4t.py", ["gemm_g4t_body_gelu.inc", "gemm_g4t_body_bias.inc", "gemm_g4t_regs.h"]),
+            ("gen_gemm_g4f.py", ["gemm_g4f_body_a3.inc", "gemm_g4f_body_mx.inc", "gemm_g4f_regs.h"])]
     headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith((".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "s2v_hip.h"))
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
@@ -70,16 +74,17 @@ def build_library(force=False, verbose=True, diag=False):
             print(f"up to date (content hash {whole[:12]}): {LIB}", flush=True)
         return LIB
     os.makedirs(objdir, exist_ok=True)
-    for g, out in gens:
-        gp, op = os.path.join(CSRC, g), os.path.join(CSRC, out)
+    for g, outs in gens:
+        gp, ops = os.path.join(CSRC, g), [os.path.join(CSRC, o) for o in outs]
         stamp = os.path.join(objdir, g + ".stamp")
         d = _digest([gp])
-        if force or not os.path.exists(op) or (_read(stamp) != d and _stale(op, [gp])):
+        missing = [o for o in ops if not os.path.exists(o)]
+        if force or missing or (_read(stamp) != d and any(_stale(o, [gp]) for o in ops)):
             if verbose:
                 print(f"{sys.executable} {gp}", flush=True)
             subprocess.check_call([sys.executable, gp])
-        with open(stamp, "w") as f:
-            f.write(d)
+            with open(stamp, "w") as f:  # written only after a regeneration: a stamp next to outputs it did not produce proved nothing
+                f.write(d)
     headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith((".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "s2v_hip.h"))
     whole = _digest(srcs + headers + gen_srcs, FLAGS + [f"{k}:{v}" for k, v in sorted(EXTRA.items())])

@@ -28,11 +28,14 @@ class TransformerConfig:
     # computes) or "intended" (base weights for video / text modulation, LoRA only for the reference-image chunks,
     # normalization.py:468-478)
     lora_adaln_scope: str = "shipped"
-    # softmax probabilities / V^T of the four-wave attention kernel: "bf16"; "f16" (packed fp16 row sums, P.V on the fp16 MFMA, deferred
-    # maximum 2^14 instead of 2^64: include/s2v_hip.h, attn_p_format; ~4 % faster on smooth score distributions, slower on spiky ones); or
-    # "auto": fp16, checked against the kernel's slow-path census after the first denoise step and switched to bf16 for good when more than
-    # 0.5 % of the (wave, KV tile) pairs took the slow path (S2VEngine.denoise_step)
-    attn_p_format: str = "auto"
+    # softmax probabilities / V^T of the four-wave attention kernel: "bf16" (the default since round 5: what the reference's bf16 SDPA
+    # materialises, no range limit, the same arithmetic on every replica and every call); opt-in "f16" (packed fp16 row sums, P.V on the
+    # fp16 MFMA, deferred maximum 2^14 instead of 2^64: include/s2v_hip.h, attn_p_format; 2-4 % faster on smooth score distributions,
+    # slower on spiky ones, V saturated at +-65504); or opt-in "auto": fp16, checked against the kernel's slow-path census after the first
+    # denoise step of every geometry and switched to bf16 when more than 0.5 % of the (wave, KV tile) pairs took the slow path
+    # (S2VEngine.denoise_step).  "auto" decides per engine from its own data: replicas may settle differently -- use it for throughput
+    # runs, not where ranks must agree bit for bit.
+    attn_p_format: str = "bf16"
 
     @property
     def inner_dim(self):

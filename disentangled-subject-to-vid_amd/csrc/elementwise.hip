@@ -438,7 +438,10 @@ __global__ __launch_bounds__(256) void qk_norm_rope_k(const QkNormRopeArgs a) {
 // V [B*Ntok, .] (cols 2D + h*64 + d) -> V^T [B][H][64][ntok_pad]; inside every aligned 16-token group the
 // tokens are stored in the order [0-3, 8-11, 4-7, 12-15] (bits 2 and 3 of the token index swapped) which is the
 // k-slot order the PV MFMA of attn_bf16_k consumes.  64 tokens x 64 dims per block through LDS.
-// to_f16: the values are written as fp16 (attn_q4h: P.V on the fp16 MFMA; a bf16 value converts exactly unless it is below 2^-14 in magnitude).
+// to_f16: the values are written as fp16 (attn_q4h: P.V on the fp16 MFMA).  A bf16 value converts exactly when its magnitude lies in
+// [2^-14, 65504]; below, it rounds into the fp16 subnormals; ABOVE, it is SATURATED to +-65504 -- an infinity in V^T would turn the whole
+// head-dim column into NaN through 0 * inf in P.V, which no slow-path census would notice.  Values of that size do not occur
+// in V of this model (LayerNorm-ed inputs through one projection); bf16 P (attn_p_format 0, the default) has no such bound.
 __global__ __launch_bounds__(256) void v_transpose_k(const bf16_t* qkv, int ld_qkv, int B, int H, int Ntok, bf16_t* vt,
                                                      int ntok_pad, int to_f16) {
     __shared__ bf16_t tile[64][64 + 2];
@@ -464,7 +467,11 @@ __global__ __launch_bounds__(256) void v_transpose_k(const bf16_t* qkv, int ld_q
         const int tok = (pos & ~12) | ((pos & 4) << 1) | ((pos & 8) >> 1);  // token stored at this position
         if (n0 + tok < Ntok) {
             bf16_t v = tile[tok][d];
-            if (to_f16) v = __builtin_bit_cast(unsigned short, (_Float16)__uint_as_float((unsigned)v << 16));
+            if (to_f16) {
+                float f = __uint_as_float((unsigned)v << 16);
+                f = f != f ? f : fminf(fmaxf(f, -65504.0f), 65504.0f);  // NaN stays NaN (it is one in bf16 too); +-inf and > 65504 saturate
+                v = __builtin_bit_cast(unsigned short, (_Float16)f);
+            }
             dst[(size_t)d * ntok_pad + n0 + pos] = v;
         }
         else if (n0 + pos < ntok_pad) dst[(size_t)d * ntok_pad + n0 + pos] = 0;

@@ -98,7 +98,10 @@ extern "C" int s2v_rccl_comm_create(const void* id128, int32_t rank, int32_t wor
     memcpy(id.internal, id128, sizeof(id.internal));
     s2v_rccl_comm* c = new s2v_rccl_comm();
     c->rank = rank; c->world = world;
-    S2V_CHECK_HIP(hipGetDevice(&c->device));  // the communicator is bound to the CURRENT device (one process per GPU)
+    {  // the communicator is bound to the CURRENT device (one process per GPU)
+        const hipError_t e = hipGetDevice(&c->device);
+        if (e != hipSuccess) { delete c; return s2v_fail(__FILE__, __LINE__, hipGetErrorString(e), -2); }
+    }
     const int rc = g_rccl.comm_init_rank(&c->comm, world, id, rank);
     if (rc) { delete c; return nccl_fail("ncclCommInitRank", rc); }
     *out = c;

@@ -67,6 +67,7 @@ struct s2v_vae {
     };
     std::vector<WS> ws;
     int ws_active = 0, ws_req = 0;  // ws_req: sets asked for when ws was built (memory may have granted fewer)
+    int fault_geo_at = 0, fault_geo_seen = 0;  // S2V_VAE_FAULT_GEO_ALLOC (dmalloc)
     int64_t set_bytes = 0;          // bytes of one set at the current capacity
     std::vector<hipStream_t> side;  // one per workspace set beyond the first
     std::vector<hipEvent_t> ev_side;
@@ -90,6 +91,10 @@ static int wmalloc(s2v_vae* v, T** p, int64_t bytes) {  // weight carve-out (256
 template <typename T>
 static int dmalloc(s2v_vae* v, T** p, int64_t bytes, bool geo = false) {
     void* q = nullptr;
+    // fault injection for tests/test_gpu_vae.py: S2V_VAE_FAULT_GEO_ALLOC=n makes the n-th workspace ("geo") allocation of a
+    // prepare_tile_capacity call fail as an out-of-memory hipMalloc would; read per call (a getenv on an allocation path, never on a launch path)
+    if (geo && v->fault_geo_at > 0 && ++v->fault_geo_seen == v->fault_geo_at)
+        return s2v_fail(__FILE__, __LINE__, "dmalloc: injected allocation failure (S2V_VAE_FAULT_GEO_ALLOC)", -2);
     S2V_CHECK_HIP(hipMalloc(&q, (size_t)(bytes > 0 ? bytes : 16)));
     S2V_CHECK_HIP(hipMemset(q, 0, (size_t)(bytes > 0 ? bytes : 16)));
     (geo ? v->geo_allocs : v->allocs).push_back(q);
@@ -327,9 +332,8 @@ static void ws_save(s2v_vae* v, int k) {
     w.zq = v->zq; w.yt = v->yt; w.bt = v->bt; w.sums = v->sums; w.gn_part = v->gn_part;
     w.cur_h = v->cur_h; w.cur_w = v->cur_w;
 }
-static void ws_activate(s2v_vae* v, int k) {
-    if (v->ws.empty() || k == v->ws_active) return;
-    v->ws[v->ws_active].cur_h = v->cur_h; v->ws[v->ws_active].cur_w = v->cur_w;
+// set k -> the live members, unconditionally
+static void ws_load(s2v_vae* v, int k) {
     const s2v_vae::WS& w = v->ws[k];
     size_t i = 0;
     for_each_conv(v, [&](ConvL& c) { c.pad = w.pads[i++]; });
@@ -337,6 +341,11 @@ static void ws_activate(s2v_vae* v, int k) {
     v->zq = w.zq; v->yt = w.yt; v->bt = w.bt; v->sums = w.sums; v->gn_part = w.gn_part;
     v->cur_h = w.cur_h; v->cur_w = w.cur_w;
     v->ws_active = k;
+}
+static void ws_activate(s2v_vae* v, int k) {
+    if (v->ws.empty() || k == v->ws_active) return;
+    v->ws[v->ws_active].cur_h = v->cur_h; v->ws[v->ws_active].cur_w = v->cur_w;
+    ws_load(v, k);
 }
 
 // one workspace set (every operand / cache / scratch buffer of a decode at window th x tw) into the live members
@@ -411,6 +420,11 @@ static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws
     }
     std::vector<s2v_vae::WS> sets;
     int rc = 0;
+    v->fault_geo_seen = 0;
+    {
+        const char* e = getenv("S2V_VAE_FAULT_GEO_ALLOC");
+        v->fault_geo_at = e ? atoi(e) : 0;
+    }
     for (int k = 0; k < nws; ++k) {
         const size_t mark = v->geo_allocs.size();
         rc = alloc_workspace_set(v, th, tw, fz_max);
@@ -430,8 +444,9 @@ static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws
         return rc ? rc : vfail("prepare_tile_capacity: no workspace set could be allocated");
     }
     nws = (int)v->ws.size();
-    v->ws_active = nws - 1;  // the members hold the last set built
-    ws_activate(v, 0);
+    // The live members hold whatever alloc_workspace_set wrote LAST -- the last set built, or the freed pointers of a set that failed part-way
+    // (with one surviving set ws_activate(0) returned early and the next decode wrote through them).  Reload set 0 unconditionally.
+    ws_load(v, 0);
     while ((int)v->side.size() < nws - 1) {
         hipStream_t sst = nullptr; hipEvent_t e = nullptr;
         S2V_CHECK_HIP(hipStreamCreateWithFlags(&sst, hipStreamNonBlocking));

@@ -111,8 +111,15 @@ def broadcast_components(components, src=0, comm=None):
         flags = [c.arenas_loaded() if (me == src and hasattr(c, "arenas_loaded")) else None]
         dist.broadcast_object_list(flags, src=src)
         flags = flags[0]
-        if flags is not None and len(flags) != len(arenas):
-            raise RuntimeError(f"replica mismatch: sender has {len(flags)} weight arenas, this rank built {len(arenas)}")
+        # a replica built differently from the sender must stop EVERY rank before the first arena collective (a rank that raised alone left
+        # the others waiting in the broadcast): the verdict is agreed on collectively and raised everywhere
+        bad = flags is not None and len(flags) != len(arenas)
+        verdicts = [None] * dist.get_world_size()
+        dist.all_gather_object(verdicts, (me, len(arenas), bool(bad)))
+        if any(v[2] for v in verdicts):
+            detail = ", ".join(f"rank {r} built {n}" for r, n, b in verdicts if b)
+            raise RuntimeError(f"replica mismatch: sender has {len(flags) if flags is not None else '?'} weight arenas; {detail} "
+                               f"(this is rank {me}; every rank raises, no arena was sent)")
         for i, arena in enumerate(arenas):
             if flags is None or flags[i]:
                 total += comm.broadcast(arena, src) if comm is not None else broadcast_arena(arena, src)

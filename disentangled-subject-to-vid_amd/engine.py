@@ -42,8 +42,10 @@ class S2VEngine:
         if cfg.attn_p_format not in ("bf16", "f16", "auto"):
             raise _lib.S2VError(f"unknown attn_p_format {cfg.attn_p_format!r} ('bf16', 'f16' or 'auto')")
         c.attn_p_format = 0 if cfg.attn_p_format == "bf16" else 1
-        # "auto": start with fp16 P (faster on smooth score distributions) and look at the slow-path census after the first denoise step of a
-        # geometry; more than AUTO_SLOW_FRACTION of the (wave, KV tile) pairs on the slow path -> back to bf16 P (threshold 2^64) for good
+        # "auto" (opt-in): start with fp16 P (faster on smooth score distributions) and look at the slow-path census after the first denoise
+        # step of a geometry (re-armed by set_geometry); more than AUTO_SLOW_FRACTION of the (wave, KV tile) pairs on the slow path -> bf16 P
+        # (threshold 2^64).  The census read synchronises the device (s2v_attn_slow_stats): the deciding step runs eagerly, never inside a
+        # caller's stream capture; forward() / the seam objects take no census and keep the format they find.
         self.attn_p_format = "f16" if c.attn_p_format else "bf16"
         self._attn_auto_pending = cfg.attn_p_format == "auto"
         self.attn_slow_fraction = None
@@ -135,8 +137,13 @@ class S2VEngine:
             self.epoch[k] += 1
 
     def set_geometry(self, B, T, F, H, W):
+        new = self.geometry != (B, T, F, H, W)
         _lib.check(_lib.lib().s2v_set_geometry(self._h, B, T, F, H, W))
         self.geometry = (B, T, F, H, W)
+        if new and self.cfg.attn_p_format == "auto":  # a new geometry is new data to the kernel: decide again, starting from fp16
+            if self.attn_p_format != "f16":
+                self.set_attn_p_format("f16")
+            self._attn_auto_pending = True
         self._rope_key, self.have_rope = None, None
         self._bump("rope", "cond")
 

@@ -29,11 +29,19 @@ def inference(pipe, text_encoder, ref_image_uint8, prompt_ids, negative_prompt_i
               num_inference_steps=50, guidance_scale=6.0, use_dynamic_cfg=False, seed=None, latents=None, output_type="np",
               **pipe_kwargs):
     """Returns the frames [F, H, W, 3] float32 in [0, 1] (what the reference hands to export_to_video), or whatever
-    `output_type` selects ("latent" / "pt").  One generator drives the reference-image posterior draw and then the initial
-    latents, in that order, like the reference's single `torch.Generator` (video_generate.py:21-23,37)."""
+    `output_type` selects ("latent" / "pt").
+
+    Random draws.  The reference creates and seeds a `torch.Generator` (video_generate.py:21-23) and then never passes it anywhere:
+    `.latent_dist.sample()` (:37) and the pipeline call (:44-56) carry no generator, so BOTH draws -- the posterior sample of the reference
+    image first, the initial latents second (pipeline_cogvideox.py:320-344) -- come from the device's GLOBAL generator, seeded by
+    seed_everything (src/inference.py:28-35: torch.manual_seed + torch.cuda.manual_seed_all).  Here a private device generator seeded with
+    `seed` produces the same two draws in the same order (a freshly seeded Philox stream is the same stream whichever generator object
+    holds it: tests/test_gpu_end_to_end.py pins the equality) without touching the process-wide RNG state; seed=None draws from the global
+    device generator exactly as the reference does."""
     dev = pipe.transformer.device
-    generator = torch.Generator(device=dev)
+    generator = None
     if seed is not None:
+        generator = torch.Generator(device=dev)
         generator.manual_seed(seed)
     ref = reference_latents(pipe.vae, ref_image_uint8, generator)
     pe = prompt_embeddings(text_encoder, prompt_ids, pipe.transformer.dtype)

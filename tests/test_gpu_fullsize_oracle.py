@@ -21,6 +21,10 @@ DEV = "cuda:0"
 F_, H_, W_, T_ = 13, 60, 90, 226  # 49 frames 480 x 720
 
 
+F32_BAR = 1e-3            # set to 2 x measured below
+BF16_BARS = (2e-2, 6e-2)
+
+
 def rel_l2(a, b):
     a, b = a.double().flatten(), b.double().flatten()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
@@ -70,11 +74,12 @@ def test_one_block_full_tokens_vs_oracle(s2v, preset, dt_name, simple):
         y = y.float().cpu()
         assert torch.isfinite(y).all(), name
         err = (y - e).abs().max().item()
+        r = rel_l2(y, e)
+        print(f"MEASURED {preset} {dt_name} simple={simple} {name}: rel-l2 {r:.3e} max-abs {err:.3e} max|ref| {e.abs().max().item():.3f}")
         if dt_name == "f32":
-            assert err <= 1e-3, f"{preset} {name}: max-abs {err}"
+            assert err <= F32_BAR, f"{preset} {name}: max-abs {err}"
         else:
-            r = rel_l2(y, e)
-            assert r <= 2e-2 and err <= 6e-2 * e.abs().max().item(), f"{preset} {name}: rel-l2 {r}, max-abs {err}"
+            assert r <= BF16_BARS[0] and err <= BF16_BARS[1] * e.abs().max().item(), f"{preset} {name}: rel-l2 {r}, max-abs {err}"
     print(f"{preset} {dt_name}: oracle block took {t_cpu:.1f} s")
 
 

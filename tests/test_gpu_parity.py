@@ -2,10 +2,12 @@
 oracle (oracle/*.py) on the same seeded inputs and with the golden vectors captured from the reference.
 
 Tolerances (stated per BASELINE.json north_star: "<= 1e-3 max-abs latent deviation vs the CPU reference" is the fp32
-bar; bf16 is compared against the reference's own bf16 CPU run at the same rounding points):
-  fp32 path : max-abs <= 1e-3 (measured ~1e-5)
-  bf16 path : relative L2 <= 2e-2 and max-abs <= 6e-2 * max|ref|  (a few bf16 ulps after 2 blocks)
-  scheduler : bit-exact in both dtypes
+bar; bf16 / fp16 are compared against the reference's own bf16 / fp16 CPU run at the same rounding points).  The bars are 2 x the
+worst value measured over this file (BARS / F32_BAR below):
+  fp32 path : max-abs <= 4e-5 (measured <= 1.8e-5; north star 1e-3)
+  bf16 path : relative L2 <= 1.3e-2 and max-abs <= 2e-2 * max|ref|  (measured <= 6.4e-3 / 9.5e-3)
+  fp16 path : relative L2 <= 1.3e-3 and max-abs <= 2e-3 * max|ref|  (measured <= 6.4e-4 / 9.3e-4)
+  scheduler : bit-exact in all three dtypes
 """
 import ctypes
 
@@ -30,8 +32,12 @@ def rel_l2(a, b):
 
 
 DT = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}
-# fp16 (round 5; src/inference.py:191,209 runs every non-5B checkpoint in it): same rounding points as bf16, 8 x finer ulps -> bars / 8
-BARS = {"bf16": (2e-2, 6e-2), "f16": (2.5e-3, 7.5e-3)}
+# Bars = 2 x the worst value any test of this file measured in round 5 (47 comparisons, gpurun_out/measured_tols.txt: bf16 rel-L2 6.4e-3,
+# max-abs 9.5e-3 max|ref|; fp16 6.4e-4 / 9.3e-4; fp32 max-abs 1.8e-5) -- a kernel regression of 2 x fails.  Until round 4 the bf16 bars were
+# 2e-2 / 6e-2.  fp16 (src/inference.py:191,209 runs every non-5B checkpoint in it): the same rounding points as bf16, 8 x finer ulps.
+# fp32: the north-star bar is 1e-3 on the latents; the tests hold the kernels to 4e-5.
+BARS = {"bf16": (1.3e-2, 2e-2), "f16": (1.3e-3, 2e-3)}
+F32_BAR = 4e-5
 
 
 def assert_close(got, exp, dt_name, what=""):
@@ -39,10 +45,12 @@ def assert_close(got, exp, dt_name, what=""):
     assert torch.isfinite(got).all(), f"{what}: non-finite output"
     err = (got - exp).abs().max().item()
     if dt_name == "f32":
-        assert err <= 1e-3, f"{what}: max-abs {err}"
+        print(f"MEASURED {dt_name} {what}: max-abs {err:.3e}")
+        assert err <= F32_BAR, f"{what}: max-abs {err}"
     else:
         r = rel_l2(got, exp)
         br, ba = BARS[dt_name]
+        print(f"MEASURED {dt_name} {what}: rel-l2 {r:.3e} max-abs/max|ref| {err / exp.abs().max().item():.3e}")
         assert r <= br and err <= ba * exp.abs().max().item(), f"{what}: rel-l2 {r}, max-abs {err} (max|ref| {exp.abs().max().item()})"
 
 
@@ -658,8 +666,34 @@ def test_op_attention_fp16_p_moderate_jumps_and_tails_vs_fp64(s2v, spread):
     assert r4 <= max(1.5 * r0, 5e-3), (r0, r4)   # fp16 P (11 significant bits) is not less accurate than bf16 P (8)
 
 
+def test_attn_q4h_saturates_v_beyond_the_fp16_range(s2v):
+    """|V| > 65504 (finite in bf16) must not become an fp16 infinity in V^T -- 0 * inf in P.V would turn the head-dim column of EVERY
+    query into NaN.  The fp16 V^T pass saturates; the result stays finite, and equals the bf16-P kernel's wherever the huge key carries no weight."""
+    L = s2v._lib
+    B, H, N = 1, 2, 300
+    D = H * 64
+    g = torch.Generator().manual_seed(9)
+    qkv = torch.randn(B * N, 3 * D, generator=g)
+    qkv[7, 2 * D + 5] = 1.0e6          # one V element far beyond 65504 ...
+    qkv[7, D:D + 64] = -50.0 * qkv[0:1, 0:64].sign()   # ... on a key that query 0 all but ignores
+    qkv = qkv.bfloat16()
+    qd = torch.cat([qkv, torch.zeros(64, 3 * D, dtype=torch.bfloat16)]).to(DEV)
+    outs = {}
+    for impl in (0, 4):
+        out = torch.full((B * N, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+        vt = torch.zeros(B * H * 64 * 320, dtype=torch.bfloat16, device=DEV)
+        L.check(L.lib().s2v_op_attention(L.ptr(qd), L.ptr(vt), L.ptr(out), B, H, N, L.DTYPE_BF16, impl, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs[impl] = out.float().cpu()
+    assert torch.isfinite(outs[4]).all() and torch.isfinite(outs[0]).all()
+    # columns other than the poisoned one are untouched by the saturation
+    mask = torch.ones(D, dtype=torch.bool)
+    mask[5] = False
+    assert (outs[4][:, mask] - outs[0][:, mask]).abs().max() <= 2e-2 * max(1.0, outs[0][:, mask].abs().max().item())
+
+
 def test_attn_p_format_auto_settles_on_the_census_of_the_first_step(s2v):
-    """attn_p_format = "auto" (the default): an engine starts with fp16 P where the four-wave attention kernel runs (> 4608 tokens), its first
+    """attn_p_format = "auto" (opt-in; the default is "bf16"): an engine starts with fp16 P where the four-wave attention kernel runs (> 4608 tokens), its first
     denoise step runs eagerly and reads the kernel's slow-path census (s2v_attn_slow_stats); smooth scores keep fp16, spiky ones (q / k LayerNorm
     weights x 12: score jumps far beyond the 2^14 threshold in most tiles) switch the engine to bf16 P for good.  Either way graph replay == eager
     afterwards, and the result stays within the bf16 tolerance of a bf16-P engine on the same weights."""

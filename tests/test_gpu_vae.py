@@ -192,3 +192,40 @@ def test_tiled_decode_workspace_byte_cap_and_regrowth(s2v, monkeypatch):
     assert np.abs(y_un[..., ::3, ::3].numpy() - g["dec_untiled_s3"]).max() <= 1e-3
     capped.enable_tiling()
     assert torch.equal(capped.decode_latents(lat), y_free)
+
+
+def test_tiled_decode_survives_a_workspace_set_that_fails_part_way(s2v, monkeypatch):
+    """set 1 of the tiled decode's workspace fails after a few allocations (injected: S2V_VAE_FAULT_GEO_ALLOC counts the workspace
+    allocations of one prepare_tile_capacity call).  The partial set is freed, ONE set survives -- and the live members must be reloaded from
+    it, not left on the freed pointers: the decode runs and is bit-identical to the unconstrained one."""
+    g = load_golden("vae_tiny.npz")
+    lat = t(g["latents"]).to(DEV)
+    free = make_vae(s2v, TINY, torch.float32, weights_of(g))
+    free.enable_tiling()
+    y_free = free.decode_latents(lat)
+    n_free, _ = free.workspace_info()
+    assert n_free >= 2
+    # count the allocations of one set: fail at the first allocation -> no capacity at all, loudly
+    monkeypatch.setenv("S2V_VAE_FAULT_GEO_ALLOC", "1")
+    none = make_vae(s2v, TINY, torch.float32, weights_of(g))
+    none.enable_tiling()
+    with pytest.raises(s2v._lib.S2VError):
+        none.decode_latents(lat)
+    # fail a few allocations INTO the second set (a set of this tiny decoder has > 20 buffers; 200 is past the first set for every level count)
+    hit = False
+    for n in (30, 40, 60, 90):
+        monkeypatch.setenv("S2V_VAE_FAULT_GEO_ALLOC", str(n))
+        v = make_vae(s2v, TINY, torch.float32, weights_of(g))
+        v.enable_tiling()
+        try:
+            y = v.decode_latents(lat)
+        except s2v._lib.S2VError:
+            continue  # n fell inside the FIRST set: nothing to survive on
+        torch.cuda.synchronize()
+        sets = v.workspace_info()[0]
+        assert torch.equal(y, y_free), n
+        if sets < n_free:
+            hit = True
+            assert torch.equal(v.decode_latents(lat), y_free)  # and again on the surviving sets
+    monkeypatch.delenv("S2V_VAE_FAULT_GEO_ALLOC")
+    assert hit, "no injected failure landed inside a later set"
