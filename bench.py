@@ -264,7 +264,10 @@ def spawn_ranks(n, argv):
     import subprocess
 
     one_dev = os.environ.get("S2V_BENCH_ONE_DEVICE", "0") == "1"
+    selftest = "--dist-selftest" in argv   # CPU / gloo exercise of the launcher, the watchdog and the broadcast: no GPU involved
     ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if selftest:
+        ndev = n
     if ndev < 1:
         raise SystemExit(f"bench.py --gpus {n}: no GPU visible (torch.cuda.is_available() is False); nothing is printed for GPUs that do not exist")
     if ndev < n and not one_dev:
@@ -276,10 +279,19 @@ def spawn_ranks(n, argv):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(n), LOCAL_RANK=str(r), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), S2V_BENCH_SPAWNED="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+        env.setdefault("NCCL_DEBUG", "WARN")               # RCCL states why a collective failed instead of just failing
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    return supervise(procs)
+
+
+def supervise(procs, grace_s=5.0):
+    """wait for the rank processes; the FIRST non-zero exit (a crash, a kill -- negative codes --, the watchdog's EXIT_WATCHDOG, a
+    non-finite output) ends the others: they would sit in a collective waiting for the dead rank.  terminate, then kill after grace_s
+    (exact PIDs).  Returns that first non-zero code, 0 when every rank exited 0."""
     rc = 0
     try:
         pending = list(procs)
+        deadline = None
         while pending:
             for p in list(pending):
                 code = p.poll()
@@ -288,14 +300,56 @@ def spawn_ranks(n, argv):
                 pending.remove(p)
                 if code != 0 and rc == 0:
                     rc = code
-                    for q in pending:  # a dead rank leaves the others in a collective: end them (exact PIDs)
+                    sys.stderr.write(f"[bench] rank process {p.pid} exited with code {code}; ending the other {len(pending)} rank(s)\n")
+                    for q in pending:
                         q.terminate()
+                    deadline = time.time() + grace_s
+            if deadline is not None and time.time() > deadline:
+                for q in pending:
+                    q.kill()
+                deadline = None
             time.sleep(0.05)
     finally:
         for p in procs:
             if p.poll() is None:
                 p.kill()
     return rc
+
+
+def dist_selftest(args):
+    """`bench.py --gpus N --dist-selftest` (no GPU): N gloo ranks rendezvous exactly as the benchmark's ranks do and replicate a synthetic CPU
+    "arena" with dist.broadcast_arena under the same Watchdog; S2V_SELFTEST_KILL_RANK=r makes rank r die in the middle of the broadcast,
+    S2V_SELFTEST_STALL_RANK=r makes it stop taking part (the peers' watchdog has to fire).  Prints one JSON line on success."""
+    s2v = importlib.import_module("disentangled-subject-to-vid_amd")
+    import torch.distributed as dist
+
+    rank, world, _ = s2v.dist.init_from_env("gloo")
+    nbytes = int(os.environ.get("S2V_SELFTEST_BYTES", str(64 << 20)))
+    arena = torch.full((nbytes,), 7 if rank == 0 else 0, dtype=torch.uint8)
+    kill = int(os.environ.get("S2V_SELFTEST_KILL_RANK", "-1"))
+    stall = int(os.environ.get("S2V_SELFTEST_STALL_RANK", "-1"))
+    done = [0]
+    with s2v.dist.Watchdog("weight broadcast (self-test)", float(os.environ.get("S2V_BENCH_BCAST_TIMEOUT_S", "300")), lambda: f"{done[0]} of {nbytes} bytes enqueued"):
+        if world > 1:
+            dist.barrier()
+        chunk = max(nbytes // 8, 1)
+        flat = arena.view(-1)
+        for off in range(0, nbytes, chunk):
+            if rank == kill and off >= nbytes // 2:
+                os._exit(9)                       # a rank that dies mid-broadcast
+            if rank == stall and off >= nbytes // 2:
+                time.sleep(3600)                   # a rank that stops taking part
+            dist.broadcast(flat[off:off + chunk], src=0)
+            done[0] = off + chunk
+        if world > 1:
+            dist.barrier()
+    ok = bool((arena == 7).all().item())
+    if rank == 0:
+        print(json.dumps({"dist_selftest": "ok" if ok else "corrupt", "ranks": world, "bytes": nbytes}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(5)
 
 
 def main(argv=None):
@@ -312,6 +366,8 @@ def main(argv=None):
     ap.add_argument("--no-vae", action="store_true", help="skip the one-off VAE decode timing")
     ap.add_argument("--native-bcast", action="store_true", help="N > 1: replicate the weights with the library's own RCCL communicator "
                     "(s2v_bcast_weights) instead of torch.distributed.broadcast")
+    ap.add_argument("--dist-selftest", action="store_true", help="no GPU: exercise the rank launcher, the rendezvous, the chunked broadcast and its "
+                    "watchdog with gloo on CPU tensors (tests/test_dist_gloo.py)")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -323,6 +379,8 @@ def main(argv=None):
         return
     if env_world is not None and int(env_world) != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={env_world}: the line reports the ranks that exist, not the flag")
+    if args.dist_selftest:
+        return dist_selftest(args)
 
     s2v = importlib.import_module("disentangled-subject-to-vid_amd")
     # S2V_BENCH_BACKEND=gloo + S2V_BENCH_ONE_DEVICE=1: a functional check of the multi-rank path on a one-GPU box (all ranks on cuda:0);
@@ -369,23 +427,35 @@ def main(argv=None):
     if rank == 0:
         n_lora = load_synthetic(s2v, eng, cfg, 1234)
     bcast_s = bcast_bytes = None
+    native_bcast = args.native_bcast
+    bcast_note = None
     if world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()  # also the communicator's first collective: its lazy set-up stays out of the broadcast time
-        tb = time.time()
-        if args.native_bcast:
-            comm = s2v.dist.RcclComm()
+        if native_bcast:  # the decision is taken by ALL ranks together: one rank without librccl sends everybody to torch.distributed
+            ok, bad = s2v.dist.rccl_available_everywhere()
+            if not ok:
+                native_bcast = False
+                bcast_note = f"--native-bcast requested but librccl could not be bound on rank(s) {[r for r, _ in bad]}: {bad[0][1]}; fell back to torch.distributed.broadcast"
+                if rank == 0:
+                    sys.stderr.write(f"[bench] WARNING: {bcast_note}\n")
+        done = [0]
+        with s2v.dist.Watchdog("weight broadcast rank 0 -> all", float(os.environ.get("S2V_BENCH_BCAST_TIMEOUT_S", "300")),
+                               lambda: f"{done[0]} bytes enqueued on {dev}, backend {dist.get_backend()}, native={native_bcast}"):
+            torch.cuda.synchronize()
+            dist.barrier()  # also the communicator's first collective: its lazy set-up stays out of the broadcast time
+            tb = time.time()
+            if native_bcast:
+                comm = s2v.dist.RcclComm()
+                torch.cuda.synchronize()
+                dist.barrier()
+                tb = time.time()  # the communicator's set-up stays out of the broadcast time, as on the other path
+                comm.broadcast_weights(eng, 0)  # receivers are marked loaded by the library
+                bcast_bytes = eng.weight_arena().numel()
+            else:
+                bcast_bytes = s2v.dist.broadcast_arena(eng.weight_arena(), 0, progress=done)
             torch.cuda.synchronize()
             dist.barrier()
-            tb = time.time()  # the communicator's set-up stays out of the broadcast time, as on the other path
-            comm.broadcast_weights(eng, 0)  # receivers are marked loaded by the library
-            bcast_bytes = eng.weight_arena().numel()
-        else:
-            bcast_bytes = s2v.dist.broadcast_arena(eng.weight_arena(), 0)
-        torch.cuda.synchronize()
-        dist.barrier()
         bcast_s = time.time() - tb
-        if rank != 0 and not args.native_bcast:
+        if rank != 0 and not native_bcast:
             eng.mark_weights_loaded()
     t_load = time.time() - t_load
 
@@ -447,6 +517,14 @@ def main(argv=None):
         dist.all_gather_object(ranks_info, me)
     n_devices = len({(r["device"], r["uuid"]) for r in ranks_info})
     finite = all(r["outputs_finite"] for r in ranks_info)
+    if not finite:  # a number measured on NaN latents is not a measurement: no metric line, every rank exits non-zero (they all hold ranks_info)
+        badr = [r["rank"] for r in ranks_info if not r["outputs_finite"]]
+        if rank == 0:
+            sys.stderr.write(f"[bench] FAILED: non-finite latents after the timed steps on rank(s) {badr}; ranks: {json.dumps(ranks_info)}\n")
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        raise SystemExit(4)
     # ---- the other launch mode, timed the same way (beside the metric, not in it)
     other_steps = min(args.steps, 5)
     other = None if args.single_mode else timed(not bool(args.graph), other_steps, 1)[0]
@@ -691,7 +769,8 @@ def main(argv=None):
                        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 2),
                        "per_gpu_steps_per_s": round(total_steps / elapsed / n_devices, 4),
                        "lora_merged": f"rank-128 synthetic adapter on {n_lora} weights (alpha / r = 0.5)" if n_lora else None, "weight_load_s": round(t_load, 2), "weight_broadcast_s": None if bcast_s is None else round(bcast_s, 3),
-                       "weight_broadcast_via": None if bcast_s is None else ("s2v_bcast_weights (the library's own RCCL communicator)" if args.native_bcast else f"torch.distributed.broadcast ({dist.get_backend()}), 256-MiB chunks"),
+                       "weight_broadcast_via": None if bcast_s is None else ("s2v_bcast_weights (the library's own RCCL communicator)" if native_bcast else f"torch.distributed.broadcast ({dist.get_backend()}), 256-MiB chunks"),
+                       "weight_broadcast_note": bcast_note,
                        "weight_broadcast_gb": None if not bcast_bytes else round(bcast_bytes / 1e9, 3),
                        "weight_broadcast_gb_per_s": None if not bcast_s else round(bcast_bytes / bcast_s / 1e9, 1),
                        "xgmi_link_bound_gb_per_s": 153.0 if world > 1 else None,

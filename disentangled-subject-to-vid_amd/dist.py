@@ -9,8 +9,61 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
-    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*)."""
+EXIT_WATCHDOG = 86  # a rank whose collective exceeded its deadline ends itself with this code
+
+
+class Watchdog:
+    """Deadline around a collective phase (the weight broadcast is the only one this path has).  A rank that is still inside the phase after
+    `timeout_s` seconds writes what it was doing to stderr (rank, phase, progress callback, the RCCL / torch.distributed settings in force,
+    every thread's Python stack) and ends the PROCESS with EXIT_WATCHDOG -- a peer that died or never arrived otherwise leaves the others
+    blocked in the collective until an outer limit kills the job without a word.  The launcher (bench.py spawn_ranks, torchrun) sees the
+    non-zero exit and takes the remaining ranks down.  No signals: a timer thread and os._exit, so it works under any launcher."""
+
+    def __init__(self, what, timeout_s, progress=None):
+        self.what, self.timeout_s, self.progress = what, float(timeout_s), progress
+        self._timer = None
+
+    def _fire(self):
+        import faulthandler
+        import sys
+
+        rank = os.environ.get("RANK", "0")
+        prog = ""
+        try:
+            prog = f"; progress: {self.progress()}" if self.progress else ""
+        except Exception as e:  # the progress callback must never mask the report
+            prog = f"; progress callback failed: {e!r}"
+        env = {k: os.environ.get(k) for k in ("WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NCCL_DEBUG", "NCCL_DEBUG_SUBSYS",
+                                              "TORCH_NCCL_ASYNC_ERROR_HANDLING", "HSA_ENABLE_IPC_MODE_LEGACY", "NCCL_SOCKET_IFNAME")}
+        sys.stderr.write(f"[s2v watchdog] rank {rank}: '{self.what}' still running after {self.timeout_s:.0f} s{prog}\n"
+                         f"[s2v watchdog] rank {rank}: environment {env}; RCCL prints its own diagnosis under NCCL_DEBUG=WARN (bench.py sets it for N > 1)\n"
+                         f"[s2v watchdog] rank {rank}: exiting with code {EXIT_WATCHDOG}; Python stacks follow\n")
+        sys.stderr.flush()
+        try:
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        finally:
+            os._exit(EXIT_WATCHDOG)
+
+    def __enter__(self):
+        import threading
+
+        if self.timeout_s > 0:
+            self._timer = threading.Timer(self.timeout_s, self._fire)
+            self._timer.daemon = True
+            self._timer.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._timer is not None:
+            self._timer.cancel()
+        return False
+
+
+def init_from_env(backend=None, timeout_s=None):
+    """torchrun-style rendezvous (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).  timeout_s (default S2V_DIST_TIMEOUT_S or 600): the process
+    group's own collective timeout -- torch's NCCL watchdog then aborts a collective whose peer vanished instead of waiting for ever."""
+    import datetime
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -21,8 +74,30 @@ def init_from_env(backend=None):
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("S2V_DIST_TIMEOUT_S", "600"))
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
     return rank, world, local
+
+
+def rccl_available_everywhere():
+    """True when EVERY rank can bind librccl through the library (s2v_rccl_unique_id dlopens it): the native-broadcast decision has to be
+    the same on all ranks, or some would enter ncclBroadcast and the others torch.distributed.broadcast."""
+    import ctypes
+
+    from . import _lib
+
+    ok, why = 1, ""
+    try:
+        _lib.check(_lib.lib().s2v_rccl_unique_id(ctypes.create_string_buffer(128)))
+    except Exception as e:
+        ok, why = 0, str(e)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        verdicts = [None] * dist.get_world_size()
+        dist.all_gather_object(verdicts, (dist.get_rank(), ok, why))
+        bad = [(r, w) for r, o, w in verdicts if not o]
+        return (not bad), bad
+    return bool(ok), ([] if ok else [(0, why)])
 
 
 def shard_prompts(num_prompts, rank, world):
@@ -30,16 +105,18 @@ def shard_prompts(num_prompts, rank, world):
     return [p for p in range(num_prompts) if p % world == rank]
 
 
-def broadcast_arena(arena, src=0, chunk_bytes=256 << 20):
+def broadcast_arena(arena, src=0, chunk_bytes=256 << 20, progress=None):
     """replicate a finalized model: `arena` is the uint8 view of the packed weights (S2VEngine.weight_arena()).
     Chunked so that each collective is large enough to saturate an xGMI link (>= 64 MB) without needing a second
-    full-size staging buffer."""
+    full-size staging buffer.  progress: an optional one-element list that receives the bytes enqueued so far (a Watchdog reports it)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return 0
     flat = arena.view(-1)
     n = flat.numel()
     for off in range(0, n, chunk_bytes):
         dist.broadcast(flat[off : min(off + chunk_bytes, n)], src=src)
+        if progress is not None:
+            progress[0] = min(off + chunk_bytes, n)
     return n
 
 

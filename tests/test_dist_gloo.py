@@ -2,6 +2,7 @@
 gather.  The engine is a stand-in whose "denoise" is the CPU oracle's scheduler arithmetic on the broadcast weights,
 so a rank that did not receive the arena produces different latents."""
 import importlib
+import json
 import os
 import socket
 import sys
@@ -219,3 +220,112 @@ def test_receiver_marks_only_the_halves_the_sender_had_loaded():
     for rank, moved, loaded, enc_loaded, d0, esum in got:
         assert moved == 70001, "only the decoder arena travels"
         assert loaded and not enc_loaded and d0 == 7 and esum == 0
+
+
+# ---- bench.py under rank failures: what the first real 8-GPU run would hit -----------------------------------
+def _bench(args, env_extra, timeout):
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(env_extra)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    return r, time.time() - t0
+
+
+def test_bench_dist_selftest_two_gloo_ranks_replicate_the_arena():
+    r, _ = _bench(["--gpus", "2", "--dist-selftest"], {"S2V_SELFTEST_BYTES": str(8 << 20)}, 180)
+    assert r.returncode == 0, r.stderr[-1500:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"dist_selftest": "ok", "ranks": 2, "bytes": 8 << 20}
+
+
+def test_bench_exits_nonzero_when_a_rank_dies_mid_broadcast():
+    """rank 1 is killed half-way through the chunked broadcast: the launcher sees its exit code, ends rank 0 (which sits in the next
+    collective) and bench.py returns non-zero long before any collective timeout"""
+    r, dt = _bench(["--gpus", "2", "--dist-selftest"], {"S2V_SELFTEST_KILL_RANK": "1", "S2V_SELFTEST_BYTES": str(8 << 20),
+                                                        "S2V_BENCH_BCAST_TIMEOUT_S": "120"}, 180)
+    assert r.returncode == 9, (r.returncode, r.stderr[-1500:])
+    assert "exited with code 9; ending the other 1 rank(s)" in r.stderr
+    assert "dist_selftest" not in r.stdout and dt < 60, dt
+
+
+def test_bench_watchdog_ends_a_broadcast_whose_peer_stopped_taking_part():
+    """rank 1 stays alive but never enters the remaining collectives: nothing dies by itself, so the per-rank Watchdog has to fire -- it
+    reports the phase, the progress and the environment, and exits with dist.EXIT_WATCHDOG"""
+    r, dt = _bench(["--gpus", "2", "--dist-selftest"], {"S2V_SELFTEST_STALL_RANK": "1", "S2V_SELFTEST_BYTES": str(8 << 20),
+                                                        "S2V_BENCH_BCAST_TIMEOUT_S": "6"}, 180)
+    assert r.returncode == 86, (r.returncode, r.stderr[-1500:])
+    assert "[s2v watchdog] rank" in r.stderr and "still running after 6 s" in r.stderr and "bytes enqueued" in r.stderr
+    assert dt < 60, dt
+
+
+def test_supervise_ends_the_survivors_of_a_failed_rank():
+    import subprocess
+    import sys
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    try:
+        import importlib
+
+        bench = importlib.import_module("bench")
+    finally:
+        sys.path.remove(root)
+    procs = [subprocess.Popen([sys.executable, "-c", "import time; time.sleep(600)"]),
+             subprocess.Popen([sys.executable, "-c", "import sys, time; time.sleep(0.5); sys.exit(4)"])]   # 4 = bench.py's "non-finite outputs" exit
+    t0 = time.time()
+    assert bench.supervise(procs, grace_s=2.0) == 4
+    assert time.time() - t0 < 30 and all(p.poll() is not None for p in procs)
+
+
+def test_replica_mismatch_is_raised_on_every_rank():
+    """a rank whose component has a different number of weight arenas than the sender's used to raise alone and leave the others in the
+    arena broadcast; the verdict is now agreed on collectively -- both ranks raise, nothing is sent"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_mismatch_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    assert got == {0: "ok", 1: "ok"}, got
+
+
+def _mismatch_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        s2v = importlib.import_module("disentangled-subject-to-vid_amd")
+        s2v.dist.init_from_env("gloo")
+
+        class Comp:
+            def __init__(self, n):
+                self.a = [torch.zeros(1024, dtype=torch.uint8) for _ in range(n)]
+
+            def weight_arenas(self):
+                return self.a
+
+            def arenas_loaded(self):
+                return [True] * len(self.a)
+
+            def mark_weights_loaded(self, loaded=None):
+                raise AssertionError("nothing must be marked loaded after a mismatch")
+
+        comp = Comp(2 if rank == 0 else 3)
+        try:
+            s2v.dist.broadcast_components([comp], 0)
+            q.put((rank, "no error"))
+        except RuntimeError as e:
+            q.put((rank, "ok" if "replica mismatch" in str(e) and "every rank raises" in str(e) else f"wrong error: {e}"))
+        dist.destroy_process_group()
+    except Exception as e:  # pragma: no cover
+        q.put((rank, f"exception: {e!r}"))
