@@ -300,6 +300,15 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
     const int xcd = blockIdx.x & 7;
     unsigned slow = 0, tiles = 0;
     clk_stamp(a.clk, 0, 0);  // persistent: workgroup 0 pulls work until the queues are empty
+    // Start stagger (round 5, configs[4] locality experiment): the 32 workgroups of an XCD walk consecutive q-blocks of one head, i.e. the SAME
+    // K / V^T tiles, and every item costs the same -- started together they request each tile within the latency of its first miss.  With
+    // a.stagger > 0 slot s of the XCD starts s * stagger * 64 cycles late, once per launch: a convoy in which the leader misses in L2 and the
+    // followers find the tile there.  0 = start together (the default; profiles/r05_attn_stagger.txt for what it measured).
+    if (a.stagger > 0) {
+        const int slot = (int)(blockIdx.x >> 3);
+        for (int i = 0; i < slot * a.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
+        if ((slot * a.stagger) & 63) __builtin_amdgcn_s_sleep(1);
+    }
     for (;;) {
         if (threadIdx.x == 0) {
             int wg = -1;

@@ -268,7 +268,8 @@ struct T5Slot { char* dst; int64_t rows, cols; bool loaded; };
 struct s2v_t5 {
     s2v_t5_config cfg;
     int dtype = 0, esz = 0, inner = 0;
-    bool mfma = false, finalized = false, have_bias = false;
+    bool mfma = false, h16 = false, finalized = false, have_bias = false;
+    int* inf_flag = nullptr;  // fp16 only: "any inf in the residual stream" of the clamp transformers applies after every sub-layer
     std::vector<T5Layer> layers;
     char *shared = nullptr, *final_ln = nullptr, *rel_table = nullptr;
     std::unordered_map<std::string, T5Slot> slots;
@@ -313,7 +314,7 @@ extern "C" void s2v_t5_destroy(s2v_t5* t) {
 
 extern "C" int s2v_t5_create(const s2v_t5_config* cfg, s2v_t5** out) {
     S2V_REQUIRE(cfg && out, "s2v_t5_create: null argument");
-    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_t5_create: unsupported dtype");
+    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16 || cfg->dtype == S2V_DTYPE_F16, "s2v_t5_create: unsupported dtype");
     S2V_REQUIRE(cfg->d_kv == 64, "s2v_t5_create: head dimension must be 64 (T5 v1.1 XXL)");
     S2V_REQUIRE(cfg->num_layers > 0 && cfg->num_heads > 0 && cfg->d_model > 0 && cfg->d_ff > 0 && cfg->vocab_size > 0,
                 "s2v_t5_create: bad model size");
@@ -321,9 +322,10 @@ extern "C" int s2v_t5_create(const s2v_t5_config* cfg, s2v_t5** out) {
     s2v_t5* t = new s2v_t5();
     t->cfg = *cfg;
     t->dtype = cfg->dtype;
-    t->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
+    t->esz = cfg->dtype == S2V_DTYPE_F32 ? 4 : 2;
     t->inner = cfg->num_heads * cfg->d_kv;
     t->mfma = cfg->dtype == S2V_DTYPE_BF16 && !cfg->force_simple && cfg->d_model % 64 == 0 && cfg->d_ff % 64 == 0;
+    t->h16 = cfg->dtype == S2V_DTYPE_F16 && !cfg->force_simple;  // fp16 (src/inference.py:209,214: text_encoder.to(device, dtype=weight_dtype)): linears on gemm_f16
     auto build = [&]() -> int {
         const int64_t d = cfg->d_model, in = t->inner, F = cfg->d_ff, E = t->esz;
         int r = t5_alloc(t, &t->shared, (int64_t)cfg->vocab_size * d * E);
@@ -400,7 +402,7 @@ extern "C" int s2v_t5_mark_weights_loaded(s2v_t5* t) {
 extern "C" int s2v_t5_load_weight(s2v_t5* t, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
                                   int32_t src_dtype, s2v_stream stream) {
     S2V_REQUIRE(t && name && dev_ptr && shape, "s2v_t5_load_weight: null argument");
-    S2V_REQUIRE(src_dtype == S2V_DTYPE_F32 || src_dtype == S2V_DTYPE_BF16, "s2v_t5_load_weight: unsupported dtype");
+    S2V_REQUIRE(src_dtype == S2V_DTYPE_F32 || src_dtype == S2V_DTYPE_BF16 || src_dtype == S2V_DTYPE_F16, "s2v_t5_load_weight: unsupported dtype");
     std::string key = name;
     if (key == "encoder.embed_tokens.weight") key = "shared.weight";  // tied
     auto it = t->slots.find(key);
@@ -484,8 +486,45 @@ static int t5_linear(s2v_t5* t, const void* A, int lda, const void* W, void* C, 
         }
         return launch_gemm_bf16(g, epi, st);
     }
+    if (t->h16 && gemm_f16_ok(g, epi)) return launch_gemm_f16(g, epi, st);
     g.valu_only = t->cfg.force_simple;
     return launch_gemm_simple(g, epi, t->dtype, st);
+}
+
+// transformers' T5Block (modeling_t5.py, T5Block.forward) after the self-attention and after the feed-forward sub-layer, fp16 only:
+//   clamp_value = finfo(fp16).max - 1000 if isinf(hidden_states).any() else finfo(fp16).max;  hidden_states = clamp(hidden_states, -c, c)
+// -- an overflowed residual stream (T5-XXL's feed-forward outputs exceed 65504) is pulled back to 64504 (stored as fp16: 64512) instead
+// of carrying inf through the remaining blocks.  Two launches: the "any inf" flag over the whole tensor, then the clamp.
+__global__ void t5_inf_flag_k(const f16_t* x, int64_t n, int* flag) {
+    bool inf = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = (float)x[i];
+        inf = inf || v == INFINITY || v == -INFINITY;
+    }
+    if (__any(inf) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+__global__ void t5_clamp_k(f16_t* x, int64_t n, const int* flag) {
+    const float c = *flag ? 65504.0f - 1000.0f : 65504.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = (float)x[i];
+        x[i] = (f16_t)fminf(fmaxf(v, -c), c);  // NaN: fmaxf / fminf return the other operand -- torch.clamp keeps NaN; keep it
+        if (v != v) x[i] = (f16_t)v;
+    }
+}
+static int t5_fp16_clamp(s2v_t5* t, int64_t n, hipStream_t st) {
+    if (t->dtype != S2V_DTYPE_F16) return 0;
+    if (!t->inf_flag) {
+        void* q = nullptr;
+        S2V_CHECK_HIP(hipMalloc(&q, 256));
+        t->allocs.push_back(q);  // freed by s2v_t5_destroy
+        t->inf_flag = (int*)q;
+    }
+    S2V_CHECK_HIP(hipMemsetAsync(t->inf_flag, 0, sizeof(int), st));
+    const unsigned grid = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(t5_inf_flag_k, dim3(grid), dim3(256), 0, st, (const f16_t*)t->X, n, t->inf_flag);
+    hipLaunchKernelGGL(t5_clamp_k, dim3(grid), dim3(256), 0, st, (f16_t*)t->X, n, t->inf_flag);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 static inline unsigned grid1d(int64_t n) { return (unsigned)std::min<int64_t>((n + 255) / 256, 65535 * 16); }
@@ -497,51 +536,38 @@ extern "C" int s2v_t5_encode(s2v_t5* t, const int64_t* input_ids_dev, int32_t B,
     hipStream_t st = (hipStream_t)stream;
     const int M = B * T, d = t->cfg.d_model, in = t->inner, F = t->cfg.d_ff, H = t->cfg.num_heads;
     const float eps = t->cfg.layer_norm_epsilon;
-    const bool bf = t->dtype == S2V_DTYPE_BF16;
-#define T5_LAUNCH(kern, grid, block, ...)                                                          \
-    do {                                                                                           \
-        if (bf) hipLaunchKernelGGL(kern<bf16_t>, grid, block, 0, st, __VA_ARGS__);                 \
-        else hipLaunchKernelGGL(kern<float>, grid, block, 0, st, __VA_ARGS__);                     \
-        S2V_CHECK_HIP(hipGetLastError());                                                          \
-    } while (0)
-    if (bf) hipLaunchKernelGGL(t5_embed_k<bf16_t>, dim3(grid1d((int64_t)M * d)), dim3(256), 0, st, (const long long*)input_ids_dev,
-                               (const bf16_t*)t->shared, M, d, t->cfg.vocab_size, (bf16_t*)t->X);
-    else hipLaunchKernelGGL(t5_embed_k<float>, dim3(grid1d((int64_t)M * d)), dim3(256), 0, st, (const long long*)input_ids_dev,
-                            (const float*)t->shared, M, d, t->cfg.vocab_size, (float*)t->X);
+    const int dtype = t->dtype, Tn = T;  // Tn: the token count inside S2V_DT_DISPATCH bodies, where `T` names the storage type
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(t5_embed_k<T>, dim3(grid1d((int64_t)M * d)), dim3(256), 0, st, (const long long*)input_ids_dev,
+                                              (const T*)t->shared, M, d, t->cfg.vocab_size, (T*)t->X))
     S2V_CHECK_HIP(hipGetLastError());
     const dim3 rows((M + 3) / 4), attn_grid((T + 3) / 4, H, B);
     for (auto& L : t->layers) {
-        if (bf) {
-            hipLaunchKernelGGL(t5_rms_norm_k<bf16_t>, rows, dim3(256), 0, st, (const bf16_t*)t->X, (const bf16_t*)L.ln0, M, d, eps, (bf16_t*)t->Xn);
-        } else {
-            hipLaunchKernelGGL(t5_rms_norm_k<float>, rows, dim3(256), 0, st, (const float*)t->X, (const float*)L.ln0, M, d, eps, (float*)t->Xn);
-        }
+        S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(t5_rms_norm_k<T>, rows, dim3(256), 0, st, (const T*)t->X, (const T*)L.ln0, M, d, eps, (T*)t->Xn))
         S2V_CHECK_HIP(hipGetLastError());
         S2V_TRY(t5_linear(t, t->Xn, d, L.wqkv, t->QKV, M, 3 * in, d, EPI_BIAS, nullptr, st));
         if (T <= T5_ATTN_MAX_T) {
             const dim3 g((T + T5_ATTN_QB - 1) / T5_ATTN_QB, H, B);
             const size_t lds = ((size_t)T * 129 + 256 * T5_ATTN_WAVES) * sizeof(float);
-            const void* fn = bf ? (const void*)t5_attn_lds_k<bf16_t> : (const void*)t5_attn_lds_k<float>;
-            S2V_TRY(ensure_lds_attr(fn, (int)lds));
-            if (bf) hipLaunchKernelGGL(t5_attn_lds_k<bf16_t>, g, dim3(64 * T5_ATTN_WAVES), lds, st, (const bf16_t*)t->QKV, (const bf16_t*)t->bias, B, H, T, (bf16_t*)t->AO);
-            else hipLaunchKernelGGL(t5_attn_lds_k<float>, g, dim3(64 * T5_ATTN_WAVES), lds, st, (const float*)t->QKV, (const float*)t->bias, B, H, T, (float*)t->AO);
-        } else if (bf) hipLaunchKernelGGL(t5_attn_k<bf16_t>, attn_grid, dim3(256), 0, st, (const bf16_t*)t->QKV, (const bf16_t*)t->bias, B, H, T, (bf16_t*)t->AO);
-        else hipLaunchKernelGGL(t5_attn_k<float>, attn_grid, dim3(256), 0, st, (const float*)t->QKV, (const float*)t->bias, B, H, T, (float*)t->AO);
+            S2V_DT_DISPATCH(dtype, {
+                S2V_TRY(ensure_lds_attr((const void*)t5_attn_lds_k<T>, (int)lds));
+                hipLaunchKernelGGL(t5_attn_lds_k<T>, g, dim3(64 * T5_ATTN_WAVES), lds, st, (const T*)t->QKV, (const T*)t->bias, B, H, Tn, (T*)t->AO);
+            })
+        } else {
+            S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(t5_attn_k<T>, attn_grid, dim3(256), 0, st, (const T*)t->QKV, (const T*)t->bias, B, H, Tn, (T*)t->AO))
+        }
         S2V_CHECK_HIP(hipGetLastError());
         S2V_TRY(t5_linear(t, t->AO, in, L.wo, t->X, M, d, in, EPI_BIAS_ADD, t->X, st));  // x = x + o(...)
-        if (bf) hipLaunchKernelGGL(t5_rms_norm_k<bf16_t>, rows, dim3(256), 0, st, (const bf16_t*)t->X, (const bf16_t*)L.ln1, M, d, eps, (bf16_t*)t->Xn);
-        else hipLaunchKernelGGL(t5_rms_norm_k<float>, rows, dim3(256), 0, st, (const float*)t->X, (const float*)L.ln1, M, d, eps, (float*)t->Xn);
+        S2V_TRY(t5_fp16_clamp(t, (int64_t)M * d, st));
+        S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(t5_rms_norm_k<T>, rows, dim3(256), 0, st, (const T*)t->X, (const T*)L.ln1, M, d, eps, (T*)t->Xn))
         S2V_CHECK_HIP(hipGetLastError());
         S2V_TRY(t5_linear(t, t->Xn, d, L.wi, t->FF, M, 2 * F, d, EPI_BIAS, nullptr, st));
-        if (bf) hipLaunchKernelGGL(t5_gate_k<bf16_t>, dim3(grid1d((int64_t)M * F)), dim3(256), 0, st, (const bf16_t*)t->FF, M, F, (bf16_t*)t->G);
-        else hipLaunchKernelGGL(t5_gate_k<float>, dim3(grid1d((int64_t)M * F)), dim3(256), 0, st, (const float*)t->FF, M, F, (float*)t->G);
+        S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(t5_gate_k<T>, dim3(grid1d((int64_t)M * F)), dim3(256), 0, st, (const T*)t->FF, M, F, (T*)t->G))
         S2V_CHECK_HIP(hipGetLastError());
         S2V_TRY(t5_linear(t, t->G, F, L.wff, t->X, M, d, F, EPI_BIAS_ADD, t->X, st));  // x = x + wo(g * u)
+        S2V_TRY(t5_fp16_clamp(t, (int64_t)M * d, st));
     }
-    if (bf) hipLaunchKernelGGL(t5_rms_norm_k<bf16_t>, rows, dim3(256), 0, st, (const bf16_t*)t->X, (const bf16_t*)t->final_ln, M, d, eps, (bf16_t*)out);
-    else hipLaunchKernelGGL(t5_rms_norm_k<float>, rows, dim3(256), 0, st, (const float*)t->X, (const float*)t->final_ln, M, d, eps, (float*)out);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(t5_rms_norm_k<T>, rows, dim3(256), 0, st, (const T*)t->X, (const T*)t->final_ln, M, d, eps, (T*)out))
     S2V_CHECK_HIP(hipGetLastError());
-#undef T5_LAUNCH
     return 0;
 }
 

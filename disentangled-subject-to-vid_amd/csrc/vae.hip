@@ -37,6 +37,12 @@ template <> struct V16<bf16_t> {
     }
 };
 
+template <> struct V16<f16_t> {  // the fp16 model dtype (round 5): the same 16-byte vector of eight values
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void ld(const f16_t* p, float* v) { Vec16<f16_t>::ld(p, v); }
+    static __device__ __forceinline__ void st(f16_t* p, const float* v) { Vec16<f16_t>::st(p, v); }
+};
+
 static inline unsigned grid_for(int64_t n, int cap = 1 << 20) {
     int64_t g = (n + 255) / 256;
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -59,12 +65,8 @@ __global__ void latent_to_zq_k(const T* lat, int F, int C, int h, int w, float i
 int launch_latent_to_zq(const void* lat, int F, int C, int h, int w, float inv_sf, void* out, int y0, int x0, int th,
                         int tw, int dtype, hipStream_t st) {
     const int64_t total = (int64_t)F * th * tw * C;
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(latent_to_zq_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)lat, F, C, h, w,
-                           inv_sf, (bf16_t*)out, y0, x0, th, tw);
-    else
-        hipLaunchKernelGGL(latent_to_zq_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)lat, F, C, h, w,
-                           inv_sf, (float*)out, y0, x0, th, tw);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(latent_to_zq_k<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)lat, F, C, h, w,
+                       inv_sf, (T*)out, y0, x0, th, tw))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -83,12 +85,8 @@ __global__ void dense_to_padded_k(const T* in, int F, int H, int W, int C, T* ou
 }
 int launch_dense_to_padded(const void* in, int F, int H, int W, int C, void* out, int f_off, int dtype, hipStream_t st) {
     const int64_t total = (int64_t)F * H * W * C;
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(dense_to_padded_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)in, F, H, W,
-                           C, (bf16_t*)out, f_off);
-    else
-        hipLaunchKernelGGL(dense_to_padded_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)in, F, H, W, C,
-                           (float*)out, f_off);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(dense_to_padded_k<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)in, F, H, W,
+                       C, (T*)out, f_off))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -135,12 +133,8 @@ __global__ void image_to_padded_k(const T* img, int C, int F, int H, int W, int 
 int launch_image_to_padded(const void* img, int C, int F, int H, int W, int y0, int x0, int th, int tw, void* out, int f_off,
                            int dtype, hipStream_t st) {
     const int64_t total = (int64_t)F * th * tw * C;
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(image_to_padded_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)img, C, F, H, W, y0, x0,
-                           th, tw, (bf16_t*)out, f_off);
-    else
-        hipLaunchKernelGGL(image_to_padded_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)img, C, F, H, W, y0, x0, th,
-                           tw, (float*)out, f_off);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(image_to_padded_k<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)img, C, F, H, W, y0, x0,
+                       th, tw, (T*)out, f_off))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -157,10 +151,7 @@ __global__ void gaussian_sample_k(const T* mom, const T* noise, int64_t n, T* ou
     }
 }
 int launch_gaussian_sample(const void* mom, const void* noise, int64_t n, void* out, int dtype, hipStream_t st) {
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(gaussian_sample_k<bf16_t>, dim3(grid_for(n)), dim3(256), 0, st, (const bf16_t*)mom, (const bf16_t*)noise, n, (bf16_t*)out);
-    else
-        hipLaunchKernelGGL(gaussian_sample_k<float>, dim3(grid_for(n)), dim3(256), 0, st, (const float*)mom, (const float*)noise, n, (float*)out);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(gaussian_sample_k<T>, dim3(grid_for(n)), dim3(256), 0, st, (const T*)mom, (const T*)noise, n, (T*)out))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -227,14 +218,11 @@ int64_t gn_stats_scratch_bytes(int64_t P, int G) {
     return ((P + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK) * G * 2 * (int64_t)sizeof(double);
 }
 int launch_gn_stats(const void* x, int64_t P, int C, int G, double* sums, double* part, int dtype, hipStream_t st) {
-    const int VN = dtype == S2V_BF16 ? 8 : 4;
+    const int VN = dtype == S2V_F32 ? 4 : 8;
     S2V_REQUIRE(C % VN == 0 && C <= 1024 && 256 % (C / VN) == 0 && C % G == 0, "gn_stats: unsupported channel count");
     S2V_REQUIRE(part != nullptr, "gn_stats: scratch missing");
     const unsigned grid = (unsigned)((P + GN_PIX_PER_BLOCK - 1) / GN_PIX_PER_BLOCK);
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(gn_stats_k<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, P, C, G, part);
-    else
-        hipLaunchKernelGGL(gn_stats_k<float>, dim3(grid), dim3(256), 0, st, (const float*)x, P, C, G, part);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(gn_stats_k<T>, dim3(grid), dim3(256), 0, st, (const T*)x, P, C, G, part))
     hipLaunchKernelGGL(gn_finalize_k, dim3(2 * G), dim3(256), 0, st, part, (int)grid, G, sums);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
@@ -398,7 +386,7 @@ __global__ void snorm_tables_k(const SNormArgs a) {
 }
 
 int launch_snorm_apply(const SNormArgs& a, int dtype, hipStream_t st) {
-    const int VN = dtype == S2V_BF16 ? 8 : 4;
+    const int VN = dtype == S2V_F32 ? 4 : 8;
     S2V_REQUIRE(a.C % VN == 0 && a.C % a.G == 0, "snorm_apply: unsupported channel count");
     const bool plain = a.yt == nullptr;  // nn.GroupNorm (+ SiLU) without the zq modulation: the encoder's resnets / norm_out
     S2V_REQUIRE(plain || a.bt, "snorm_apply: table scratch missing");
@@ -408,15 +396,11 @@ int launch_snorm_apply(const SNormArgs& a, int dtype, hipStream_t st) {
     const int vpp = a.C / VN;
     const bool rows_form = vpp <= 256 && 256 % vpp == 0 && (int64_t)a.W * a.wz < (1ll << 31);
     const unsigned row_grid = (unsigned)std::min<int64_t>((int64_t)a.F * a.H, 16384);
-    if (dtype == S2V_BF16) {
-        if (!plain) hipLaunchKernelGGL(snorm_tables_k<bf16_t>, dim3(grid_for(tl)), dim3(256), 0, st, a);
-        if (rows_form) hipLaunchKernelGGL(snorm_apply_rows_k<bf16_t>, dim3(row_grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(snorm_apply_k<bf16_t>, dim3(grid_for(total, 16384)), dim3(256), shmem, st, a);
-    } else {
-        if (!plain) hipLaunchKernelGGL(snorm_tables_k<float>, dim3(grid_for(tl)), dim3(256), 0, st, a);
-        if (rows_form) hipLaunchKernelGGL(snorm_apply_rows_k<float>, dim3(row_grid), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(snorm_apply_k<float>, dim3(grid_for(total, 16384)), dim3(256), shmem, st, a);
-    }
+    S2V_DT_DISPATCH(dtype, {
+        if (!plain) hipLaunchKernelGGL(snorm_tables_k<T>, dim3(grid_for(tl)), dim3(256), 0, st, a);
+        if (rows_form) hipLaunchKernelGGL(snorm_apply_rows_k<T>, dim3(row_grid), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(snorm_apply_k<T>, dim3(grid_for(total, 16384)), dim3(256), shmem, st, a);
+    })
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -448,15 +432,11 @@ __global__ void upsample_k(const T* x, int F, int H, int W, int C, int compress_
     }
 }
 int launch_upsample(const void* x, int F, int H, int W, int C, int compress_time, void* out, int dtype, hipStream_t st) {
-    const int VN = dtype == S2V_BF16 ? 8 : 4;
+    const int VN = dtype == S2V_F32 ? 4 : 8;
     S2V_REQUIRE(C % VN == 0, "upsample: unsupported channel count");
     const int64_t total = (int64_t)upsample_out_frames(F, compress_time) * 4 * H * W * (C / VN);
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(upsample_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)x, F, H, W, C,
-                           compress_time, (bf16_t*)out);
-    else
-        hipLaunchKernelGGL(upsample_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)x, F, H, W, C,
-                           compress_time, (float*)out);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(upsample_k<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)x, F, H, W, C,
+                       compress_time, (T*)out))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -476,12 +456,8 @@ __global__ void to_ncfhw_k(const T* y, int F, int H, int W, int Co, T* out, int 
 }
 int launch_to_ncfhw(const void* y, int F, int H, int W, int Co, void* out, int Ftot, int f0, int dtype, hipStream_t st) {
     const int64_t total = (int64_t)F * H * W * Co;
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(to_ncfhw_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)y, F, H, W, Co,
-                           (bf16_t*)out, Ftot, f0);
-    else
-        hipLaunchKernelGGL(to_ncfhw_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)y, F, H, W, Co,
-                           (float*)out, Ftot, f0);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(to_ncfhw_k<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)y, F, H, W, Co,
+                       (T*)out, Ftot, f0))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -511,12 +487,8 @@ int launch_blend(const void* a, int Ha, int Wa, void* b, int Hb, int Wb, int CF,
                  hipStream_t st) {
     const int64_t total = (int64_t)CF * (vertical ? E : (Ha < Hb ? Ha : Hb)) * (vertical ? (Wa < Wb ? Wa : Wb) : E);
     if (total <= 0) return 0;
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(blend_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)a, Ha, Wa, (bf16_t*)b,
-                           Hb, Wb, CF, E, vertical);
-    else
-        hipLaunchKernelGGL(blend_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)a, Ha, Wa, (float*)b, Hb,
-                           Wb, CF, E, vertical);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(blend_k<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)a, Ha, Wa, (T*)b,
+                       Hb, Wb, CF, E, vertical))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -536,12 +508,8 @@ int launch_paste(const void* tile, int Ht, int Wt, int ch, int cw, void* out, in
                  int dtype, hipStream_t st) {
     const int64_t total = (int64_t)CF * ch * cw;
     if (total <= 0) return 0;
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(paste_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)tile, Ht, Wt, ch, cw,
-                           (bf16_t*)out, H, W, y0, x0, CF);
-    else
-        hipLaunchKernelGGL(paste_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)tile, Ht, Wt, ch, cw,
-                           (float*)out, H, W, y0, x0, CF);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(paste_k<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)tile, Ht, Wt, ch, cw,
+                       (T*)out, H, W, y0, x0, CF))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -575,19 +543,13 @@ __global__ void postprocess_u8_k(const T* v, int C, int F, int H, int W, unsigne
 }
 int launch_postprocess_u8(const void* v, int C, int F, int H, int W, unsigned char* out, int dtype, hipStream_t st) {
     const int64_t total = (int64_t)C * F * H * W;
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(postprocess_u8_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)v, C, F, H, W, out);
-    else
-        hipLaunchKernelGGL(postprocess_u8_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)v, C, F, H, W, out);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(postprocess_u8_k<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)v, C, F, H, W, out))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
 int launch_postprocess(const void* v, int C, int F, int H, int W, float* out, int dtype, hipStream_t st) {
     const int64_t total = (int64_t)C * F * H * W;
-    if (dtype == S2V_BF16)
-        hipLaunchKernelGGL(postprocess_k<bf16_t>, dim3(grid_for(total)), dim3(256), 0, st, (const bf16_t*)v, C, F, H, W, out);
-    else
-        hipLaunchKernelGGL(postprocess_k<float>, dim3(grid_for(total)), dim3(256), 0, st, (const float*)v, C, F, H, W, out);
+    S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(postprocess_k<T>, dim3(grid_for(total)), dim3(256), 0, st, (const T*)v, C, F, H, W, out))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -607,10 +569,18 @@ int launch_conv_w_repack(const void* src, int sdt, int cout, int cin, int taps, 
     const int64_t total = (int64_t)cout * cin * taps;
     dim3 g(grid_for(total));
 #define RP(TS, TD) hipLaunchKernelGGL((conv_w_repack_k<TS, TD>), g, dim3(256), 0, st, (const TS*)src, cout, cin, taps, (TD*)dst)
-    if (sdt == S2V_F32 && ddt == S2V_F32) RP(float, float);
-    else if (sdt == S2V_F32 && ddt == S2V_BF16) RP(float, bf16_t);
-    else if (sdt == S2V_BF16 && ddt == S2V_F32) RP(bf16_t, float);
-    else RP(bf16_t, bf16_t);
+    S2V_REQUIRE(sdt >= 0 && sdt <= 2 && ddt >= 0 && ddt <= 2, "conv_w_repack: unknown dtype");
+    switch (sdt * 3 + ddt) {
+        case S2V_F32 * 3 + S2V_F32: RP(float, float); break;
+        case S2V_F32 * 3 + S2V_BF16: RP(float, bf16_t); break;
+        case S2V_F32 * 3 + S2V_F16: RP(float, f16_t); break;
+        case S2V_BF16 * 3 + S2V_F32: RP(bf16_t, float); break;
+        case S2V_BF16 * 3 + S2V_BF16: RP(bf16_t, bf16_t); break;
+        case S2V_BF16 * 3 + S2V_F16: RP(bf16_t, f16_t); break;
+        case S2V_F16 * 3 + S2V_F32: RP(f16_t, float); break;
+        case S2V_F16 * 3 + S2V_BF16: RP(f16_t, bf16_t); break;
+        default: RP(f16_t, f16_t); break;
+    }
 #undef RP
     S2V_CHECK_HIP(hipGetLastError());
     return 0;

@@ -36,7 +36,7 @@ struct VSlot { int kind; void* dst; int64_t d0, d1, taps; bool loaded; };  // ki
 struct s2v_vae {
     s2v_vae_config cfg;
     int dtype = 0, esz = 0, G = 0, Cz = 0;
-    bool mfma = false, finalized = false;
+    bool mfma = false, h16 = false, finalized = false;
     bool encoder = false;  // plan built by s2v_vae_enc_create (reference-image encode) instead of the decoder
     ConvL conv_in, conv_out;
     SNormL norm_out;
@@ -209,15 +209,16 @@ static int build_decoder(s2v_vae* v) {
 
 extern "C" int s2v_vae_create(const s2v_vae_config* cfg, s2v_vae** out) {
     S2V_REQUIRE(cfg && out, "s2v_vae_create: null argument");
-    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_vae_create: unsupported dtype");
+    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16 || cfg->dtype == S2V_DTYPE_F16, "s2v_vae_create: unsupported dtype");
     S2V_REQUIRE(cfg->num_blocks >= 1 && cfg->num_blocks <= 6, "s2v_vae_create: 1..6 blocks");
     s2v_vae* v = new s2v_vae();
     v->cfg = *cfg;
     v->dtype = cfg->dtype;
-    v->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
+    v->esz = cfg->dtype == S2V_DTYPE_F32 ? 4 : 2;
     v->G = cfg->norm_num_groups;
     v->Cz = cfg->latent_channels;
     v->mfma = cfg->dtype == S2V_DTYPE_BF16 && !cfg->force_simple;
+    v->h16 = cfg->dtype == S2V_DTYPE_F16 && !cfg->force_simple;  // fp16: convolutions / shortcuts with cin % 64 == 0 on v_mfma_f32_32x32x16_f16 (gemm_f16)
     const int r = build_two_pass(v, build_decoder);
     if (r) { s2v_vae_destroy(v); return r; }
     *out = v;
@@ -250,7 +251,7 @@ __global__ void to_f32_transposed_k(const TS* src, int rows, int cols, float* ds
 extern "C" int s2v_vae_load_weight(s2v_vae* v, const char* name, const void* dev_ptr, const int64_t* shape, int32_t ndim,
                                    int32_t src_dtype, s2v_stream stream) {
     S2V_REQUIRE(v && name && dev_ptr && shape, "s2v_vae_load_weight: null argument");
-    S2V_REQUIRE(src_dtype == S2V_DTYPE_F32 || src_dtype == S2V_DTYPE_BF16, "s2v_vae_load_weight: unsupported dtype");
+    S2V_REQUIRE(src_dtype == S2V_DTYPE_F32 || src_dtype == S2V_DTYPE_BF16 || src_dtype == S2V_DTYPE_F16, "s2v_vae_load_weight: unsupported dtype");
     auto it = v->slots.find(name);
     if (it == v->slots.end()) {
         std::string m = std::string("s2v_vae_load_weight: unknown tensor name: ") + name;
@@ -268,30 +269,28 @@ extern "C" int s2v_vae_load_weight(s2v_vae* v, const char* name, const void* dev
     else if (s.kind == 3) S2V_TRY(launch_convert(dev_ptr, src_dtype, s.dst, S2V_F32, n, st));
     else if (s.kind == 1) S2V_TRY(launch_conv_w_repack(dev_ptr, src_dtype, (int)s.d0, (int)s.d1, (int)s.taps, s.dst, v->dtype, st));
     else {
-        // the reference holds conv_y / conv_b in the model dtype: round first, then widen
+        // the reference holds conv_y / conv_b in the model dtype: round first (through a scratch of that dtype unless the source already is
+        // of it or the model is fp32), then widen + transpose
         const int tot = (int)n;
-        if (src_dtype == S2V_DTYPE_BF16 || v->dtype == S2V_DTYPE_F32) {
-            if (src_dtype == S2V_DTYPE_BF16)
-                hipLaunchKernelGGL(to_f32_transposed_k<bf16_t>, dim3((tot + 255) / 256), dim3(256), 0, st, (const bf16_t*)dev_ptr, (int)s.d0, (int)s.d1, (float*)s.dst);
-            else
-                hipLaunchKernelGGL(to_f32_transposed_k<float>, dim3((tot + 255) / 256), dim3(256), 0, st, (const float*)dev_ptr, (int)s.d0, (int)s.d1, (float*)s.dst);
-        } else {
-            bf16_t* tmp = nullptr;
-            S2V_CHECK_HIP(hipMalloc((void**)&tmp, sizeof(bf16_t) * n));
-            int r = launch_convert(dev_ptr, src_dtype, tmp, S2V_BF16, n, st);
-            if (!r) hipLaunchKernelGGL(to_f32_transposed_k<bf16_t>, dim3((tot + 255) / 256), dim3(256), 0, st, tmp, (int)s.d0, (int)s.d1, (float*)s.dst);
-            (void)hipStreamSynchronize(st);
-            (void)hipFree(tmp);
-            if (r) return r;
+        const void* srcp = dev_ptr;
+        int sdt = src_dtype;
+        void* tmp = nullptr;
+        if (v->dtype != S2V_DTYPE_F32 && src_dtype != v->dtype) {
+            S2V_CHECK_HIP(hipMalloc(&tmp, 2 * (size_t)n));
+            const int r = launch_convert(dev_ptr, src_dtype, tmp, v->dtype, n, st);
+            if (r) { (void)hipFree(tmp); return r; }
+            srcp = tmp; sdt = v->dtype;
         }
+        S2V_DT_DISPATCH(sdt, hipLaunchKernelGGL(to_f32_transposed_k<T>, dim3((tot + 255) / 256), dim3(256), 0, st, (const T*)srcp, (int)s.d0, (int)s.d1, (float*)s.dst))
+        if (tmp) { (void)hipStreamSynchronize(st); (void)hipFree(tmp); }
         S2V_CHECK_HIP(hipGetLastError());
     }
-    if (s.kind == 3 && v->dtype == S2V_DTYPE_BF16 && src_dtype == S2V_DTYPE_F32) {
-        // bias held in bf16 by the reference: round through the model dtype
-        bf16_t* tmp = nullptr;
-        S2V_CHECK_HIP(hipMalloc((void**)&tmp, sizeof(bf16_t) * n));
-        int r = launch_convert(dev_ptr, src_dtype, tmp, S2V_BF16, n, st);
-        if (!r) r = launch_convert(tmp, S2V_BF16, s.dst, S2V_F32, n, st);
+    if (s.kind == 3 && v->dtype != S2V_DTYPE_F32 && src_dtype != v->dtype) {
+        // bias held in the model dtype by the reference: round through it
+        void* tmp = nullptr;
+        S2V_CHECK_HIP(hipMalloc(&tmp, 2 * (size_t)n));
+        int r = launch_convert(dev_ptr, src_dtype, tmp, v->dtype, n, st);
+        if (!r) r = launch_convert(tmp, v->dtype, s.dst, S2V_F32, n, st);
         (void)hipStreamSynchronize(st);
         (void)hipFree(tmp);
         if (r) return r;
@@ -478,6 +477,15 @@ static int set_layout(s2v_vae* v, int h, int w, hipStream_t st, bool ring_only =
 }
 
 // ---- launch sequences --------------------------------------------------------------------------------------------
+#ifdef S2V_DIAG
+// tools/vae_conv_rates.py: EVERY GEMM-shaped launch of the decode in launch order -- convolutions AND the 1 x 1 shortcut GEMMs between them --
+// so that the log zips one-to-one with the GEMM kernels of a kernel trace (round 4 logged the convolutions only and matched the rest by grid
+// size: a shortcut GEMM with a convolution's grid then stood in for it, and rows above the 2.5 PF peak appeared)
+static void vae_gemm_log(const GemmArgs& g, int epi, bool mfma, const char* kind) {
+    if (const char* lg = getenv("S2V_VAE_CONV_LOG"))
+        if (FILE* f = fopen(lg, "a")) { fprintf(f, "%d %d %d %d %d %s\n", g.M, g.N, g.K, epi, (int)mfma, kind); fclose(f); }
+}
+#endif
 static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int epi, const void* resid, void* out,
                     hipStream_t st) {
     const int64_t fb = (int64_t)(H + 2) * (W + 2) * c.cin * v->esz;
@@ -497,11 +505,10 @@ static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int e
         if (epi == EPI_BIAS_ADD && atoi(e) == 1) { epi = EPI_BIAS; g.R = nullptr; }
         if (epi == EPI_BIAS_ADD && atoi(e) == 2) g.R = (const char*)c.pad;  // some other resident buffer of at least M x cout elements
     }
-    if (const char* lg = getenv("S2V_VAE_CONV_LOG")) {  // tools/vae_conv_rates.py: the convolutions in launch order, to be zipped with a kernel trace
-        if (FILE* f = fopen(lg, "a")) { fprintf(f, "%d %d %d %d %d\n", g.M, g.N, g.K, epi, (int)(v->mfma && c.cin % 64 == 0)); fclose(f); }
-    }
+    vae_gemm_log(g, epi, v->mfma && c.cin % 64 == 0, "conv");
 #endif
     if (v->mfma && c.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, epi, st));  // cout = 3 (conv_out) runs one padded 128-column tile
+    else if (v->h16 && gemm_f16_ok(g, epi)) S2V_TRY(launch_gemm_f16(g, epi, st));
     else { g.valu_only = v->cfg.force_simple; S2V_TRY(launch_gemm_simple(g, epi, v->dtype, st)); }
     if (c.kt == 3) {  // conv cache: the last two frames of the operand become frames 0, 1 of the next batch (adjacent on both sides: one copy unless they overlap)
         if (F >= 2) S2V_CHECK_HIP(hipMemcpyAsync(c.pad, c.pad + (int64_t)F * fb, 2 * fb, hipMemcpyDeviceToDevice, st));
@@ -540,7 +547,11 @@ static int decode_batch(s2v_vae* v, int Fz, int h, int w, bool first, char* dst,
                 g.A = v->dense[cur]; g.lda = r.cin; g.W = r.sc.w; g.ldw = r.cin; g.bias = r.sc.b;
                 g.C = v->dense[t2]; g.ldc = r.cout; g.M = F * H * W; g.N = r.cout; g.K = r.cin;
                 g.a_rows_padded = (int)rup64(g.M, 256);  // dense buffers carry a 256-row slack
+#ifdef S2V_DIAG
+                vae_gemm_log(g, EPI_BIAS, v->mfma && r.cin % 64 == 0, "shortcut");
+#endif
                 if (v->mfma && r.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, EPI_BIAS, st));
+                else if (v->h16 && gemm_f16_ok(g, EPI_BIAS)) S2V_TRY(launch_gemm_f16(g, EPI_BIAS, st));
                 else { g.valu_only = v->cfg.force_simple; S2V_TRY(launch_gemm_simple(g, EPI_BIAS, v->dtype, st)); }
                 S2V_TRY(run_conv(v, r.c2, F, H, W, first, EPI_BIAS_ADD, v->dense[t2], v->dense[t2], st));
                 std::swap(cur, t2);
@@ -808,15 +819,16 @@ static int build_encoder(s2v_vae* v) {
 
 extern "C" int s2v_vae_enc_create(const s2v_vae_config* cfg, s2v_vae** out) {
     S2V_REQUIRE(cfg && out, "s2v_vae_enc_create: null argument");
-    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16, "s2v_vae_enc_create: unsupported dtype");
+    S2V_REQUIRE(cfg->dtype == S2V_DTYPE_F32 || cfg->dtype == S2V_DTYPE_BF16 || cfg->dtype == S2V_DTYPE_F16, "s2v_vae_enc_create: unsupported dtype");
     S2V_REQUIRE(cfg->num_blocks >= 1 && cfg->num_blocks <= 6, "s2v_vae_enc_create: 1..6 blocks");
     s2v_vae* v = new s2v_vae();
     v->cfg = *cfg;
     v->dtype = cfg->dtype;
-    v->esz = cfg->dtype == S2V_DTYPE_BF16 ? 2 : 4;
+    v->esz = cfg->dtype == S2V_DTYPE_F32 ? 4 : 2;
     v->G = cfg->norm_num_groups;
     v->Cz = cfg->latent_channels;
     v->mfma = cfg->dtype == S2V_DTYPE_BF16 && !cfg->force_simple;
+    v->h16 = cfg->dtype == S2V_DTYPE_F16 && !cfg->force_simple;  // fp16: convolutions / shortcuts with cin % 64 == 0 on v_mfma_f32_32x32x16_f16 (gemm_f16)
     v->encoder = true;
     const int r = build_two_pass(v, build_encoder);
     if (r) { s2v_vae_destroy(v); return r; }
@@ -866,6 +878,7 @@ static int run_conv_down(s2v_vae* v, ConvL& c, int H, int W, void* out, hipStrea
     g.conv = 1; g.cin = c.cin; g.Hp = H + 2; g.Wp = W + 2; g.oH = H / 2; g.oW = W / 2; g.kt = 1; g.cstride = 2;
     g.w_rows_padded = (int)rup64(c.cout, 256);
     if (v->mfma && c.cin % 64 == 0) return launch_gemm_bf16(g, EPI_BIAS, st);
+    if (v->h16 && gemm_f16_ok(g, EPI_BIAS)) return launch_gemm_f16(g, EPI_BIAS, st);
     g.valu_only = v->cfg.force_simple;
     return launch_gemm_simple(g, EPI_BIAS, v->dtype, st);
 }
@@ -889,6 +902,7 @@ static int encode_window(s2v_vae* v, const void* image, int Himg, int Wimg, int 
                 g.C = v->dense[t2]; g.ldc = r.cout; g.M = H * W; g.N = r.cout; g.K = r.cin;
                 g.a_rows_padded = (int)rup64(g.M, 256);
                 if (v->mfma && r.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, EPI_BIAS, st));
+                else if (v->h16 && gemm_f16_ok(g, EPI_BIAS)) S2V_TRY(launch_gemm_f16(g, EPI_BIAS, st));
                 else { g.valu_only = v->cfg.force_simple; S2V_TRY(launch_gemm_simple(g, EPI_BIAS, v->dtype, st)); }
                 S2V_TRY(run_conv(v, r.c2, 1, H, W, true, EPI_BIAS_ADD, v->dense[t2], v->dense[t2], st));
                 std::swap(cur, t2);
@@ -1004,6 +1018,6 @@ extern "C" int s2v_vae_encode(s2v_vae* v, const void* image, int32_t H, int32_t 
 extern "C" int s2v_vae_gaussian_sample(const void* moments, const void* noise, int32_t latent_channels, int64_t n_spatial, void* out,
                                        int32_t dtype, s2v_stream stream) {
     S2V_REQUIRE(moments && noise && out && latent_channels > 0 && n_spatial > 0, "s2v_vae_gaussian_sample: bad argument");
-    S2V_REQUIRE(dtype == S2V_DTYPE_F32 || dtype == S2V_DTYPE_BF16, "s2v_vae_gaussian_sample: unsupported dtype");
+    S2V_REQUIRE(dtype == S2V_DTYPE_F32 || dtype == S2V_DTYPE_BF16 || dtype == S2V_DTYPE_F16, "s2v_vae_gaussian_sample: unsupported dtype");
     return launch_gaussian_sample(moments, noise, (int64_t)latent_channels * n_spatial, out, dtype, (hipStream_t)stream);
 }

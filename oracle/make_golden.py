@@ -311,6 +311,22 @@ def gen_t5():
     with torch.no_grad():
         out["last_hidden_state"] = m(ids)[0].numpy()
         out["last_hidden_state_T9"] = m(ids[:, :9])[0].numpy()
+        # fp16 (round 5): src/inference.py:209,214 moves the text encoder to the pipeline dtype -- fp16 for every non-5B checkpoint.  Two runs:
+        # the plain one, and one whose block-0 feed-forward output overflows fp16 (its wo scaled by 3e4) so that T5Block's inf clamp acts
+        mh = T5EncoderModel(T5Config(**T5_TINY)).eval()
+        mh.load_state_dict(m.state_dict())
+        mh = mh.half()
+        out["last_hidden_state_f16"] = mh(ids)[0].float().numpy()
+        key = "encoder.block.0.layer.1.DenseReluDense.wo.weight"
+        sd2 = {k: v.clone() for k, v in m.state_dict().items()}
+        sd2[key] = sd2[key] * 3.0e4
+        mo = T5EncoderModel(T5Config(**T5_TINY)).eval()
+        mo.load_state_dict(sd2)
+        mo = mo.half()
+        yo = mo(ids)[0].float()
+        assert torch.isfinite(yo).all()
+        out["last_hidden_state_f16_overflow"] = yo.numpy()
+        out["f16_overflow_wo_scale"] = np.array(3.0e4)
     out["transformers_version"] = np.array(transformers.__version__)
     np.savez_compressed(os.path.join(OUT, "t5_tiny.npz"), **out)
 

@@ -63,6 +63,15 @@ def self_attention(sd, p, x, bias, H, dk):
     return F.linear(o, sd[p + "o.weight"])
 
 
+def fp16_clamp(x):
+    """T5Block.forward after every sub-layer, fp16 only ("clamp inf values to enable fp16 training"): the residual stream is clamped to
+    +-finfo.max, or to +-(finfo.max - 1000) when it holds an inf (T5-XXL's feed-forward outputs overflow fp16)"""
+    if x.dtype != torch.float16:
+        return x
+    c = torch.where(torch.isinf(x).any(), torch.finfo(x.dtype).max - 1000, torch.finfo(x.dtype).max)
+    return torch.clamp(x, min=-c, max=c)
+
+
 def encoder_forward(sd, cfg, input_ids):
     H, dk, eps = cfg["num_heads"], cfg["d_kv"], cfg.get("layer_norm_epsilon", 1e-6)
     x = sd["shared.weight"][input_ids]
@@ -72,9 +81,9 @@ def encoder_forward(sd, cfg, input_ids):
     for i in range(cfg["num_layers"]):
         p = f"encoder.block.{i}."
         h = rms_norm(x, sd[p + "layer.0.layer_norm.weight"], eps)
-        x = x + self_attention(sd, p + "layer.0.SelfAttention.", h, bias, H, dk)
+        x = fp16_clamp(x + self_attention(sd, p + "layer.0.SelfAttention.", h, bias, H, dk))
         h = rms_norm(x, sd[p + "layer.1.layer_norm.weight"], eps)
         g = gelu_new(F.linear(h, sd[p + "layer.1.DenseReluDense.wi_0.weight"]))
         u = F.linear(h, sd[p + "layer.1.DenseReluDense.wi_1.weight"])
-        x = x + F.linear(g * u, sd[p + "layer.1.DenseReluDense.wo.weight"])
+        x = fp16_clamp(x + F.linear(g * u, sd[p + "layer.1.DenseReluDense.wo.weight"]))
     return rms_norm(x, sd["encoder.final_layer_norm.weight"], eps)

@@ -132,3 +132,46 @@ def test_t5_xxl_real_width_and_depth_vs_oracle(s2v):
           f"oracle's own bf16 run {rel(e16, e32):.3e}; HIP bf16 vs bf16 oracle {rel(y16, e16):.3e}")
     assert err32 <= 1e-3, err32
     assert torch.isfinite(y16).all() and rel(y16, e32) <= 1.5 * rel(e16, e32) + 5e-3
+
+
+def test_t5_tiny_fp16_vs_transformers_golden_including_the_inf_clamp(s2v):
+    """the fp16 text encoder (src/inference.py:209,214: every non-5B checkpoint) against transformers' own fp16 run: plain, and with a block-0
+    feed-forward whose output overflows fp16 so that T5Block's `clamp inf values` step acts (finfo.max - 1000 once an inf is present).  The tiny
+    encoder's unscaled logits (~100) make a score's fp16 ulp 6e-2: transformers' fp16 run and the fp16 oracle agree to 6e-3 relative L2, the bar
+    here is 1.5e-2."""
+    g = load_golden("t5_tiny.npz")
+    ids = t(g["input_ids"])
+    for key, scale in (("last_hidden_state_f16", 1.0), ("last_hidden_state_f16_overflow", float(g["f16_overflow_wo_scale"]))):
+        sd = weights_of(g)
+        k = "encoder.block.0.layer.1.DenseReluDense.wo.weight"
+        sd[k] = sd[k] * scale
+        m = s2v.HipT5EncoderModel(s2v.T5Config(**TINY), torch.float16, DEV)
+        m.load_state_dict({a: b.half() for a, b in sd.items()})
+        y = m(ids.to(DEV))[0]
+        torch.cuda.synchronize()
+        assert y.dtype == torch.float16 and torch.isfinite(y.float()).all(), key
+        exp = t(g[key])
+        rel = ((y.float().cpu() - exp).norm() / exp.norm()).item()
+        print(f"MEASURED t5 f16 {key}: rel-l2 {rel:.3e}")
+        assert rel <= 1.5e-2, (key, rel)
+
+
+@pytest.mark.parametrize("simple", [False, True])
+def test_t5_mfma_width_f16_vs_oracle(s2v, simple):
+    """d_model 512 / d_ff 1024 / 8 heads, 3 blocks, fp16, B = 2 x T = 226: every Linear on v_mfma_f32_32x32x16_f16 (gemm_f16; or the VALU kernels
+    with force_simple) against the oracle run in fp16 on the CPU"""
+    cfgd = dict(vocab_size=300, d_model=512, d_kv=64, num_heads=8, d_ff=1024, num_layers=3, relative_attention_num_buckets=32,
+                relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
+    cfg = s2v.T5Config(**cfgd)
+    sd = {k: v.half() for k, v in s2v.weights.synthetic_t5_state_dict(cfg, seed=61).items()}
+    ids = torch.randint(0, 300, (2, 226), generator=torch.Generator().manual_seed(62))
+    m = s2v.HipT5EncoderModel(cfg, torch.float16, DEV, force_simple=simple)
+    m.load_state_dict(sd)
+    y = m(ids.to(DEV))[0].float().cpu()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        exp = t5_ref.encoder_forward(sd, cfgd, ids).float()
+    assert torch.isfinite(y).all()
+    rel = ((y - exp).norm() / exp.norm()).item()
+    print(f"MEASURED t5 f16 mfma-width simple={simple}: rel-l2 {rel:.3e}")
+    assert rel <= 4e-3, rel   # the bf16 bar (3e-2) / 8

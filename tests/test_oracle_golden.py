@@ -329,6 +329,32 @@ def test_t5_bucket_table_host_equals_oracle():
     assert int(b.min()) == 0 and int(b.max()) == 31 and int(b[0, 225]) == 31 and int(b[225, 0]) == 15
 
 
+def test_t5_fp16_oracle_vs_transformers_golden_including_the_inf_clamp():
+    """fp16 text encoder (src/inference.py:209,214 for every non-5B checkpoint): the oracle in fp16 against transformers' own fp16 run, plain and with
+    a block-0 feed-forward that overflows fp16 (T5Block's `clamp inf values` path: finfo.max - 1000).  The tiny encoder has unscaled logits of
+    magnitude ~100, where one fp16 ulp of a score is 6e-2: the two fp16 runs (different attention kernels) agree to 6e-3 relative L2."""
+    from oracle import t5_ref
+
+    g = load_golden("t5_tiny.npz")
+    cfg = dict(vocab_size=100, d_model=128, d_kv=64, num_heads=2, d_ff=256, num_layers=2, relative_attention_num_buckets=32,
+               relative_attention_max_distance=128, layer_norm_epsilon=1e-6)
+    ids = t(g["input_ids"], torch.int64)
+    with torch.no_grad():
+        y = t5_ref.encoder_forward(weights_of(g, torch.float16), cfg, ids).float().numpy()
+    exp = g["last_hidden_state_f16"]
+    assert np.linalg.norm(y - exp) / np.linalg.norm(exp) <= 1.2e-2
+    sd = weights_of(g)
+    k = "encoder.block.0.layer.1.DenseReluDense.wo.weight"
+    sd[k] = sd[k] * float(g["f16_overflow_wo_scale"])
+    with torch.no_grad():
+        y = t5_ref.encoder_forward({a: b.half() for a, b in sd.items()}, cfg, ids).float().numpy()
+    exp = g["last_hidden_state_f16_overflow"]
+    assert np.isfinite(y).all() and np.linalg.norm(y - exp) / np.linalg.norm(exp) <= 1.2e-2
+    # without the clamp the overflow reaches the output as NaN / inf
+    x = torch.tensor([[70000.0, -70000.0, 1.0]]).half()
+    assert torch.isinf(x).any() and torch.isfinite(t5_ref.fp16_clamp(x)).all() and t5_ref.fp16_clamp(x)[0, 0].item() == 64512.0
+
+
 def test_lora_merge_equals_runtime_adapter_within_bf16_rounding():
     """the PEFT runtime path of the reference computes base(x) + scaling * lora_B(lora_A(x)) with every Linear output rounded
     to bf16 (peft is not installed here: this is the library's documented forward); the build merges W' = W + scaling * B A
