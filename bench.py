@@ -42,6 +42,9 @@ WORKLOADS = {
     "cogvideox-5b-49x720x1280": ("cogvideox-5b", 13, 90, 160, 226),
     "cogvideox-5b-fp8-49x720x1280": ("cogvideox-5b-fp8", 13, 90, 160, 226),
     "cogvideox-5b-fp8-49x480x720": ("cogvideox-5b-fp8", 13, 60, 90, 226),
+    # weight_format "fp8" proper (linears only) at the configs[4] geometry, for comparison: the configs[4] preset itself is "fp8-auto" since round 5
+    # (fp8 QK^T from 40 000 tokens on; config.cogvideox_5b_fp8)
+    "cogvideox-5b-fp8lin-49x720x1280": ("cogvideox-5b-fp8lin", 13, 90, 160, 226),
     # an option BEYOND configs[4]'s "fp8 weights": additionally q / k as MX e4m3 and QK^T on the scaled fp8 MFMA (weight_format 2)
     "cogvideox-5b-fp8qk-49x720x1280": ("cogvideox-5b-fp8qk", 13, 90, 160, 226),
     "cogvideox-5b-fp8qk-49x480x720": ("cogvideox-5b-fp8qk", 13, 60, 90, 226),
@@ -405,7 +408,7 @@ def main(argv=None):
     cfg = s2v.config.PRESETS[preset]()
     if os.environ.get("S2V_ATTN_P"):   # same-box A/B of attn_p_format ("bf16" / "f16"); the line reports it in config.attn_p_format
         cfg.attn_p_format = os.environ["S2V_ATTN_P"]
-    fp8 = cfg.weight_format in ("fp8", "fp8-qk")
+    fp8 = cfg.weight_format in ("fp8", "fp8-qk", "fp8-auto")
     dt = torch.bfloat16
     vae = None
     if rank == 0 and not args.no_vae:
@@ -757,9 +760,9 @@ def main(argv=None):
             "n_gpus": n_devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp8 (e4m3 W8A8 block linears, MX e4m3 QK^T) + bf16" if cfg.weight_format == "fp8-qk" else "fp8 (e4m3 W8A8 block linears) + bf16") if fp8 else "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
+            "dtype": ("fp8 (e4m3 W8A8 block linears, MX e4m3 QK^T) + bf16" if eng.fp8_qk_active else "fp8 (e4m3 W8A8 block linears) + bf16") if fp8 else "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
             "config": {"workload": args.workload, "latent_frames": F, "latent_hw": [H, W], "tokens": T + (F + 1) * (H // 2) * (W // 2),
-                       "cfg_pair": 2, "scheduler": "ddim-trailing-50", "attn_p_format": cfg.attn_p_format if cfg.attn_p_format != "auto" else f"auto -> {eng.attn_p_format}",
+                       "cfg_pair": 2, "scheduler": "ddim-trailing-50", "weight_format": cfg.weight_format, "fp8_qk_active": eng.fp8_qk_active if fp8 else None, "attn_p_format": cfg.attn_p_format if cfg.attn_p_format != "auto" else f"auto -> {eng.attn_p_format}",
                        "attn_slow_path_fraction": eng.attn_slow_fraction, "parallelism": f"replicas x{world}",
                        "rccl_ranks": world, "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "launcher": "self-spawned" if os.environ.get("S2V_BENCH_SPAWNED") == "1" else ("torchrun env" if env_world is not None else "single process"),

@@ -33,9 +33,9 @@ class S2VEngine:
         c.dtype = _lib.DTYPE_OF[dtype]
         c.norm_eps = cfg.norm_eps
         c.force_simple = int(force_simple)
-        if cfg.weight_format not in (None, "fp8", "fp8-qk"):
-            raise _lib.S2VError(f"unknown weight_format {cfg.weight_format!r} (None, 'fp8' or 'fp8-qk')")
-        c.weight_format = {None: 0, "fp8": 1, "fp8-qk": 2}[cfg.weight_format]
+        if cfg.weight_format not in (None, "fp8", "fp8-qk", "fp8-auto"):
+            raise _lib.S2VError(f"unknown weight_format {cfg.weight_format!r} (None, 'fp8', 'fp8-qk' or 'fp8-auto')")
+        c.weight_format = {None: 0, "fp8": 1, "fp8-qk": 2, "fp8-auto": 3}[cfg.weight_format]
         if cfg.lora_adaln_scope not in ("shipped", "intended"):
             raise _lib.S2VError(f"unknown lora_adaln_scope {cfg.lora_adaln_scope!r} ('shipped' or 'intended')")
         c.lora_adaln_scope = 1 if cfg.lora_adaln_scope == "intended" else 0
@@ -135,6 +135,18 @@ class S2VEngine:
     def _bump(self, *kinds):
         for k in kinds:
             self.epoch[k] += 1
+
+    FP8_QK_AUTO_TOKENS = 40000   # csrc/api.hip S2V_FP8_QK_AUTO_TOKENS
+
+    @property
+    def fp8_qk_active(self):
+        """whether QK^T of the attention runs in fp8 at the current geometry ("fp8-qk": always; "fp8-auto": from 40 000 tokens per sample on)"""
+        if self.cfg.weight_format == "fp8-qk":
+            return True
+        if self.cfg.weight_format == "fp8-auto" and self.geometry is not None:
+            B, T, F, H, W = self.geometry
+            return T + (F + 1) * (H // 2) * (W // 2) >= self.FP8_QK_AUTO_TOKENS
+        return False
 
     def set_geometry(self, B, T, F, H, W):
         new = self.geometry != (B, T, F, H, W)

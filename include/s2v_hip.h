@@ -57,7 +57,11 @@ typedef struct s2v_model_config {
                                * 2 = 1 plus fp8 QK^T (an option beyond "fp8 weights", off unless asked for): after the per-head LayerNorm and
                                * rotary embedding q (times scale * log2 e) and k are re-quantised as MX e4m3 (one power-of-two scale per
                                * 32 head-dim elements) and S = K.Q^T of the attention runs on the same scaled fp8 MFMA; softmax, P and P.V
-                               * stay fp32 / bf16.  The reference has no fp8 path: parity unpinned, tolerance stated in tests/test_gpu_fp8.py */
+                               * stay fp32 / bf16;
+                               * 3 = 1 below 40 000 tokens per sample, 2 from there on (decided at s2v_set_geometry): at the configs[4] geometry
+                               * (N = 50 626) the attention is > 80 % of the step, fp8 QK^T takes 11-14 % off it and adds nothing measurable to the
+                               * fp8 engine's whole-run drift (profiles/r05_whole_run_c5_10steps.txt) -- what the package's configs[4] preset uses.
+                               * The reference has no fp8 path: parity unpinned, tolerance stated in tests/test_gpu_fp8.py */
     int32_t lora_adaln_scope; /* where the subject-LoRA acts inside CogVideoXLayerNormZero (normalization.py:467-484):
                                * 0 = as shipped: `enable_lora([self.linear], False)` sets an attribute nothing reads, so the LoRA
                                *     is active on both evaluations of norm{1,2}.linear and is merged into it (SURVEY preamble 6);

@@ -116,6 +116,36 @@ def test_config4_fp8_engine_full_geometry(s2v, fmt):
     assert torch.equal(a, b), "graph replay must equal the eager launch sequence"
 
 
+def test_fp8_auto_is_fp8_below_40k_tokens_and_fp8_qk_above(s2v):
+    """weight_format "fp8-auto" (the configs[4] preset since round 5, config.cogvideox_5b_fp8): bit-identical to "fp8" at a short sequence and to
+    "fp8-qk" at configs[4]'s 50 626 tokens (the decision is taken at s2v_set_geometry)"""
+    assert s2v.config.cogvideox_5b_fp8().weight_format == "fp8-auto"
+    cfg = s2v.cogvideox_5b()
+    cfg.num_layers = 1
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=47, device=DEV, parity=True)
+    for (F, H, W, twin) in ((2, 16, 24, "fp8"), (F4, H4, W4, "fp8-qk")):
+        g = torch.Generator(device=DEV).manual_seed(48)
+        t1 = torch.randn(1, T4, 4096, generator=g, device=DEV)
+        text = torch.cat([t1, t1])
+        ref = torch.randn(1, 1, 16, H, W, generator=g, device=DEV) * 0.7
+        lat = torch.randn(1, F, 16, H, W, generator=g, device=DEV).bfloat16()
+        outs = {}
+        for fmt in ("fp8-auto", twin):
+            c = copy.copy(cfg)
+            c.weight_format = fmt
+            m = s2v.HipCogVideoXTransformer3DModel(c, torch.bfloat16, DEV)
+            m.load_state_dict(sd)
+            eng = m.engine
+            eng.set_geometry(2, T4, F, H, W)
+            eng.prepare_tables(H * 8, W * 8)
+            eng.set_conditioning(text, ref)
+            outs[fmt] = eng.forward(lat, torch.tensor([500.0, 500.0]), shared_latent=True).clone()
+            torch.cuda.synchronize()
+            assert eng.fp8_qk_active == (twin == "fp8-qk")
+            eng.close()
+        assert torch.isfinite(outs[twin].float()).all() and torch.equal(outs["fp8-auto"], outs[twin]), twin
+
+
 def test_config4_tiled_vae_decode_real_width_properties(s2v):
     cfg = s2v.VAEConfig(scaling_factor=0.7, sample_height=480, sample_width=720)
     sd = s2v.weights.synthetic_vae_state_dict(cfg, seed=45, device=DEV)
