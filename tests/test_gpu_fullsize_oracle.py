@@ -6,7 +6,7 @@
     the fp32 path (VALU kernels, and the fp32 matrix-pipe kernels gemm_f32m / attn_f32m that the fp32 engine runs by default), and 2B width (D = 1920, 30 heads, no RoPE; configs[1]: padded 256-column tiles at M = 38252);
   * attention alone at the geometry of configs[4] (49 x 720 x 1280 -> N = 50626 tokens), two heads, against fp32 SDPA.
 
-Tolerances: fp32 generic path max-abs <= 1e-3 (north_star); bf16 path relative L2 <= 2e-2 and max-abs <= 6e-2 * max|ref|
+Tolerances (2 x measured, F32_BAR / BF16_BARS below): fp32 max-abs <= 2e-5 (north_star: 1e-3); bf16 relative L2 <= 5e-3 and max-abs <= 1.1e-2 * max|ref|
 against the fp32 oracle evaluated on the same bf16-rounded weights and inputs.
 """
 import time
@@ -21,8 +21,10 @@ DEV = "cuda:0"
 F_, H_, W_, T_ = 13, 60, 90, 226  # 49 frames 480 x 720
 
 
-F32_BAR = 1e-3            # set to 2 x measured below
-BF16_BARS = (2e-2, 6e-2)
+# 2 x the values measured in round 5 (fp32, VALU and matrix-pipe kernels alike: max-abs 8.6e-6; bf16: rel-L2 2.44e-3, max-abs 5.5e-3 max|ref|);
+# until round 4: 1e-3 and 2e-2 / 6e-2.  North star for fp32: 1e-3.
+F32_BAR = 2e-5
+BF16_BARS = (5e-3, 1.1e-2)
 
 
 def rel_l2(a, b):

@@ -138,7 +138,7 @@ def test_t5_tiny_fp16_vs_transformers_golden_including_the_inf_clamp(s2v):
     """the fp16 text encoder (src/inference.py:209,214: every non-5B checkpoint) against transformers' own fp16 run: plain, and with a block-0
     feed-forward whose output overflows fp16 so that T5Block's `clamp inf values` step acts (finfo.max - 1000 once an inf is present).  The tiny
     encoder's unscaled logits (~100) make a score's fp16 ulp 6e-2: transformers' fp16 run and the fp16 oracle agree to 6e-3 relative L2, the bar
-    here is 1.5e-2."""
+    here is 1.2e-2."""
     g = load_golden("t5_tiny.npz")
     ids = t(g["input_ids"])
     for key, scale in (("last_hidden_state_f16", 1.0), ("last_hidden_state_f16_overflow", float(g["f16_overflow_wo_scale"]))):
@@ -153,7 +153,7 @@ def test_t5_tiny_fp16_vs_transformers_golden_including_the_inf_clamp(s2v):
         exp = t(g[key])
         rel = ((y.float().cpu() - exp).norm() / exp.norm()).item()
         print(f"MEASURED t5 f16 {key}: rel-l2 {rel:.3e}")
-        assert rel <= 1.5e-2, (key, rel)
+        assert rel <= 1.2e-2, (key, rel)   # 2 x measured (6.0e-3)
 
 
 @pytest.mark.parametrize("simple", [False, True])
@@ -174,4 +174,4 @@ def test_t5_mfma_width_f16_vs_oracle(s2v, simple):
     assert torch.isfinite(y).all()
     rel = ((y - exp).norm() / exp.norm()).item()
     print(f"MEASURED t5 f16 mfma-width simple={simple}: rel-l2 {rel:.3e}")
-    assert rel <= 4e-3, rel   # the bf16 bar (3e-2) / 8
+    assert rel <= 2.3e-3, rel   # 2 x measured (1.1e-3)

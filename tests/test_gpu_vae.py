@@ -119,9 +119,9 @@ def test_vae_real_width_decoder_vs_oracle(s2v, dt_name):
         assert err <= 1e-3, err
     else:  # fp16 (round 5): the same rounding points, 8 x finer ulps
         rel = ((y - exp).double().norm() / exp.double().norm()).item()
-        k = 1.0 if dt_name == "bf16" else 0.125
+        br, ba = (1.7e-2, 2.1e-2) if dt_name == "bf16" else (2.1e-3, 2.5e-3)   # 2 x measured in round 5 (bf16 8.4e-3 / 1.05e-2, fp16 1.04e-3 / 1.23e-3)
         print(f"MEASURED vae {dt_name}: rel-l2 {rel:.3e} max-abs/max|ref| {err / exp.abs().max().item():.3e}")
-        assert rel <= 2e-2 * k and err <= 6e-2 * k * exp.abs().max().item(), (rel, err)
+        assert rel <= br and err <= ba * exp.abs().max().item(), (rel, err)
 
 
 @pytest.mark.parametrize("dt_name", ["f32", "bf16", "f16"])
@@ -149,9 +149,9 @@ def test_vae_real_width_tiled_decoder_vs_oracle(s2v, dt_name):
         assert err <= 1e-3, err
     else:  # fp16 (round 5): the same rounding points, 8 x finer ulps
         rel = ((y - exp).double().norm() / exp.double().norm()).item()
-        k = 1.0 if dt_name == "bf16" else 0.125
+        br, ba = (1.7e-2, 2.1e-2) if dt_name == "bf16" else (2.1e-3, 2.5e-3)   # 2 x measured in round 5 (bf16 8.4e-3 / 1.05e-2, fp16 1.04e-3 / 1.23e-3)
         print(f"MEASURED vae {dt_name}: rel-l2 {rel:.3e} max-abs/max|ref| {err / exp.abs().max().item():.3e}")
-        assert rel <= 2e-2 * k and err <= 6e-2 * k * exp.abs().max().item(), (rel, err)
+        assert rel <= br and err <= ba * exp.abs().max().item(), (rel, err)
 
 
 def test_frames_uint8_matches_export_to_video_conversion(s2v):
