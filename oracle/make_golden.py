@@ -380,7 +380,7 @@ def gen_pipeline():
             def spy(model_output, *a, **k):
                 trace["noise_pred"].append(model_output.detach().float().clone())
                 ret = step(model_output, *a, **k)
-                trace["latents"].append(ret[0].detach().to(pe.dtype).float().clone())  # `latents.to(prompt_embeds.dtype)`, :296
+                trace["latents"].append(ret[0].detach().to(args["prompt_embeds"].dtype).float().clone())  # `latents.to(prompt_embeds.dtype)`, :296
                 return ret
 
             pipe.scheduler.step = spy
@@ -424,6 +424,22 @@ def gen_pipeline():
             out["frames_ddim_tiled_shape"] = np.array(frames.shape)
             out["frames_ddim_tiled_sub8"] = frames[:, :, ::8, ::8, :].astype(np.float32)
             out["frames_ddim_tiled_sums"] = frames.astype(np.float64).sum(axis=(2, 3))  # [1, F, 3]
+    # Round 5: the same three DDIM steps with the WHOLE pipeline in bf16 and in fp16 (src/inference.py:191,209: bf16 for 5B checkpoints, fp16 for
+    # the others): the loop's own rounding points -- `latents.to(prompt_embeds.dtype)` (:296), the scheduler on reduced-precision samples, the
+    # transformer in that dtype -- pinned against the reference itself, not only against the oracle.  Appended after everything else: the fp32
+    # entries above keep their bits.
+    import copy
+
+    for dt_name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        trh = copy.deepcopy(tr).to(dt)
+        sched = CogVideoXDDIMScheduler(**sched_kwargs(1.0))
+        pipe = CustomCogVideoXPipeline(tokenizer=None, text_encoder=None, transformer=trh, vae=vae, scheduler=sched, customization=True)
+        trace = {"noise_pred": [], "latents": []}
+        res, _ = run(pipe, trace, prompt_embeds=pe.to(dt), negative_prompt_embeds=ne.to(dt), ref_img_states=ref.to(dt), latents=lat0.to(dt).clone())
+        assert res.dtype == dt and torch.isfinite(res.float()).all()
+        out[f"final_ddim_{dt_name}"] = res.float().numpy()
+        put_steps(out, f"steps_latents_ddim_{dt_name}", trace["latents"])
+        put_steps(out, f"steps_noise_pred_ddim_{dt_name}", trace["noise_pred"])
     np.savez_compressed(os.path.join(OUT, "pipeline_tiny.npz"), **out)
 
 

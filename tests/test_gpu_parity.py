@@ -325,6 +325,33 @@ def test_pipeline_three_steps_vs_reference_golden(s2v, kind, mode):
         _check_steps(nps, g, f"steps_noise_pred_{kind}")
 
 
+@pytest.mark.parametrize("dt_name", ["bf16", "f16"])
+@pytest.mark.parametrize("mode", ["fused_graph", "seams"])
+def test_pipeline_three_steps_reduced_precision_vs_reference_pipeline_golden(s2v, dt_name, mode):
+    """S2VPipeline in bf16 / fp16 against CustomCogVideoXPipeline.__call__ ITSELF run in that dtype on the CPU (round 5 fixtures
+    final_ddim_{bf16,f16}, steps_latents_ddim_*: the loop's rounding points -- `latents.to(prompt_embeds.dtype)`, the scheduler on
+    reduced-precision samples -- pinned to the reference, which the CPU oracle reproduces bit for bit): latents after every step and at the end"""
+    g = load_golden("pipeline_tiny.npz")
+    dt = DT[dt_name]
+    cfg = s2v.tiny(use_rope=True, text_dim=64, temb=64)
+    cfg.max_text_seq_length = 6
+    m = s2v.HipCogVideoXTransformer3DModel(cfg, dt, DEV)
+    m.load_state_dict(weights_of(g))
+    pipe = s2v.S2VPipeline(m, s2v.CogVideoXDDIMScheduler(snr_shift_scale=1.0), None)
+    lats = []
+    args = _pipe_args(g)
+    for k in ("prompt_embeds", "negative_prompt_embeds", "ref_img_states", "latents"):
+        args[k] = args[k].to(dt)
+    out = pipe(output_type="latent", fused=mode != "seams", use_graph=mode == "fused_graph",
+               callback_on_step_end=lambda p_, i, tt, kw: lats.append(kw["latents"].float().cpu().clone()), **args)[0]
+    torch.cuda.synchronize()
+    assert out.dtype == dt
+    assert_close(out, t(g[f"final_ddim_{dt_name}"]), dt_name, f"pipeline final latents {mode}")
+    exp = t(g[f"steps_latents_ddim_{dt_name}_sub2"])
+    for i, x in enumerate(lats):
+        assert_close(x[..., ::2, ::2], exp[i], dt_name, f"pipeline latents after step {i + 1} {mode}")
+
+
 @pytest.mark.parametrize("mode", ["fused_graph", "seams"])
 def test_pipeline_dynamic_cfg_vs_reference_golden(s2v, mode):
     """use_dynamic_cfg=True (custom_cogvideox_pipe.py:268-271): the guidance scale changes every step, so the captured graph must read

@@ -231,6 +231,32 @@ def test_pipeline_dynamic_cfg_and_tiled_frames():
     np.testing.assert_allclose(frames.astype(np.float64).sum(axis=(2, 3)), g["frames_ddim_tiled_sums"], rtol=1e-5)
 
 
+@pytest.mark.parametrize("dt_name", ["bf16", "f16"])
+def test_pipeline_three_steps_in_reduced_precision_bit_exact(dt_name):
+    """the WHOLE reference pipeline in bf16 / fp16 (src/inference.py:191,209; three DDIM steps, CFG 6): transformer in that dtype, fp32 CFG,
+    scheduler on the reduced-precision sample, `latents.to(prompt_embeds.dtype)` (custom_cogvideox_pipe.py:296).  The oracle loop runs the same
+    torch CPU kernels at the same rounding points: its latents after EVERY step equal the reference pipeline's bit for bit."""
+    g = load_golden("pipeline_tiny.npz")
+    dt = DT[dt_name]
+    sd = weights_of(g, dt)
+    cfg = dict(TINY_CFG, use_rope=True)
+    pe, ne, ref, lat = (t(g[k], dt) for k in ("prompt_embeds", "negative_prompt_embeds", "ref", "latents0"))
+    text = torch.cat([ne, pe], dim=0)
+    ref_rope, rope = tr.pipeline_rope(480, 720, lat.shape[1])
+    ac = sched_ref.alphas_cumprod(1.0)
+    lats, nps = [], []
+    with torch.no_grad():
+        for tt in sched_ref.trailing_timesteps(3):
+            npred = tr.transformer_forward(sd, cfg, torch.cat([lat] * 2), text, ref, torch.tensor([tt, tt]), rope, ref_rope).float()
+            v = sched_ref.cfg_combine(npred, 6.0)
+            nps.append(v)
+            lat = sched_ref.ddim_step(ac, 3, v, int(tt), lat)[0].to(dt)
+            lats.append(lat.float())
+    np.testing.assert_array_equal(lats[-1].numpy(), g[f"final_ddim_{dt_name}"])
+    np.testing.assert_array_equal(torch.stack(lats)[..., ::2, ::2].numpy(), g[f"steps_latents_ddim_{dt_name}_sub2"])
+    np.testing.assert_array_equal(torch.stack(nps)[..., ::2, ::2].numpy(), g[f"steps_noise_pred_ddim_{dt_name}_sub2"])
+
+
 PIPE_VAE_CFG = dict(block_out_channels=(8, 8, 8, 8), layers_per_block=1, norm_num_groups=2, latent_channels=16, sample_height=480,
                     sample_width=720, scaling_factor=0.7, temporal_compression_ratio=4)
 

@@ -30,7 +30,7 @@ for fused in (1, 0, 1, 0):
         eng.denoise_step(lat, float(sch.timesteps[i]), coefs[i], use_graph=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    n = 40
+    n = int(os.environ.get("N_STEPS", "40"))
     for i in range(n):
         eng.denoise_step(lat, float(sch.timesteps[(5 + i) % 50]), coefs[(5 + i) % 50], use_graph=False)
     torch.cuda.synchronize()
