@@ -28,6 +28,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3    # fp32-input MFMA (v_mfma_f32_32x32x2_f32) = the fp32 vector rate, same guide
 PEAK_FP8_TFLOPS = 5000.0   # dense fp8 MFMA peak (block-scaled f8f6f4 instructions), same guide
 PEAK_HBM_GBS = 8000.0     # HBM3E spec peak; ~6300 GB/s is what a float4 copy reaches (same guide)
 PEAK_CLOCK_MHZ = 2400.0   # the shader clock the datasheet peaks are quoted at (same guide: 157.3 TF fp32 = 64 FLOP/clk/SIMD x 1024 SIMDs x 2.4 GHz)
@@ -369,6 +370,9 @@ def main(argv=None):
     ap.add_argument("--no-vae", action="store_true", help="skip the one-off VAE decode timing")
     ap.add_argument("--native-bcast", action="store_true", help="N > 1: replicate the weights with the library's own RCCL communicator "
                     "(s2v_bcast_weights) instead of torch.distributed.broadcast")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"], help="model dtype of the engine, VAE and T5: bf16 = the headline (and every "
+                    "5B configuration); f32 = configs[0] as BASELINE names it (the CPU-reference-parity mode, on the fp32 matrix pipe); f16 = what the "
+                    "reference loads non-5B checkpoints in (src/inference.py:191).  Non-bf16 lines skip the format A/B passes and the CPU baseline")
     ap.add_argument("--dist-selftest", action="store_true", help="no GPU: exercise the rank launcher, the rendezvous, the chunked broadcast and its "
                     "watchdog with gloo on CPU tensors (tests/test_dist_gloo.py)")
     args = ap.parse_args(argv)
@@ -409,7 +413,13 @@ def main(argv=None):
     if os.environ.get("S2V_ATTN_P"):   # same-box A/B of attn_p_format ("bf16" / "f16"); the line reports it in config.attn_p_format
         cfg.attn_p_format = os.environ["S2V_ATTN_P"]
     fp8 = cfg.weight_format in ("fp8", "fp8-qk", "fp8-auto")
-    dt = torch.bfloat16
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[args.dtype]
+    if fp8 and args.dtype != "bf16":
+        raise SystemExit("fp8 workloads are bf16 engines (weight_format needs the bf16 MFMA path)")
+    if args.dtype != "bf16":  # the A/B passes are about the bf16 asm kernels; the CPU-baseline check compares against a bf16 block
+        os.environ["S2V_BENCH_SKIP_PFMT"] = os.environ["S2V_BENCH_SKIP_PARITY_PASS"] = "1"
+        args.no_cpu_baseline = True
+    PEAK_DT = {"bf16": PEAK_BF16_TFLOPS, "f16": PEAK_BF16_TFLOPS, "f32": PEAK_F32_TFLOPS}[args.dtype]
     vae = None
     if rank == 0 and not args.no_vae:
         # The decoder is created, and its first tiled decode run, BEFORE the transformer engine exists: the runtime binds a stream to a hardware
@@ -565,7 +575,7 @@ def main(argv=None):
                  "gemm_ff1_gelu": 2 * 2 * N * D * 4 * D, "gemm_ff2": 2 * 2 * N * D * 4 * D}
         # HBM-bound kernels: algorithmic bytes per launch: LayerNorm + modulate reads and writes the residual
         # stream once; the V transpose reads V and writes V^T; the modulation GEMV streams every norm linear's weights once per step
-        E = 2
+        E = 4 if args.dtype == "f32" else 2
         mod_rows = 2 * cfg.num_layers * 6 * D + 2 * D
         hbm_bytes = {"ln_modulate": 2 * (2 * N * D * E), "qknorm_rope_vt": 2 * (2 * N * D * E), "mod_gemv": mod_rows * cfg.time_embed_dim * E}
         per_kernel = {}
@@ -578,7 +588,7 @@ def main(argv=None):
                 e["shader_clock_mhz"] = round(mhz[k], 0)
             if name in flops:
                 e["tflops"] = round(flops[name] / avg / 1e9, 1)
-                e["peak_tflops"] = PEAK_FP8_TFLOPS if (fp8 and name.startswith("gemm_")) else PEAK_BF16_TFLOPS
+                e["peak_tflops"] = PEAK_FP8_TFLOPS if (fp8 and name.startswith("gemm_")) else PEAK_DT
                 e["frac_of_peak"] = round(e["tflops"] / e["peak_tflops"], 4)
                 if mhz[k] > 0:  # the datasheet peak is quoted at 2400 MHz; at the clock the part actually ran this launch at, the pipe's ceiling was
                     e["peak_at_measured_clock_tflops"] = round(e["peak_tflops"] * mhz[k] / PEAK_CLOCK_MHZ, 1)
@@ -591,7 +601,7 @@ def main(argv=None):
         dom = max((n for n in per_kernel if n in flops), key=lambda n: per_kernel[n]["avg_ms"] * per_kernel[n]["launches"])
         ach = per_kernel[dom]["tflops"]
         peak = per_kernel[dom]["peak_tflops"]  # the dominant kernel's own matrix-core peak (fp8 GEMMs: 5 PF, everything else 2.5 PF)
-        traffic, traffic_files = pmc_traffic_bytes(dom, args.workload)
+        traffic, traffic_files = pmc_traffic_bytes(dom, args.workload) if args.dtype == "bf16" else (None, [])  # the committed PMC passes are bf16 runs
         # unique operand bytes of one launch (bf16 activations; fp8 engines read 1-byte weights / activations on the GEMMs):
         # attention reads Q, K, V^T and writes O; a GEMM reads A [M,K] and W [N,K] and writes C [M,N]
         Eg = 1 if fp8 else 2
@@ -599,6 +609,8 @@ def main(argv=None):
         algo_bytes = {"attention": 4 * Mr * D * 2, "gemm_qkv": Mr * D * Eg + 3 * D * D * Eg + Mr * 3 * D * 2,
                       "gemm_out": Mr * D * Eg + D * D * Eg + Mr * D * 2, "gemm_ff1_gelu": Mr * D * Eg + 4 * D * D * Eg + Mr * 4 * D * Eg,
                       "gemm_ff2": Mr * 4 * D * Eg + 4 * D * D * Eg + Mr * D * 2}
+        if args.dtype == "f32":
+            algo_bytes = {k_: 2 * v_ for k_, v_ in algo_bytes.items()}
         roofline = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                     "frac": round(ach / peak, 4), "traffic": traffic,
                     "traffic_unit": "bytes/launch = 2 x FETCH_SIZE + WRITE_SIZE (MI355X_MICROARCH, HBM section) from "
@@ -612,8 +624,8 @@ def main(argv=None):
             # (a) CALIBRATED peak: what the vendor library reaches in this process, on this box, now, on the FF1 shape -- the part is
             # power-managed (shader_clock_mhz above), so the datasheet's 2.5 PF at 2.4 GHz is not what the matrix pipe can deliver under load
             Mr2, Kc, Nc = 2 * N, D, 4 * D
-            xa = torch.randn(Mr2, Kc, device=dev, dtype=torch.bfloat16)
-            xw = torch.randn(Kc, Nc, device=dev, dtype=torch.bfloat16)
+            xa = torch.randn(Mr2, Kc, device=dev, dtype=dt)
+            xw = torch.randn(Kc, Nc, device=dev, dtype=dt)
             for _ in range(3):
                 torch.matmul(xa, xw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -626,11 +638,11 @@ def main(argv=None):
             cal = 2.0 * Mr2 * Kc * Nc / (e0.elapsed_time(e1) / 10) / 1e9
             del xa, xw
             roofline["calibrated_peak"] = round(cal, 1)
-            roofline["calibrated_peak_note"] = (f"torch.matmul (hipBLASLt) bf16 [{Mr2} x {Kc}] x [{Kc} x {Nc}] (the FF1 shape, no epilogue), 10 launches, same process / box, "
+            roofline["calibrated_peak_note"] = (f"torch.matmul (hipBLASLt) {args.dtype} [{Mr2} x {Kc}] x [{Kc} x {Nc}] (the FF1 shape, no epilogue), 10 launches, same process / box, "
                                                 "right after the profile pass; fp8 GEMM classes are held against twice this figure")
             for name, e in per_kernel.items():
                 if "tflops" in e:
-                    e["frac_of_calibrated"] = round(e["tflops"] / (cal * e["peak_tflops"] / PEAK_BF16_TFLOPS), 4)
+                    e["frac_of_calibrated"] = round(e["tflops"] / (cal * e["peak_tflops"] / PEAK_DT), 4)
             roofline["frac_of_calibrated"] = per_kernel[dom].get("frac_of_calibrated")
             roofline["shader_clock_mhz"] = per_kernel[dom].get("shader_clock_mhz")
             roofline["frac_of_peak_at_measured_clock"] = per_kernel[dom].get("frac_of_peak_at_measured_clock")
@@ -760,7 +772,7 @@ def main(argv=None):
             "n_gpus": n_devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": ("fp8 (e4m3 W8A8 block linears, MX e4m3 QK^T) + bf16" if eng.fp8_qk_active else "fp8 (e4m3 W8A8 block linears) + bf16") if fp8 else "bf16", "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
+            "dtype": ("fp8 (e4m3 W8A8 block linears, MX e4m3 QK^T) + bf16" if eng.fp8_qk_active else "fp8 (e4m3 W8A8 block linears) + bf16") if fp8 else args.dtype, "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
             "config": {"workload": args.workload, "latent_frames": F, "latent_hw": [H, W], "tokens": T + (F + 1) * (H // 2) * (W // 2),
                        "cfg_pair": 2, "scheduler": "ddim-trailing-50", "weight_format": cfg.weight_format, "fp8_qk_active": eng.fp8_qk_active if fp8 else None, "attn_p_format": cfg.attn_p_format if cfg.attn_p_format != "auto" else f"auto -> {eng.attn_p_format}",
                        "attn_slow_path_fraction": eng.attn_slow_fraction, "parallelism": f"replicas x{world}",
