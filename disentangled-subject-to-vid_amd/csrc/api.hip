@@ -702,7 +702,7 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
         q.qkv = c->QKV; q.ld_qkv = 3 * D; q.B = c->B; q.H = c->cfg.num_heads; q.Ntok = c->Ntok; q.text_len = c->T;
         q.nq_w = w.nq_w; q.nq_b = w.nq_b; q.nk_w = w.nk_w; q.nk_b = w.nk_b; q.eps = 1e-6f;
         q.cos = c->have_rope ? c->rope_cos : nullptr; q.sin = c->have_rope ? c->rope_sin : nullptr;
-        q.vt = c->mfma ? c->VT : nullptr; q.ntok_pad = c->ntok_pad; q.vt_f16 = p16 ? 1 : 0;
+        q.vt = (c->mfma || c->h16) ? c->VT : nullptr; q.ntok_pad = c->ntok_pad; q.vt_f16 = p16 ? 1 : 0;  // fp16 dtype: the pass moves fp16 bits
         ProfScope ps(c, PK_QKNORM, st);
         S2V_TRY(launch_qk_norm_rope(q, c->dtype, st));
     }
@@ -729,6 +729,7 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     ProfScope ps(c, PK_ATTN, st);
     a.clk = c->clk_cur;
     if (c->mfma) S2V_TRY(launch_attn_bf16(a, st));
+    else if (c->h16) S2V_TRY(launch_attn_f16(a, st));   // fp16 dtype: q, k, V^T, P in fp16 on v_mfma_f32_32x32x16_f16
     else S2V_TRY(launch_attn_simple(a, c->dtype, st));
     return 0;
 }
@@ -1189,6 +1190,12 @@ extern "C" int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, in
         S2V_TRY(launch_v_transpose(qkv, 3 * D, B, H, Ntok, vt_scratch, a.ntok_pad, st, a.p16 != 0));
         if (impl == 4) return launch_attn_q4h(a, false, st);
         return launch_attn_bf16(a, st);
+    }
+    if (impl == 6) {  // fp16 on v_mfma_f32_32x32x16_f16 (what the fp16 engine runs); vt_scratch as for impl 0
+        S2V_REQUIRE(dtype == S2V_DTYPE_F16 && vt_scratch, "s2v_op_attention: impl 6 is fp16 and needs vt_scratch");
+        a.vt = vt_scratch;
+        S2V_TRY(launch_v_transpose(qkv, 3 * D, B, H, Ntok, vt_scratch, a.ntok_pad, st, false));
+        return launch_attn_f16(a, st);
     }
     if (impl == 5) {  // fp32 on the fp32 matrix pipe (what the fp32 engine runs)
         S2V_REQUIRE(dtype == S2V_DTYPE_F32 || dtype == S2V_DTYPE_F16, "s2v_op_attention: impl 5 is fp32 / fp16 only");

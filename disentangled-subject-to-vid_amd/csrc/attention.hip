@@ -20,6 +20,7 @@
 #define S2V_HOST
 #include "common.h"
 #include "kernels.h"
+#include <type_traits>
 
 #define KV_TILE 64
 #define Q_BLOCK 128
@@ -35,7 +36,7 @@ __device__ __forceinline__ float max3f(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-#ifdef S2V_DIAG  // ---- A/B reference kernels (diagnostics library only) ----
+// ---- the lock-step kernel: A/B reference in bf16 (diagnostics library), the fp16 model dtype's attention in the product (T16 = f16_t) ----
 template <int NT>
 __device__ __forceinline__ void stage64(const bf16_t* __restrict__ g, size_t ld, char* lds, int tid) {
     // 64 rows x 128 B; 512 chunks of 16 B; 512 / NT rounds of NT threads.  The address is written as
@@ -64,9 +65,14 @@ __device__ __forceinline__ bf16x8 frag64(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + row * 128 + ((cl ^ ((row >> 1) & 7)) << 4));
 }
 
-// round-1 lock-step kernel (A/B reference of tools/attn_harness); ABL is unused
-template <int ABL, int NW = 8>
+// round-1 lock-step kernel (A/B reference of tools/attn_harness); ABL is unused.
+// T16 = f16_t (round 5): the attention of the fp16 model dtype (src/inference.py:191) -- q, k, V^T and P in fp16 on v_mfma_f32_32x32x16_f16, output
+// fp16.  This kernel takes a true per-tile row maximum, so p <= 1 and nothing can leave the fp16 range; staging, swizzle and fragment reads move
+// 16-bit elements whatever they encode.  ~1 PFLOP/s at C3 in bf16 (9.2-9.4 ms, profiles/r02_attn_harness.txt): not the tuned asm kernel, but an
+// order of magnitude above the fp32-pipe kernel the fp16 dtype started on.
+template <int ABL, int NW = 8, typename T16 = bf16_t>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int nqb) {
+    constexpr bool H16 = std::is_same<T16, f16_t>::value;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K tile | VT tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 31, hi = lane >> 5;
@@ -93,9 +99,20 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         qf[kk] = *(const bf16x8*)(qkv + (size_t)q_ld * a.ld_qkv + h * 64 + kk * 16 + hi * 8);
+        if constexpr (H16) {
+            f16x8 qh = __builtin_bit_cast(f16x8, qf[kk]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) qf[kk][e] = (__bf16)((float)qf[kk][e] * c0);
+            for (int e = 0; e < 8; ++e) qh[e] = (_Float16)((float)qh[e] * c0);
+            qf[kk] = __builtin_bit_cast(bf16x8, qh);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[kk][e] = (__bf16)((float)qf[kk][e] * c0);
+        }
     }
+    auto mfma16 = [](bf16x8 x, bf16x8 y, f32x16 acc) __attribute__((always_inline)) {
+        if constexpr (H16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), acc, 0, 0, 0);
+        else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+    };
 
     f32x16 ot[2];
 #pragma unroll
@@ -127,10 +144,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
         f32x16 st[2];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag64(tK, kb * 32 + fr, hi), qf[0], negm16, 0, 0, 0);
+            st[kb] = mfma16(frag64(tK, kb * 32 + fr, hi), qf[0], negm16);
 #pragma unroll
-            for (int kk = 1; kk < 4; ++kk)
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag64(tK, kb * 32 + fr, kk * 2 + hi), qf[kk], st[kb], 0, 0, 0);
+            for (int kk = 1; kk < 4; ++kk) st[kb] = mfma16(frag64(tK, kb * 32 + fr, kk * 2 + hi), qf[kk], st[kb]);
         }
         if (kv0 + KV_TILE > a.Ntok) {  // tail tile: mask keys >= Ntok
 #pragma unroll
@@ -183,12 +199,19 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
         for (int s = 0; s < 4; ++s) {
             const int kb = s >> 1, r0 = (s & 1) * 8;
             bf16x8 pf;
+            if constexpr (H16) {
+                f16x8 ph;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) pf[e] = (__bf16)st[kb][r0 + e];
+                for (int e = 0; e < 8; ++e) ph[e] = (_Float16)st[kb][r0 + e];
+                pf = __builtin_bit_cast(bf16x8, ph);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (__bf16)st[kb][r0 + e];
+            }
 #pragma unroll
             for (int db = 0; db < 2; ++db) {
                 bf16x8 vf = frag64(tV, db * 32 + fr, s * 2 + hi);
-                ot[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, ot[db], 0, 0, 0);
+                ot[db] = mfma16(vf, pf, ot[db]);
             }
         }
         __syncthreads();
@@ -204,8 +227,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
             for (int rq = 0; rq < 4; ++rq) {
                 const int d = db * 32 + 8 * rq + 4 * hi;
                 u32x2 p;
-                p.x = pack2bf(ot[db][rq * 4 + 0] * inv, ot[db][rq * 4 + 1] * inv);
-                p.y = pack2bf(ot[db][rq * 4 + 2] * inv, ot[db][rq * 4 + 3] * inv);
+                if constexpr (H16) {
+                    p.x = pack2h(ot[db][rq * 4 + 0] * inv, ot[db][rq * 4 + 1] * inv);
+                    p.y = pack2h(ot[db][rq * 4 + 2] * inv, ot[db][rq * 4 + 3] * inv);
+                } else {
+                    p.x = pack2bf(ot[db][rq * 4 + 0] * inv, ot[db][rq * 4 + 1] * inv);
+                    p.y = pack2bf(ot[db][rq * 4 + 2] * inv, ot[db][rq * 4 + 3] * inv);
+                }
                 *(u32x2*)(o + d) = p;
             }
     }
@@ -240,7 +268,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_k(const AttnArgs a, int 
 // MFMAs (+3 %) or in S (+4 %), dedicated loader waves (three waves per SIMD force 168 registers and drop the fragment
 // prefetch: +2 %), bounded scores with no maximum at all and the row sums on the matrix pipe (20 MFMA per tile: -1.5 %, not
 // worth its precondition).
-#endif  // S2V_DIAG (attn_pp below is product code again: the short-sequence kernel, see launch_attn_bf16)
+// (attn_pp below: the bf16 short-sequence kernel, see launch_attn_bf16)
 __device__ long long g_attn_dbg[64];  // ACCT: per-wave s_memtime totals of block 100
 __device__ long long g_attn_blk[2 * 8192];  // ACCT: s_memrealtime at entry / exit of every workgroup (timeline of a launch)
 #ifdef S2V_DIAG
@@ -634,6 +662,16 @@ __global__ __launch_bounds__(256) void attn_simple_k(const AttnArgs a) {
         }
     }
     if (active) ET<T>::st((T*)a.out + (size_t)(b * a.Ntok + q) * a.ld_out + h * 64 + lane, o / l);
+}
+
+// fp16 model dtype: qkv / out fp16, a.vt = V^T [B][H][64][ntok_pad] fp16 in the k-slot order (launch_v_transpose moves 16-bit elements: the bf16
+// pass serves fp16 input unchanged)
+int launch_attn_f16(const AttnArgs& a, hipStream_t st) {
+    S2V_REQUIRE(a.vt != nullptr && a.ntok_pad % 64 == 0 && a.ld_qkv % 8 == 0, "attn_f16: V^T scratch / padding / leading dimension");
+    const int nqb = (a.Ntok + 255) / 256, total = nqb * a.B * a.H;
+    hipLaunchKernelGGL((attn_bf16_k<0, 8, f16_t>), dim3(total), dim3(512), 4 * ATT_TILE_BYTES, st, a, nqb);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st) {

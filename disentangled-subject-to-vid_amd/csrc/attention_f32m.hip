@@ -23,7 +23,8 @@
 #define AKT_PITCH 40  // floats per d-row of the K^T image (32 keys + 8: the two d-rows of a fragment read differ by 40 = 8 mod 32 banks)
 #define AV_PITCH 72   // floats per key row of the V image (rows k and k + 4 of a fragment read: 288 = 32 mod 64 banks)
 
-// T = float, or f16_t: the fp16 model dtype (src/inference.py:191,209).  fp16 values convert exactly to fp32 and so do their products, so
+// T = float, or f16_t: fp16 storage (the fp16 ENGINE runs launch_attn_f16, the fp16-MFMA kernel of attention.hip; this form stays as the
+// higher-accuracy operator-level reference, s2v_op_attention impl 5).  fp16 values convert exactly to fp32 and so do their products, so
 // QK^T is what an fp16 MFMA with fp32 accumulation would return; the probabilities are rounded to fp16 before P.V (the row sum is taken
 // before that rounding) -- the points at which torch's CPU flash kernel rounds for a reduced-precision dtype -- and the output is stored
 // as fp16.

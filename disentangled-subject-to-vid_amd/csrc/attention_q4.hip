@@ -304,11 +304,13 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
     // K / V^T tiles, and every item costs the same -- started together they request each tile within the latency of its first miss.  With
     // a.stagger > 0 slot s of the XCD starts s * stagger * 64 cycles late, once per launch: a convoy in which the leader misses in L2 and the
     // followers find the tile there.  0 = start together (the default; profiles/r05_attn_stagger.txt for what it measured).
+#ifndef S2V_NO_CLK_STAMP
     if (a.stagger > 0) {
         const int slot = (int)(blockIdx.x >> 3);
         for (int i = 0; i < slot * a.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
         if ((slot * a.stagger) & 63) __builtin_amdgcn_s_sleep(1);
     }
+#endif
     for (;;) {
         if (threadIdx.x == 0) {
             int wg = -1;

@@ -215,6 +215,9 @@ __device__ __forceinline__ void glds16_saddr_m0_imm(const char* sbase, unsigned 
 // from the same CU (the counters are per CU / XCD, not chip-synchronous: stamps from neighbouring launches disagree by millions of cycles).
 // clk == nullptr (every launch but the profile pass): one scalar compare.
 __device__ __forceinline__ void clk_stamp(long long* clk, unsigned designated_wg, int which) {
+#ifdef S2V_NO_CLK_STAMP   // tools: a build without the stamps, for the same-box A/B that shows they cost nothing
+    return;
+#endif
     if (clk != nullptr && blockIdx.x == designated_wg && threadIdx.x == 0) {
         clk[2 * which] = (long long)__builtin_amdgcn_s_memtime();
         clk[2 * which + 1] = (long long)__builtin_amdgcn_s_memrealtime();

@@ -542,7 +542,7 @@ int launch_qk_norm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t st) {
     S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(qk_norm_rope_k<T>, grid, dim3(256), 0, st, a))
     S2V_CHECK_HIP(hipGetLastError());
     if (a.vt != nullptr) {
-        S2V_REQUIRE(dtype == S2V_BF16, "V^T is only produced on the bf16 path");
+        S2V_REQUIRE(dtype == S2V_BF16 || (dtype == S2V_F16 && !a.vt_f16), "V^T is produced for 16-bit storage only (fp16 rows are moved as they are)");
         S2V_TRY(launch_v_transpose(a.qkv, a.ld_qkv, a.B, a.H, a.Ntok, a.vt, a.ntok_pad, st, a.vt_f16 != 0));
     }
     return 0;

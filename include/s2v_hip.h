@@ -345,7 +345,7 @@ S2V_API int s2v_op_mod_gemv(const void* emb, const void* W, const void* bias, vo
 S2V_API int s2v_attn_slow_stats(s2v_ctx* ctx, uint64_t* slow, uint64_t* total, int32_t reset);
 S2V_API int s2v_set_attn_p_format(s2v_ctx* ctx, int32_t attn_p_format);
 S2V_API int s2v_op_attention(const void* qkv, void* vt_scratch, void* out, int32_t B, int32_t H, int32_t Ntok, int32_t dtype,
-                     int32_t impl, s2v_stream stream);   /* impl: 0 product dispatch (bf16), 1 generic (VALU), 3 = 0 with attn_p_format 1, 4 = attn_q4h (fp16 P) at any length, 5 = fp32 / fp16 storage on the fp32 matrix pipe (what the fp32 and fp16 engines run) */
+                     int32_t impl, s2v_stream stream);   /* impl: 0 product dispatch (bf16), 1 generic (VALU), 3 = 0 with attn_p_format 1, 4 = attn_q4h (fp16 P) at any length, 5 = fp32 / fp16 storage on the fp32 matrix pipe (what the fp32 engine runs), 6 = fp16 on v_mfma_f32_32x32x16_f16 (what the fp16 engine runs; vt scratch as impl 0) */
 /* The same joint attention (F.scaled_dot_product_attention at attention_processor.py:2083-2087, head_dim 64, scale 1/8) as weight_format 2
  * runs it: q (times scale * log2 e) and k of the bf16 qkv rows [B*Ntok, 3*H*64] are quantised to MX e4m3 (32-element blocks along the
  * head dimension, E8M0 scales) into `scratch` and QK^T runs on v_mfma_scale_f32_32x32x64_f8f6f4; V^T (vt_scratch: B*H*64*rup(Ntok,64)
