@@ -46,6 +46,7 @@ struct s2v_ctx {
     s2v_model_config cfg;
     int D = 0, L = 0, dtype = 0, esz = 0, temb = 0;
     bool mfma = false;
+    int attn_order = 0;          // AttnArgs::order (S2V_ATTN_ORDER at s2v_create: an experiment knob, default 0)
     int attn_stagger = 0;        // AttnArgs::stagger (S2V_ATTN_STAGGER at s2v_create: an experiment knob, default 0)
     bool h16 = false;            // fp16 model dtype: linears on v_mfma_f32_32x32x16_f16 (gemm_f16), attention on attn_f32m<f16_t>
     int mc = 6;                  // modulation chunks per norm{1,2}.linear in the stack: 6, or 9 under lora_adaln_scope = 1 (+ the
@@ -179,6 +180,7 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     c->mfma = (cfg->dtype == S2V_DTYPE_BF16) && !cfg->force_simple;
     c->h16 = (cfg->dtype == S2V_DTYPE_F16) && !cfg->force_simple;
     if (const char* e = getenv("S2V_ATTN_STAGGER")) c->attn_stagger = atoi(e);
+    if (const char* e = getenv("S2V_ATTN_ORDER")) c->attn_order = atoi(e) ? 1 : 0;
     if (hipMalloc((void**)&c->attn_stats, 4096) != hipSuccess || hipMemset(c->attn_stats, 0, 4096) != hipSuccess) {
         s2v_destroy(c);
         return s2v_fail(__FILE__, __LINE__, "s2v_create: attention census allocation failed", -2);
@@ -714,6 +716,7 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     a.stats = c->attn_stats;
     a.valu_only = c->cfg.force_simple;
     a.stagger = c->attn_stagger;
+    a.order = c->attn_order;
     if (attn_mx_out(c)) { a.mx_q = (unsigned char*)c->aq; a.mx_s = c->hs; a.mx_rows = (int)c->Mpad; }
     if (c->fp8_qk) {  // weight_format 2: q (times scale * log2 e) and k as MX e4m3, QK^T on the scaled fp8 MFMA (the pass is timed with the V^T pass)
         {

@@ -317,10 +317,17 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
             for (int k = 0; k < 8 && wg < 0; ++k) {
                 const int y = (xcd + k) & 7;
                 int first, cnt;
-                attn_xcd_range(total, y, first, cnt);
+                // a.order 0: XCD y owns a contiguous range of items (a head's q-blocks stay on one XCD); 1 (experiment, round 5): a head's q-blocks
+                // are dealt round-robin over the XCDs (q-block qb on XCD qb & 7), so all 32 workgroups of an XCD are on the SAME head at any time
+                const int per = a.order ? (nqb > y ? (nqb - y + 7) >> 3 : 0) : 0;
+                if (a.order) { first = 0; cnt = (total / nqb) * per; }
+                else attn_xcd_range(total, y, first, cnt);
                 if (__hip_atomic_load(&queue[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cnt) continue;
                 const int i = atomicAdd(&queue[y], 1);
-                if (i < cnt) wg = first + i;
+                if (i < cnt) {
+                    if (a.order) { const int bh = i / per, j = i - bh * per; wg = bh * nqb + y + 8 * j; }
+                    else wg = first + i;
+                }
             }
             s_item = wg;
         }

@@ -148,6 +148,7 @@ struct AttnArgs {
     // [2 s] += slow paths taken, [2 s + 1] += (wave, KV tile) pairs run.  The engine reads it to decide whether fp16 P pays on the data at hand.
     unsigned long long* stats;
     long long* clk;            // profile pass only: shader-clock stamp slot (common.h clk_stamp; the four-wave kernels), else null
+    int order;                 // persistent four-wave launch: 0 = a head's q-blocks on one XCD (default), 1 = dealt over the XCDs (experiment, attn_qx_persist_k)
     int stagger;               // persistent four-wave launch: workgroup (blockIdx >> 3) = slot s of its XCD starts s * stagger * 64 cycles late (0 = together); see attn_qx_persist_k
     int valu_only;             // fp32 only: stay on attn_simple_k (cfg.force_simple) instead of the fp32-MFMA kernel attn_f32m_k
 };
