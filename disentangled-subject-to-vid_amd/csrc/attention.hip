@@ -668,6 +668,9 @@ __global__ __launch_bounds__(256) void attn_simple_k(const AttnArgs a) {
 // pass serves fp16 input unchanged)
 int launch_attn_f16(const AttnArgs& a, hipStream_t st) {
     S2V_REQUIRE(a.vt != nullptr && a.ntok_pad % 64 == 0 && a.ld_qkv % 8 == 0, "attn_f16: V^T scratch / padding / leading dimension");
+    // long sequences: the four-wave generated-asm kernel (fp16 q / k / P: attn_q4hh), persistent when the caller brought a queue; short ones
+    // (where attn_q4's long pipeline does not pay, as in bf16) the lock-step kernel below
+    if (a.Ntok > ATTN_PP_MAX_TOKENS) return launch_attn_q4hh(a, a.queue != nullptr && a.num_cus >= 8, st);
     const int nqb = (a.Ntok + 255) / 256, total = nqb * a.B * a.H;
     hipLaunchKernelGGL((attn_bf16_k<0, 8, f16_t>), dim3(total), dim3(512), 4 * ATT_TILE_BYTES, st, a, nqb);
     S2V_CHECK_HIP(hipGetLastError());

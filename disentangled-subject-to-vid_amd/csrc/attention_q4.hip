@@ -70,9 +70,12 @@ extern "C" __attribute__((visibility("default"))) int s2v_attn_slow_read(unsigne
 // kernel's.  No reference code for it (the reference has no fp8 path): parity unpinned, selected only by weight_format 2.
 // P16 (JB = 2 only, attn_q4h / attn_q4fh): P and V^T in fp16, row sums by packed fp16 adds, deferred maximum 2^14 (gen_attn_q4.py, P16); the
 // code around the body is the same -- the format lives in the V^T buffer (AttnArgs::p16) and in the generated instructions.
-template <int JB, bool F8 = false, bool P16 = false>
+// H16 (JB = 2, with P16, not F8: attn_q4hh): the fp16 model dtype -- q, k and the output are fp16 as well; only the QK^T mnemonic of the body differs from
+// attn_q4h's, and the code around it converts q and packs O as fp16.
+template <int JB, bool F8 = false, bool P16 = false, bool H16 = false>
 __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg, char* smem, unsigned& slow_acc, unsigned& tile_acc) {
     static_assert((!F8 && !P16) || JB == 2, "the fp8 QK^T and fp16 P bodies exist for the four-wave form only");
+    static_assert(!H16 || (P16 && !F8), "fp16 q / k come with fp16 P and bf16-free MFMAs only");
     constexpr int NW = 8 / JB;  // waves per work item
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -148,7 +151,14 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
             for (int kk = 0; kk < 4; ++kk) {
                 const bf16x8 q = *(const bf16x8*)(qkv + (size_t)q_ld * a.ld_qkv + h * 64 + kk * 16 + hi * 8);
 #pragma unroll
-                for (int e = 0; e < 8; e += 2) qf[16 * j + 4 * kk + (e >> 1)] = pack2bf((float)q[e] * c0, (float)q[e + 1] * c0);
+                for (int e = 0; e < 8; e += 2) {
+                    if constexpr (H16) {
+                        const f16x8 qh = __builtin_bit_cast(f16x8, q);
+                        qf[16 * j + 4 * kk + (e >> 1)] = pack2h((float)qh[e] * c0, (float)qh[e + 1] * c0);
+                    } else {
+                        qf[16 * j + 4 * kk + (e >> 1)] = pack2bf((float)q[e] * c0, (float)q[e + 1] * c0);
+                    }
+                }
             }
         }
     }
@@ -187,6 +197,12 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
                 : Q4F_QF(qf), Q4F_VIN(vin), Q4F_SIN(sin), Q4F_QS(qs), Q4F_KIN(kin), Q4F_KSB(ksbp)
                 : Q4F_CLOBBERS);
         }
+    } else if constexpr (H16) {
+        asm volatile(
+#include "attn_q4hh_body.inc"
+            : "=" Q4HH_OT0(OT[0]), "=" Q4HH_OT1(OT[JB - 1]), "=" Q4HH_LRUN(LR), "+" Q4HH_PTR(ptr), "=" Q4HH_CNT(slow_cnt)
+            : Q4HH_QF(qf), Q4HH_VIN(vin), Q4HH_SIN(sin)
+            : Q4HH_CLOBBERS);
     } else if constexpr (P16) {
         asm volatile(
 #include "attn_q4h_body.inc"
@@ -224,8 +240,13 @@ __device__ __forceinline__ void attn_qx_item(const AttnArgs& a, int nqb, int wg,
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int db = g >> 2, rq = g & 3;
-            og[g].x = pack2bf(OT[j][16 * db + rq * 4 + 0] * inv, OT[j][16 * db + rq * 4 + 1] * inv);
-            og[g].y = pack2bf(OT[j][16 * db + rq * 4 + 2] * inv, OT[j][16 * db + rq * 4 + 3] * inv);
+            if constexpr (H16) {
+                og[g].x = pack2h(OT[j][16 * db + rq * 4 + 0] * inv, OT[j][16 * db + rq * 4 + 1] * inv);
+                og[g].y = pack2h(OT[j][16 * db + rq * 4 + 2] * inv, OT[j][16 * db + rq * 4 + 3] * inv);
+            } else {
+                og[g].x = pack2bf(OT[j][16 * db + rq * 4 + 0] * inv, OT[j][16 * db + rq * 4 + 1] * inv);
+                og[g].y = pack2bf(OT[j][16 * db + rq * 4 + 2] * inv, OT[j][16 * db + rq * 4 + 3] * inv);
+            }
         }
         u32x4 vv[4];  // the lane's 8-column groups: columns 16 u + 8 hi .. + 7 of the head, u = 0 .. 3
 #pragma unroll
@@ -282,18 +303,18 @@ __device__ __forceinline__ void attn_report(const AttnArgs& a, unsigned slow, un
         atomicAdd(s + 1, (unsigned long long)tiles);
     }
 }
-template <int JB, bool F8 = false, bool P16 = false>
+template <int JB, bool F8 = false, bool P16 = false, bool H16 = false>
 __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_k(const AttnArgs a, int nqb) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [4 slots][K tile | VT tile]
     int first, cnt;
     clk_stamp(a.clk, gridDim.x >> 1, 0);
     attn_xcd_range((int)gridDim.x, blockIdx.x & 7, first, cnt);
     unsigned slow = 0, tiles = 0;
-    attn_qx_item<JB, F8, P16>(a, nqb, first + (int)(blockIdx.x >> 3), smem, slow, tiles);
+    attn_qx_item<JB, F8, P16, H16>(a, nqb, first + (int)(blockIdx.x >> 3), smem, slow, tiles);
     attn_report(a, slow, tiles);
     clk_stamp(a.clk, gridDim.x >> 1, 1);
 }
-template <int JB, bool F8 = false, bool P16 = false>
+template <int JB, bool F8 = false, bool P16 = false, bool H16 = false>
 __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const AttnArgs a, int nqb, int total, int* __restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int s_item;
@@ -335,7 +356,7 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
         const int wg = s_item;
         __syncthreads();
         if (wg < 0) break;
-        attn_qx_item<JB, F8, P16>(a, nqb, wg, smem, slow, tiles);
+        attn_qx_item<JB, F8, P16, H16>(a, nqb, wg, smem, slow, tiles);
     }
     attn_report(a, slow, tiles);
     clk_stamp(a.clk, 0, 1);
@@ -348,21 +369,21 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
     }
 }
 
-template <int JB, bool F8 = false, bool P16 = false>
+template <int JB, bool F8 = false, bool P16 = false, bool H16 = false>
 static int launch_attn_qx(const AttnArgs& a, bool persistent, hipStream_t st) {
     const int nqb = (a.Ntok + 255) / 256;  // 256 query rows per item in both forms
     const int total = nqb * a.B * a.H;
     const size_t lds = 65536;
     const dim3 blk(64 * (8 / JB));
     if (persistent && a.queue != nullptr && a.num_cus >= 8) {
-        const void* fn = (const void*)attn_qx_persist_k<JB, F8, P16>;
+        const void* fn = (const void*)attn_qx_persist_k<JB, F8, P16, H16>;
         S2V_TRY(ensure_lds_attr(fn, 65536));
         int* queue = a.queue;
         void* args[] = {(void*)&a, (void*)&nqb, (void*)&total, (void*)&queue};
         S2V_CHECK_HIP(hipLaunchKernel(fn, dim3((a.num_cus / 8) * 8), blk, args, lds, st));
         return 0;
     }
-    const void* fn = (const void*)attn_qx_k<JB, F8, P16>;
+    const void* fn = (const void*)attn_qx_k<JB, F8, P16, H16>;
     S2V_TRY(ensure_lds_attr(fn, 65536));
     void* args[] = {(void*)&a, (void*)&nqb};
     S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(total), blk, args, lds, st));
@@ -373,6 +394,11 @@ int launch_attn_q8(const AttnArgs& a, bool persistent, hipStream_t st) { return 
 int launch_attn_q4f(const AttnArgs& a, bool persistent, hipStream_t st) {
     S2V_REQUIRE(a.q8 && a.k8 && a.q8s && a.k8s && a.vt, "attn_q4f: the MX images of q / k (launch_qk_quant_mx) and V^T are required");
     return a.p16 ? launch_attn_qx<2, true, true>(a, persistent, st) : launch_attn_qx<2, true>(a, persistent, st);
+}
+// fp16 model dtype: qkv / out fp16, a.vt = fp16 V^T (the transpose pass moves the bits); the four-wave kernel with fp16 q, k, P
+int launch_attn_q4hh(const AttnArgs& a, bool persistent, hipStream_t st) {
+    S2V_REQUIRE(a.vt && a.mx_q == nullptr, "attn_q4hh: the fp16 V^T is required (and no MX output)");
+    return launch_attn_qx<2, false, true, true>(a, persistent, st);
 }
 int launch_attn_q4h(const AttnArgs& a, bool persistent, hipStream_t st) {
     S2V_REQUIRE(a.p16 && a.vt, "attn_q4h: the fp16 V^T (launch_v_transpose(..., to_f16)) is required");

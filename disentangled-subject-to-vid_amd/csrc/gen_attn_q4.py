@@ -55,6 +55,9 @@ F8 = False
 #     is dropped only below 2^-25 of the weight of the row's maximum key, the whole tail of N <= 2^17 such keys weighs < 2^-8 of that key alone;
 #   * P keeps 11 significant bits (bf16: 8), V^T is converted bf16 -> fp16 by the transpose pass (exact above 2^-14).
 P16 = False
+# H16 (attn_q4hh_body.inc, JB = 2, with P16): q and k are fp16 too (the fp16 model dtype, src/inference.py:191) -- QK^T on v_mfma_f32_32x32x16_f16.  The
+# register map, the schedule and every other instruction are attn_q4h's: staging and fragment reads move 16-bit elements whatever they encode.
+H16 = False
 # Deferred maximum: a row keeps the maximum its first tile adopted until a partial row sum of a later tile exceeds 2^64, i.e. until some
 # p = exp2(s - m) does -- fp32 and bf16 share the exponent range, sums and P.V stay below 2^64 * N * |v| << 2^127, and every quantity is
 # scale-free, so nothing is lost by letting m lag (keys 2^126 below the adopted maximum flush to zero, as they would below any maximum).
@@ -91,8 +94,9 @@ S_KPTR, S_VPTR, S_T, S_END, S_KADV, S_VADV, S_NT, S_KSTR, S_NTOK, S_M0W, S_THR, 
 S_KSB, S_KSX, S_NTM1, S_KSA = 54, 56, 57, 58  # F8: IN K block-scale base (64-bit); scratch; nt - 1; address of the tile being loaded (64-bit)
 
 
-def layout(jb, f8=False, p16=False):
-    global JB, ST, NEGM, PK, TMP, PS, VIN, LRUN, VS, OT, QF, KF, VF, NM, F8, KS, QS, KIN, P16
+def layout(jb, f8=False, p16=False, h16=False):
+    global JB, ST, NEGM, PK, TMP, PS, VIN, LRUN, VS, OT, QF, KF, VF, NM, F8, KS, QS, KIN, P16, H16
+    H16 = h16
     JB = jb
     F8 = f8
     P16 = p16
@@ -269,7 +273,7 @@ def qk_mfma(buf, i):
     j, kb, kk = i % JB, (i // JB) & 1, i // (2 * JB)
     d = vr(st(buf, j, kb), 16)
     c = vr(NEGM + 16 * j, 16) if kk == 0 else d
-    return f"v_mfma_f32_32x32x16_bf16 {d}, {ar(KF + 4 * (kk * 2 + kb), 4)}, {ar(QF + 16 * j + 4 * kk, 4)}, {c}"
+    return f"v_mfma_f32_32x32x16_{'f16' if H16 else 'bf16'} {d}, {ar(KF + 4 * (kk * 2 + kb), 4)}, {ar(QF + 16 * j + 4 * kk, 4)}, {c}"
 
 
 def pv_mfma(i):
@@ -601,8 +605,9 @@ def main():
     here = os.path.dirname(os.path.abspath(__file__))
     with open(os.path.join(here, "attn_q4_regs.h"), "w") as f:
         f.write("// generated by gen_attn_q4.py: the physical registers the bodies of attn_q4 (JB = 2) / attn_q8 (JB = 1) own\n#pragma once\n")
-        for jb, name, f8, p16 in ((2, "Q4", False, False), (1, "Q8", False, False), (2, "Q4F", True, False), (2, "Q4H", False, True), (2, "Q4FH", True, True)):
-            layout(jb, f8, p16)
+        for jb, name, f8, p16, h16 in ((2, "Q4", False, False, False), (1, "Q8", False, False, False), (2, "Q4F", True, False, False), (2, "Q4H", False, True, False),
+                                       (2, "Q4FH", True, True, False), (2, "Q4HH", False, True, True)):
+            layout(jb, f8, p16, h16)
             with open(os.path.join(here, f"attn_{name.lower()}_body.inc"), "w") as g:
                 for ln in gen():
                     g.write('"' + ln + '\\n\\t"\n')

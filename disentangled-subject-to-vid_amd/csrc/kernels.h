@@ -170,7 +170,9 @@ int launch_attn_bf16(const AttnArgs& a, hipStream_t st);
 int launch_attn_simple(const AttnArgs& a, int dtype, hipStream_t st);
 int launch_attn_f32m(const AttnArgs& a, int dtype, hipStream_t st);
 // fp16 storage on v_mfma_f32_32x32x16_f16 (the lock-step kernel of attention.hip): what the fp16 engine runs; needs a.vt (fp16 V^T)
-int launch_attn_f16(const AttnArgs& a, hipStream_t st);  // dtype S2V_F32 or S2V_F16 (storage; the arithmetic is fp32 either way)
+int launch_attn_f16(const AttnArgs& a, hipStream_t st);
+// the four-wave asm kernel with fp16 q / k / V^T / P (attention_q4.hip, attn_q4hh); launch_attn_f16 routes long sequences to it
+int launch_attn_q4hh(const AttnArgs& a, bool persistent, hipStream_t st);  // dtype S2V_F32 or S2V_F16 (storage; the arithmetic is fp32 either way)
 // four-wave form of the bf16 kernel (attention_q4.hip); persistent needs a.queue / a.num_cus
 int launch_attn_q4(const AttnArgs& a, bool persistent, hipStream_t st);
 // eight waves x 32 rows running the same fine-grained stream, two waves per SIMD

@@ -244,6 +244,16 @@ def gen_vae():
         # a 2-frame latent (even branch everywhere) and a single-frame latent
         out["dec_2f"] = vae.decode(z[:, :, :2, :6, :8]).sample.numpy()
         out["dec_1f"] = vae.decode(z[:, :, :1, :6, :8]).sample.numpy()
+    # Round 5: the same decoder in bf16 and fp16 (src/inference.py:239 moves the VAE to the pipeline dtype): untiled decode of the first two
+    # latent frames of a 6 x 8 window, every pixel -- the reduced-precision rounding points of the conv / norm stack pinned to the reference
+    for dt_name, dt in (("bf16", torch.bfloat16), ("f16", torch.float16)):
+        vh = AutoencoderKLCogVideoX(**VAE_TINY).eval()
+        vh.load_state_dict(vae.state_dict())
+        vh = vh.to(dt)
+        with torch.no_grad():
+            yh = vh.decode(z[:, :, :2, :6, :8].to(dt)).sample
+        assert yh.dtype == dt and torch.isfinite(yh.float()).all()
+        out[f"dec_2f_{dt_name}"] = yh.float().numpy()
     from diffusers.video_processor import VideoProcessor
 
     vp = VideoProcessor(vae_scale_factor=8)
@@ -317,6 +327,9 @@ def gen_t5():
         mh.load_state_dict(m.state_dict())
         mh = mh.half()
         out["last_hidden_state_f16"] = mh(ids)[0].float().numpy()
+        mb = T5EncoderModel(T5Config(**T5_TINY)).eval()
+        mb.load_state_dict(m.state_dict())
+        out["last_hidden_state_bf16"] = mb.bfloat16()(ids)[0].float().numpy()
         key = "encoder.block.0.layer.1.DenseReluDense.wo.weight"
         sd2 = {k: v.clone() for k, v in m.state_dict().items()}
         sd2[key] = sd2[key] * 3.0e4

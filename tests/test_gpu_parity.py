@@ -705,6 +705,41 @@ def test_op_attention_fp16_p_moderate_jumps_and_tails_vs_fp64(s2v, spread):
     assert r4 <= max(1.5 * r0, 5e-3), (r0, r4)   # fp16 P (11 significant bits) is not less accurate than bf16 P (8)
 
 
+def test_fp16_engine_long_sequence_runs_the_four_wave_kernel_and_matches_fp32(s2v):
+    """fp16 model dtype at 5 127 tokens (> 4 608: launch_attn_f16 routes to attn_q4hh, the four-wave asm kernel with fp16 q / k / V^T / P, persistent
+    launch inside the engine) against the fp32 engine on the same fp16-representable weights: one forward, and graph replay == eager over three steps"""
+    cfg = s2v.tiny(use_rope=True, heads=4, layers=1, text_dim=128, temb=64)
+    cfg.max_text_seq_length = 7
+    g = torch.Generator().manual_seed(41)
+    F, H, W = 4, 64, 64
+    sd = {k: v.half().float() for k, v in s2v.weights.synthetic_state_dict(cfg, seed=6, parity=True).items()}
+    lat0 = torch.randn(1, F, 16, H, W, generator=g).half()
+    text = torch.randn(2, 7, 128, generator=g).half()
+    ref = (torch.randn(1, 1, 16, H, W, generator=g) * 0.7).half()
+    outs = {}
+    for dt in (torch.float16, torch.float32):
+        m = s2v.HipCogVideoXTransformer3DModel(cfg, dt, DEV)
+        m.load_state_dict(sd)
+        eng = m.engine
+        eng.set_geometry(2, 7, F, H, W)
+        eng.prepare_tables(H * 8, W * 8)
+        eng.set_conditioning(text.to(dt), ref.to(dt))
+        outs[dt] = eng.forward(lat0.to(dt), torch.tensor([500.0, 500.0]), shared_latent=True).float().cpu()
+        if dt == torch.float16:
+            sch = s2v.CogVideoXDDIMScheduler(snr_shift_scale=1.0)
+            sch.set_timesteps(50)
+            a, b = lat0.to(DEV).clone(), lat0.to(DEV).clone()
+            for x, graph in ((a, True), (b, False)):
+                for i in range(3):
+                    t_ = sch.timesteps[i]
+                    eng.denoise_step(x, float(t_), sch.coef(t_, dt, 6.0), use_graph=graph)
+            torch.cuda.synchronize()
+            assert torch.isfinite(a.float()).all() and torch.equal(a, b)
+            slow, total = eng.attn_slow_stats()
+            assert total > 0   # the four-wave kernel ran (the census is its own)
+    assert_close(outs[torch.float16], outs[torch.float32], "f16", "fp16 engine at 5127 tokens vs fp32 engine")
+
+
 def test_attn_q4h_saturates_v_beyond_the_fp16_range(s2v):
     """|V| > 65504 (finite in bf16) must not become an fp16 infinity in V^T -- 0 * inf in P.V would turn the head-dim column of EVERY
     query into NaN.  The fp16 V^T pass saturates; the result stays finite, and equals the bf16-P kernel's wherever the huge key carries no weight."""

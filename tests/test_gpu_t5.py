@@ -175,3 +175,17 @@ def test_t5_mfma_width_f16_vs_oracle(s2v, simple):
     rel = ((y - exp).norm() / exp.norm()).item()
     print(f"MEASURED t5 f16 mfma-width simple={simple}: rel-l2 {rel:.3e}")
     assert rel <= 2.3e-3, rel   # 2 x measured (1.1e-3)
+
+
+def test_t5_tiny_bf16_vs_transformers_golden(s2v):
+    """transformers' own bf16 run of the tiny encoder (fixture last_hidden_state_bf16, round 5).  Unscaled logits of magnitude ~100 make a score's
+    bf16 ulp 0.5: the bf16 CPU oracle itself sits at 4.3e-2 relative L2 from this fixture; bar 9e-2"""
+    g = load_golden("t5_tiny.npz")
+    m = s2v.HipT5EncoderModel(s2v.T5Config(**TINY), torch.bfloat16, DEV)
+    m.load_state_dict({a: b.bfloat16() for a, b in weights_of(g).items()})
+    y = m(t(g["input_ids"]).to(DEV))[0].float().cpu()
+    torch.cuda.synchronize()
+    exp = t(g["last_hidden_state_bf16"])
+    rel = ((y - exp).norm() / exp.norm()).item()
+    print(f"MEASURED t5 bf16 vs transformers: rel-l2 {rel:.3e}")
+    assert torch.isfinite(y).all() and rel <= 9e-2, rel

@@ -64,6 +64,25 @@ def test_vae_even_single_frame_and_postprocess_vs_reference_golden(s2v):
         vae.encode(lat)
 
 
+@pytest.mark.parametrize("dt_name", ["bf16", "f16"])
+def test_vae_tiny_reduced_precision_vs_reference_golden(s2v, dt_name):
+    """the reference decoder itself run in bf16 / fp16 on the CPU (fixtures dec_2f_bf16 / dec_2f_f16, round 5): the HIP decoder in that dtype on the
+    same latent window, every pixel.  (Tiny channel counts: these convolutions take the generic kernels; the MFMA widths are held to the oracle below.)"""
+    g = load_golden("vae_tiny.npz")
+    dt = {"bf16": torch.bfloat16, "f16": torch.float16}[dt_name]
+    vae = make_vae(s2v, TINY, dt, weights_of(g))
+    lat = t(g["latents"]).to(dt)[:, :2, :, :6, :8].contiguous().to(DEV)
+    y = vae.decode_latents(lat).float().cpu()
+    torch.cuda.synchronize()
+    exp = t(g[f"dec_2f_{dt_name}"])
+    assert y.shape == exp.shape and torch.isfinite(y).all()
+    rel = ((y - exp).double().norm() / exp.double().norm()).item()
+    err = (y - exp).abs().max().item() / exp.abs().max().item()
+    print(f"MEASURED vae tiny {dt_name} vs reference: rel-l2 {rel:.3e} max-abs/max|ref| {err:.3e}")
+    br, ba = (1.8e-2, 2.5e-2) if dt_name == "bf16" else (2.5e-3, 3.5e-3)  # the CPU oracle's own distance to these fixtures is 9.0e-3 / 1.2e-3
+    assert rel <= br and err <= ba, (rel, err)
+
+
 @pytest.mark.parametrize("dt_name,simple", [("bf16", False), ("bf16", True), ("f32", False)])
 @pytest.mark.parametrize("tiling", [False, True])
 def test_vae_mfma_channels_vs_oracle(s2v, dt_name, simple, tiling):

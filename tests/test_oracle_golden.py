@@ -266,6 +266,21 @@ VAE_CFG = dict(block_out_channels=(16, 16, 32, 32), layers_per_block=1, norm_num
                sample_height=96, sample_width=160, scaling_factor=0.7, temporal_compression_ratio=4)
 
 
+@pytest.mark.parametrize("dt_name,bar", [("bf16", 1.8e-2), ("f16", 2.5e-3)])
+def test_vae_decode_reduced_precision_vs_reference_golden(dt_name, bar):
+    """the reference decoder ITSELF in bf16 / fp16 on the CPU (round-5 fixtures dec_2f_{bf16,f16}; src/inference.py:239 moves the VAE to the pipeline
+    dtype): the oracle in that dtype agrees to 9.0e-3 / 1.2e-3 relative L2 (it composes the causal convolutions from differently shaped torch
+    calls, so the reduced-precision sums round differently); bars = 2 x that"""
+    g = load_golden("vae_tiny.npz")
+    dt = DT[dt_name]
+    lat = t(g["latents"], dt)[:, :2, :, :6, :8]
+    with torch.no_grad():
+        y = vae_ref.decode_latents(weights_of(g, dt), VAE_CFG, lat, False).float().numpy()
+    exp = g[f"dec_2f_{dt_name}"]
+    assert y.shape == exp.shape and np.isfinite(y).all()
+    assert np.linalg.norm(y - exp) / np.linalg.norm(exp) <= bar
+
+
 def test_vae_tile_geometry_of_the_real_config():
     tg = vae_ref.tile_geometry(dict(block_out_channels=(128, 256, 256, 512), sample_height=480, sample_width=720))
     assert tg == dict(tl_h=30, tl_w=45, ov_h=25, ov_w=36, bl_h=40, bl_w=72, lim_h=200, lim_w=288)
