@@ -61,7 +61,7 @@ def build_library(force=False, verbose=True, diag=False):
     FLAGS = globals()["FLAGS"] + (["-DS2V_DIAG"] if diag else [])
     # generated asm (outputs are committed): generator -> EVERY file it writes (a missing one of them re-runs the generator)
     gens = [("gen_attn_q4.py", ["attn_q4_body.inc", "attn_q4h_body.inc", "attn_q4f_body.inc", "attn_q4fh_body.inc", "attn_q4hh_body.inc", "attn_q8_body.inc", "attn_q4_regs.h"]),
-            ("gen_gemm_g4.py", ["gemm_g4_body.inc", "gemm_g4_sk_sum.inc", "gemm_g4_regs.h"]),
+            ("gen_gemm_g4.py", ["gemm_g4_body.inc", "gemm_g4_body_f16.inc", "gemm_g4_sk_sum.inc", "gemm_g4_regs.h"]),
             ("gen_gemm_g4t.py", ["gemm_g4t_body_gelu.inc", "gemm_g4t_body_bias.inc", "gemm_g4t_regs.h"]),
             ("gen_gemm_g4f.py", ["gemm_g4f_body_a3.inc", "gemm_g4f_body_mx.inc", "gemm_g4f_regs.h"])]
     headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith((".h", ".inc"))]

@@ -186,6 +186,12 @@ bool gemm_f16_ok(const GemmArgs& a, int epi) {
 }
 int launch_gemm_f16(const GemmArgs& a, int epi, hipStream_t st) {
     S2V_REQUIRE(gemm_f16_ok(a, epi), "gemm_f16: shape / padding not supported");
+    // more than one round of 256 x 256 tiles on the part: the four-wave generated-asm loop (gemm_g4 on fp16 operands); otherwise the 128 x 128 kernel
+    {
+        int dev = 0, ncu = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (gemm_g4_f16_ok(a, epi) && (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) >= ncu) return launch_gemm_g4_f16(a, epi, st);
+    }
     const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
     const dim3 grid(tiles_m * tiles_n);
     const size_t shmem = 4 * TILE_BYTES;

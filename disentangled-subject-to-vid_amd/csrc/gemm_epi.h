@@ -110,7 +110,22 @@ __device__ __forceinline__ void load_bias64(const GemmArgs& a, int nw, int hi, u
 // residual in that layout -> full-line global stores.  A row-per-lane epilogue (8-B stores at a row stride) was
 // store-issue bound: ~0.7 ms of a 3.4 ms FF1 launch.
 // GRP = rows-of-8 groups whose patch reads and gate / residual loads are in flight together (one memory latency per GRP groups)
-template <int EPI, int MB, bool SC = false, int GRP = 4>
+// one packed pair of 16-bit storage values <-> two floats: what the vector epilogue decodes and packs (round 5: the same epilogue serves the fp16
+// model dtype; for bf16 these are exactly the shifts / masks / v_cvt_pk_bf16_f32 the epilogue had inline)
+template <typename T16> struct H2;
+template <> struct H2<bf16_t> {
+    static __device__ __forceinline__ float lo(unsigned w) { return __uint_as_float(w << 16); }
+    static __device__ __forceinline__ float hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+    static __device__ __forceinline__ unsigned pack(float a, float b) { return pack2bf(a, b); }
+    static __device__ __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
+};
+template <> struct H2<f16_t> {
+    static __device__ __forceinline__ float lo(unsigned w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+    static __device__ __forceinline__ float hi(unsigned w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+    static __device__ __forceinline__ unsigned pack(float a, float b) { return pack2h(a, b); }
+    static __device__ __forceinline__ float rnd(float v) { return (float)(f16_t)v; }
+};
+template <int EPI, int MB, bool SC = false, int GRP = 4, typename T16 = bf16_t>
 __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 (&acc)[2][MB], int mw, int nw, char* patch, int lane,
                                                 const u32x2 (&bvec)[8]) {
     // MB 32-row blocks: the patch holds MB*32 rows of 128 B (8 KiB for MB = 2, 16 KiB for MB = 4); all accumulator blocks are
@@ -147,8 +162,8 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
         const u32x4 w4 = *(const u32x4*)((const bf16_t*)a.qk_w[which] + c16 * 8), b4 = *(const u32x4*)((const bf16_t*)a.qk_b[which] + c16 * 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            qw[2 * e] = __uint_as_float(w4[e] << 16); qw[2 * e + 1] = __uint_as_float(w4[e] & 0xffff0000u);
-            qb[2 * e] = __uint_as_float(b4[e] << 16); qb[2 * e + 1] = __uint_as_float(b4[e] & 0xffff0000u);
+            qw[2 * e] = H2<T16>::lo(w4[e]); qw[2 * e + 1] = H2<T16>::hi(w4[e]);
+            qb[2 * e] = H2<T16>::lo(b4[e]); qb[2 * e + 1] = H2<T16>::hi(b4[e]);
         }
         rot_load(0, 0);
     }
@@ -176,8 +191,8 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
             const u32x2 bq = bvec[i * 4 + rq];
             f32x4 sw = {1.f, 1.f, 1.f, 1.f};
             if (SC) sw = *(const f32x4*)(a.w_scale + nw + nl);  // the scale array is padded to the 256-column tile
-            const float bv[4] = {__uint_as_float(bq.x << 16), __uint_as_float(bq.x & 0xffff0000u), __uint_as_float(bq.y << 16),
-                                 __uint_as_float(bq.y & 0xffff0000u)};
+            const float bv[4] = {H2<T16>::lo(bq.x), H2<T16>::hi(bq.x), H2<T16>::lo(bq.y),
+                                 H2<T16>::hi(bq.y)};
 #pragma unroll
             for (int j = 0; j < MB; ++j) {
                 float y[4];
@@ -185,11 +200,11 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
                 for (int e = 0; e < 4; ++e) y[e] = (SC ? acc[i][j][rq * 4 + e] * (sa[j] * sw[e]) : acc[i][j][rq * 4 + e]) + bv[e];
                 const int row = j * 32 + fr;
                 u32x2 p;
-                p.x = pack2bf(y[0], y[1]);  // the linear's bf16 output (one rounding; a single wave per SIMD issues a VALU
-                p.y = pack2bf(y[2], y[3]);  // instruction every ~5 cycles, so the instruction count of this loop is its time)
+                p.x = H2<T16>::pack(y[0], y[1]);  // the linear's bf16 output (one rounding; a single wave per SIMD issues a VALU
+                p.y = H2<T16>::pack(y[2], y[3]);  // instruction every ~5 cycles, so the instruction count of this loop is its time)
                 if (EPI == EPI_BIAS_GELU) {  // GELU of the ROUNDED linear output, rounded again
-                    p.x = pack2bf(gelu_tanh_fast(__uint_as_float(p.x << 16)), gelu_tanh_fast(__uint_as_float(p.x & 0xffff0000u)));
-                    p.y = pack2bf(gelu_tanh_fast(__uint_as_float(p.y << 16)), gelu_tanh_fast(__uint_as_float(p.y & 0xffff0000u)));
+                    p.x = H2<T16>::pack(gelu_tanh_fast(H2<T16>::lo(p.x)), gelu_tanh_fast(H2<T16>::hi(p.x)));
+                    p.y = H2<T16>::pack(gelu_tanh_fast(H2<T16>::lo(p.y)), gelu_tanh_fast(H2<T16>::hi(p.y)));
                 }
                 *(u32x2*)(patch + row * 128 + ((((nl >> 3) ^ (row & 7))) << 4) + (nl & 4) * 2) = p;
             }
@@ -227,7 +242,7 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
             if (EPI == EPI_BIAS_QKNORM && qk_head) {  // qk_norm_rope_k's arithmetic on the rounded projection, lane = (row, octet)
                 float x[8];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) { x[2 * e] = __uint_as_float(v[u][e] << 16); x[2 * e + 1] = __uint_as_float(v[u][e] & 0xffff0000u); }
+                for (int e = 0; e < 4; ++e) { x[2 * e] = H2<T16>::lo(v[u][e]); x[2 * e + 1] = H2<T16>::hi(v[u][e]); }
                 float s = 0.f;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) s += x[e];
@@ -239,31 +254,31 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
                 q = oct_sum(q);
                 const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + a.qk_eps);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = bf2f(f2bf((x[e] - mean) * rstd * qw[e] + qb[e]));
+                for (int e = 0; e < 8; ++e) x[e] = H2<T16>::rnd(((x[e] - mean) * rstd * qw[e] + qb[e]));
                 if (rope[cur][u]) {
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) {
                         const float x0 = x[e], x1 = x[e + 1];
                         const float cc = rc[cur][u][e >> 1], ss = rs[cur][u][e >> 1];  // cos / sin of the pair (e, e + 1)
-                        x[e] = bf2f(f2bf(x0 * cc + (-x1) * ss));
-                        x[e + 1] = bf2f(f2bf(x1 * cc + x0 * ss));
+                        x[e] = H2<T16>::rnd((x0 * cc + (-x1) * ss));
+                        x[e + 1] = H2<T16>::rnd((x1 * cc + x0 * ss));
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = pack2bf(x[2 * e], x[2 * e + 1]);
+                for (int e = 0; e < 4; ++e) o[e] = H2<T16>::pack(x[2 * e], x[2 * e + 1]);
             }
             if (EPI == EPI_BIAS_GATE_RES) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t0 = bf2f(f2bf(__uint_as_float(g[u][e] << 16) * __uint_as_float(v[u][e] << 16)));
-                    const float t1 = bf2f(f2bf(__uint_as_float(g[u][e] & 0xffff0000u) * __uint_as_float(v[u][e] & 0xffff0000u)));
-                    o[e] = pack2bf(__uint_as_float(xo[u][e] << 16) + t0, __uint_as_float(xo[u][e] & 0xffff0000u) + t1);
+                    const float t0 = H2<T16>::rnd((H2<T16>::lo(g[u][e]) * H2<T16>::lo(v[u][e])));
+                    const float t1 = H2<T16>::rnd((H2<T16>::hi(g[u][e]) * H2<T16>::hi(v[u][e])));
+                    o[e] = H2<T16>::pack(H2<T16>::lo(xo[u][e]) + t0, H2<T16>::hi(xo[u][e]) + t1);
                 }
             } else if (EPI == EPI_BIAS_ADD) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    o[e] = pack2bf(__uint_as_float(v[u][e] << 16) + __uint_as_float(xo[u][e] << 16),
-                                   __uint_as_float(v[u][e] & 0xffff0000u) + __uint_as_float(xo[u][e] & 0xffff0000u));
+                    o[e] = H2<T16>::pack(H2<T16>::lo(v[u][e]) + H2<T16>::lo(xo[u][e]),
+                                   H2<T16>::hi(v[u][e]) + H2<T16>::hi(xo[u][e]));
             }
             if (EPI == EPI_BIAS_GELU && a.mx_out_q) {
                 // MX output (GemmArgs::mx_out_q): the lane's 8 values are a quarter of a 32-column block (lanes c16 & ~3 .. + 3 of
@@ -300,11 +315,11 @@ __device__ __forceinline__ void epilogue_wave_b(const GemmArgs& a, const f32x16 
         }
     }
 }
-template <int EPI, int MB, bool SC = false>
+template <int EPI, int MB, bool SC = false, typename T16 = bf16_t>
 __device__ __forceinline__ void epilogue_wave(const GemmArgs& a, const f32x16 (&acc)[2][MB], int mw, int nw, char* patch, int lane) {
     u32x2 bvec[8];
     load_bias64(a, nw, lane >> 5, bvec);
-    epilogue_wave_b<EPI, MB, SC, 4>(a, acc, mw, nw, patch, lane, bvec);
+    epilogue_wave_b<EPI, MB, SC, 4, T16>(a, acc, mw, nw, patch, lane, bvec);
 }
 template <int EPI>
 __device__ __forceinline__ void epilogue_wave64(const GemmArgs& a, const f32x16 (&acc)[2][2], int mw, int nw, char* patch,

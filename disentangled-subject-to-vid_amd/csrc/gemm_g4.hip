@@ -10,6 +10,7 @@
 #include "gemm_epi.h"
 #include "gemm_g4_regs.h"
 #include <cstdlib>
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(32))) float f32x32;
 typedef __attribute__((ext_vector_type(16))) unsigned int u32x16;
@@ -32,7 +33,9 @@ extern "C" __attribute__((visibility("default"))) int s2v_g4_debug_read(unsigned
 #define G4_STAMP(i) do { } while (0)
 #endif
 
-template <int EPI>
+// T16 = f16_t (round 5): the fp16 model dtype's linears -- the K loop with v_mfma_f32_32x32x16_f16 (gemm_g4_body_f16.inc: the same generated
+// statement, one mnemonic changed) and the shared vector epilogue decoding / packing fp16 (gemm_epi.h H2<T16>); no split K, no fused q/k norm
+template <int EPI, typename T16 = bf16_t>
 __global__ __launch_bounds__(256, 1) void gemm_g4(const GemmArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 stages x [A 256 rows x 128 B | W 256 rows x 128 B]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -108,12 +111,21 @@ __global__ __launch_bounds__(256, 1) void gemm_g4(const GemmArgs a, int tiles_m,
 
     G4_STAMP(1);
     f32x32 AC[8];  // acc[i][j] (i: 32-column block of W rows, j: 32-row block of A rows) = registers 64 i + 16 j of a[0:255]
-    asm volatile(
+    if constexpr (std::is_same<T16, f16_t>::value) {
+        asm volatile(
+#include "gemm_g4_body_f16.inc"
+            : "=" G4_ACC0(AC[0]), "=" G4_ACC1(AC[1]), "=" G4_ACC2(AC[2]), "=" G4_ACC3(AC[3]), "=" G4_ACC4(AC[4]), "=" G4_ACC5(AC[5]),
+              "=" G4_ACC6(AC[6]), "=" G4_ACC7(AC[7]), "+" G4_PTR(ptr), "+" G4_SIN(sin), "+" G4_VADDR(vaddr)
+            : G4_VOFF(voff), G4_VPF(vpf), G4_SK(sk), G4_VSK(voff16)
+            : G4_CLOBBERS);
+    } else {
+        asm volatile(
 #include "gemm_g4_body.inc"
-        : "=" G4_ACC0(AC[0]), "=" G4_ACC1(AC[1]), "=" G4_ACC2(AC[2]), "=" G4_ACC3(AC[3]), "=" G4_ACC4(AC[4]), "=" G4_ACC5(AC[5]),
-          "=" G4_ACC6(AC[6]), "=" G4_ACC7(AC[7]), "+" G4_PTR(ptr), "+" G4_SIN(sin), "+" G4_VADDR(vaddr)
-        : G4_VOFF(voff), G4_VPF(vpf), G4_SK(sk), G4_VSK(voff16)
-        : G4_CLOBBERS);
+            : "=" G4_ACC0(AC[0]), "=" G4_ACC1(AC[1]), "=" G4_ACC2(AC[2]), "=" G4_ACC3(AC[3]), "=" G4_ACC4(AC[4]), "=" G4_ACC5(AC[5]),
+              "=" G4_ACC6(AC[6]), "=" G4_ACC7(AC[7]), "+" G4_PTR(ptr), "+" G4_SIN(sin), "+" G4_VADDR(vaddr)
+            : G4_VOFF(voff), G4_VPF(vpf), G4_SK(sk), G4_VSK(voff16)
+            : G4_CLOBBERS);
+    }
     G4_STAMP(2);
     __builtin_amdgcn_s_barrier();  // every wave is done with the stages: the epilogue patches alias them
 
@@ -154,7 +166,7 @@ __global__ __launch_bounds__(256, 1) void gemm_g4(const GemmArgs a, int tiles_m,
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[i][j][e] = AC[2 * (2 * h + i) + (j >> 1)][(j & 1) * 16 + e];
-        epilogue_wave<EPI, 4>(a, acc, m0 + wm * 128, n0 + wn * 128 + h * 64, patch, lane);
+        epilogue_wave<EPI, 4, false, T16>(a, acc, m0 + wm * 128, n0 + wn * 128 + h * 64, patch, lane);
     }
 #ifdef S2V_DIAG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -173,7 +185,7 @@ __global__ __launch_bounds__(256, 1) void gemm_g4(const GemmArgs a, int tiles_m,
     clk_stamp(a.clk, gridDim.x >> 1, 1);
 }
 
-template <int EPI>
+template <int EPI, typename T16 = bf16_t>
 static int launch_g4_t(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     const int tiles_m = (a.M + 255) / 256, tiles_n = (a.N + 255) / 256;
@@ -183,7 +195,7 @@ static int launch_g4_t(const GemmArgs& a_in, hipStream_t st) {
         if (const char* e = getenv("S2V_G4_GM")) a.gm = atoi(e);
 #endif
     }
-    const void* fn = (const void*)gemm_g4<EPI>;
+    const void* fn = (const void*)gemm_g4<EPI, T16>;
     S2V_TRY(ensure_lds_attr(fn, G4_LDS_BYTES));
     void* args[] = {(void*)&a, (void*)&tiles_m, (void*)&tiles_n};
     const int S = a.splitk > 1 ? a.splitk : 1;
@@ -205,6 +217,18 @@ int gemm_choose_splitk(int64_t tiles, int K, int64_t ncu) {
     int S = (int)(ncu / tiles < 4 ? ncu / tiles : 4);  // the sum adds at most four partials
     while (S > 1 && !(K % (128 * S) == 0 && K / (64 * S) >= 16)) --S;
     return S;
+}
+// fp16 operands: the same conditions as gemm_g4_ok without split K and without the fused q/k norm epilogue
+bool gemm_g4_f16_ok(const GemmArgs& a, int epi) { return a.splitk <= 1 && epi != EPI_BIAS_QKNORM && a.mx_out_q == nullptr && gemm_g4_ok(a, epi); }
+int launch_gemm_g4_f16(const GemmArgs& a, int epi, hipStream_t st) {
+    S2V_REQUIRE(gemm_g4_f16_ok(a, epi), "gemm_g4 (fp16): shape / epilogue not supported");
+    switch (epi) {
+        case EPI_BIAS: return launch_g4_t<EPI_BIAS, f16_t>(a, st);
+        case EPI_BIAS_GELU: return launch_g4_t<EPI_BIAS_GELU, f16_t>(a, st);
+        case EPI_BIAS_GATE_RES: return launch_g4_t<EPI_BIAS_GATE_RES, f16_t>(a, st);
+        case EPI_BIAS_ADD: return launch_g4_t<EPI_BIAS_ADD, f16_t>(a, st);
+        default: return s2v_fail(__FILE__, __LINE__, "gemm_g4 (fp16): bad epilogue", -1);
+    }
 }
 int launch_gemm_g4(const GemmArgs& a, int epi, hipStream_t st) {
     switch (epi) {

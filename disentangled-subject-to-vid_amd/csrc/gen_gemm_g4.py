@@ -512,9 +512,15 @@ def gen_sk_sum():
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
+    body = gen_reg() if STAGE == "reg" else gen()
     with open(os.path.join(here, "gemm_g4_body.inc"), "w") as f:
-        for ln in (gen_reg() if STAGE == "reg" else gen()):
+        for ln in body:
             f.write('"' + ln + '\\n\\t"\n')
+    # the fp16 model dtype (round 5): the same loop on v_mfma_f32_32x32x16_f16 -- staging, swizzle and fragment reads move 16-bit elements
+    # whatever they encode, so the mnemonic is the only difference
+    with open(os.path.join(here, "gemm_g4_body_f16.inc"), "w") as f:
+        for ln in body:
+            f.write('"' + ln.replace("v_mfma_f32_32x32x16_bf16", "v_mfma_f32_32x32x16_f16") + '\\n\\t"\n')
     for name, body in (("gemm_g4_sk_sum.inc", gen_sk_sum()),):
         with open(os.path.join(here, name), "w") as f:
             for ln in body:

@@ -104,6 +104,9 @@ int launch_gemm_f32m(const GemmArgs& a, int epi, hipStream_t st);
 // gemm_g4.hip: 256 x 256 tiles, four waves, generated-asm K loop (plain bf16 operands; gemm_g4_ok says whether a call qualifies)
 bool gemm_g4_ok(const GemmArgs& a, int epi);
 int launch_gemm_g4(const GemmArgs& a, int epi, hipStream_t st);
+// the same loop on fp16 operands (v_mfma_f32_32x32x16_f16) with the fp16 form of the vector epilogue: the fp16 model dtype's big linears
+bool gemm_g4_f16_ok(const GemmArgs& a, int epi);
+int launch_gemm_g4_f16(const GemmArgs& a, int epi, hipStream_t st);
 // gemm_g4f.hip: the four-wave loop on e4m3 operands (launch_gemm_fp8 routes to it where gemm_g4f_ok)
 bool gemm_g4f_ok(const GemmArgs& a, int epi);
 int launch_gemm_g4f(const GemmArgs& a, int epi, hipStream_t st);

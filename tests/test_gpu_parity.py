@@ -118,7 +118,8 @@ def test_op_attention(s2v, B, H, N, impl, dt_name):
     assert (got - ref).abs().max() <= tol * max(1.0, ref.abs().max().item()), (got - ref).abs().max()
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(128, 128, 64, 0), (384, 256, 3072, 0), (256, 512, 1024, 1), (1280, 1920 + 128, 1920, 0)])
+@pytest.mark.parametrize("M,N,K,epi", [(128, 128, 64, 0), (384, 256, 3072, 0), (256, 512, 1024, 1), (1280, 1920 + 128, 1920, 0),
+                                        (4096, 4096, 1024, 0), (4096, 4096, 512, 1)])   # the last two: >= 256 tiles of 256 x 256 -> gemm_g4 on fp16 operands
 def test_op_linear_mfma_f16(s2v, M, N, K, epi):
     """fp16 operands on v_mfma_f32_32x32x16_f16 (impl 4: what the fp16 engine's linears run) against fp64 on the same fp16 values"""
     g = torch.Generator().manual_seed(M + N + K)
