@@ -568,7 +568,8 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
     // every GEMM operand of the transformer lives in a workspace buffer with >= 256 rows of slack behind it
     g.a_rows_padded = (int)(rup(g.M, 256));
     g.w_rows_padded = (int)(rup(g.N, 256));  // every weight of the arena is carved with its rows padded to 256
-    if (c->mfma && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0) {
+    if ((c->mfma || c->h16) && g.K % 64 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0) {
+        g.f16 = c->h16 ? 1 : 0;  // the fp16 model dtype takes the same dispatch on the kernels' fp16 instantiations (launch_gemm_bf16)
         // Tile-count quantisation: the 256 x 256 kernel runs one tile per CU, so a grid that spills a few tiles into an extra
         // round pays a whole round (C3: 150 x 12 = 1800 tiles = 7.03 rounds of 256 CUs for the out-proj / FF2).  When the
         // last row tile is partial and dropping it saves a round, the full row tiles run on the big kernel and the row tail
@@ -600,7 +601,6 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
         }
         return launch_gemm_bf16(g, epi, st);
     }
-    if (c->h16 && gemm_f16_ok(g, epi)) return launch_gemm_f16(g, epi, st);
     g.valu_only = c->cfg.force_simple;  // fp32: the matrix-pipe kernel (gemm_f32m, same bits) unless the cross-check path is asked for
     return launch_gemm_simple(g, epi, c->dtype, st);
 }

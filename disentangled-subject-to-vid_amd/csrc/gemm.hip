@@ -85,6 +85,12 @@ __device__ __forceinline__ bf16x8 lds_frag(const char* tile, int row, int cl) {
     return *(const bf16x8*)(tile + off);
 }
 
+// one 32 x 32 x 16 MFMA on 16-bit operands of either encoding (the fragments are bits: bf16x8 is just their carrier type)
+template <typename T16>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 x, bf16x8 y, f32x16 acc) {
+    if constexpr (std::is_same<T16, f16_t>::value) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, x), __builtin_bit_cast(f16x8, y), acc, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc, 0, 0, 0);
+}
 // T16 = bf16_t (v_mfma_f32_32x32x16_bf16) or f16_t (v_mfma_f32_32x32x16_f16: the fp16 model dtype, round 5 -- the staging, the swizzle and the
 // fragment reads move 16-bit elements whatever they encode; the fp16 form takes the lane-local epilogue4 below)
 template <int EPI, typename T16 = bf16_t>
@@ -156,11 +162,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_128(const GemmArgs a, int ti
         __syncthreads();
     }
 
-    if constexpr (std::is_same<T16, bf16_t>::value) {
-        if (epi_vec_ok(a, EPI)) {  // the k-loop ended with a barrier: the operand stages are free
-            epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
-            return;
-        }
+    if (epi_vec_ok(a, EPI)) {  // the k-loop ended with a barrier: the operand stages are free
+        epilogue_wave<EPI, 2, false, T16>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
+        return;
     }
     // epilogue: D[i = n][j = m]; lane: m = fr, n = (reg&3) + 8*(reg>>2) + 4*hi
 #pragma unroll
@@ -184,26 +188,11 @@ bool gemm_f16_ok(const GemmArgs& a, int epi) {
     const int64_t mp = (int64_t)((a.M + BM - 1) / BM) * BM, np = (int64_t)((a.N + BN - 1) / BN) * BN;
     return (a.conv || a.a_rows_padded >= mp) && (a.w_rows_padded >= np || a.N % BN == 0);
 }
-int launch_gemm_f16(const GemmArgs& a, int epi, hipStream_t st) {
-    S2V_REQUIRE(gemm_f16_ok(a, epi), "gemm_f16: shape / padding not supported");
-    // more than one round of 256 x 256 tiles on the part: the four-wave generated-asm loop (gemm_g4 on fp16 operands); otherwise the 128 x 128 kernel
-    {
-        int dev = 0, ncu = 256;
-        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-        if (gemm_g4_f16_ok(a, epi) && (int64_t)((a.M + 255) / 256) * ((a.N + 255) / 256) >= ncu) return launch_gemm_g4_f16(a, epi, st);
-    }
-    const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-    const dim3 grid(tiles_m * tiles_n);
-    const size_t shmem = 4 * TILE_BYTES;
-    switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS, f16_t>), grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS_GELU, f16_t>), grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
-        case EPI_BIAS_GATE_RES: hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS_GATE_RES, f16_t>), grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
-        case EPI_BIAS_ADD: hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS_ADD, f16_t>), grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
-        default: return s2v_fail(__FILE__, __LINE__, "gemm_f16: bad epilogue", -1);
-    }
-    S2V_CHECK_HIP(hipGetLastError());
-    return 0;
+int launch_gemm_f16(const GemmArgs& a0, int epi, hipStream_t st) {
+    S2V_REQUIRE(gemm_f16_ok(a0, epi), "gemm_f16: shape / padding not supported");
+    GemmArgs a = a0;
+    a.f16 = 1;  // the dispatcher of the bf16 kernels on their fp16 instantiations
+    return launch_gemm_bf16(a, epi, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -225,7 +214,7 @@ int launch_gemm_f16(const GemmArgs& a, int epi, hipStream_t st) {
 //                        barrier ago), A computes tile t, B loads tile t; both end with the counted vmcnt that
 //                        retires tile t+1, then barrier
 //   even slot          : A loads tile t+1, B computes tile t
-template <int EPI>
+template <int EPI, typename T16 = bf16_t>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_stag(const GemmArgs a, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -297,8 +286,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_stag(const GemmArgs a, int t
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma16<T16>(wf[kk][i], af[kk][j], acc[i][j]);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -341,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_stag(const GemmArgs a, int t
 
     if (epi_vec_ok(a, EPI)) {
         // group A left the loop through a barrier that B passed after its last LDS reads: the stages are free
-        epilogue_wave64<EPI>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
+        epilogue_wave<EPI, 2, false, T16>(a, acc, m0 + wm * 64, n0 + wn * 64, smem + wave * 8192, lane);
         return;
     }
 #pragma unroll
@@ -353,7 +341,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_stag(const GemmArgs a, int t
             for (int rq = 0; rq < 4; ++rq) {
                 const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
                 float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
-                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
+                if (n < a.N) epilogue4<T16, EPI>(a, m, n, v);
             }
         }
 }
@@ -543,7 +531,7 @@ __device__ __forceinline__ i32x8v cat16(bf16x8 lo, bf16x8 hi) {
     const i32x4v a = __builtin_bit_cast(i32x4v, lo), b = __builtin_bit_cast(i32x4v, hi);
     return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
 }
-template <int EPI, int ABL = 0, bool FP8 = false>
+template <int EPI, int ABL = 0, bool FP8 = false, typename T16 = bf16_t>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int tiles_m, int tiles_n) {
     constexpr int ES = FP8 ? 1 : 2;         // bytes per operand element
     constexpr int BKE = 128 / ES;           // elements per 128-byte K-tile
@@ -670,7 +658,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        if (ABL != 3 && ABL != 5) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][i], af[kk][j], acc[i][j], 0, 0, 0);
+                        if (ABL != 3 && ABL != 5) acc[i][j] = mfma16<T16>(wf[kk][i], af[kk][j], acc[i][j]);
                         else asm volatile("" ::"v"(wf[kk][i]), "v"(af[kk][j]));
                     }
         }
@@ -730,7 +718,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
 
     char* patch = smem + wave * 16384;
     if (epi_vec_ok(a, EPI)) {
-        epilogue_wave<EPI, 4, FP8>(a, acc, m0 + wm * 128, n0 + wn * 64, patch, lane);
+        epilogue_wave<EPI, 4, FP8, T16>(a, acc, m0 + wm * 128, n0 + wn * 64, patch, lane);
         if ((ABL >= 4)) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             tacc[3] = now() - te0;  // epilogue incl. store drain (replaces the vmcnt slot)
@@ -750,7 +738,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_pp64(const GemmArgs a, int t
             for (int rq = 0; rq < 4; ++rq) {
                 const int n = n0 + wn * 64 + i * 32 + 8 * rq + 4 * hi;
                 float v[4] = {acc[i][j][rq * 4 + 0], acc[i][j][rq * 4 + 1], acc[i][j][rq * 4 + 2], acc[i][j][rq * 4 + 3]};
-                if (n < a.N) epilogue4<bf16_t, EPI>(a, m, n, v);
+                if (n < a.N) epilogue4<T16, EPI>(a, m, n, v);
             }
         }
 }
@@ -1169,12 +1157,12 @@ static int device_cus() {
     return cus[d];
 }
 
-template <int EPI>
+template <int EPI, typename T16 = bf16_t>
 static int launch_pp64_t(const GemmArgs& a_in, hipStream_t st) {
     GemmArgs a = a_in;
     const int tiles_m = (a.M + WBM - 1) / WBM, tiles_n = (a.N + WBN - 1) / WBN;
     if (a.gm <= 0) a.gm = (!a.conv && tiles_n <= 16 && tiles_m >= 32) ? (a.K >= 8192 ? 1 : 3) : 4;
-    S2V_TRY(ensure_lds_attr((const void*)gemm_bf16_pp64<EPI>, 131072));
+    S2V_TRY(ensure_lds_attr((const void*)gemm_bf16_pp64<EPI, 0, false, T16>, 131072));
 #ifdef S2V_DIAG
     if (EPI == EPI_BIAS && a.ablate) {  // diagnostics only (tools/ablate_gemm.py)
         const void* fn = a.ablate == 1 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 1> : a.ablate == 4 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 4> : a.ablate == 5 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 5> : a.ablate == 6 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 6> : a.ablate == 7 ? (const void*)gemm_bf16_pp64<EPI_BIAS, 7> : (const void*)gemm_bf16_pp64<EPI_BIAS, 3>;
@@ -1184,7 +1172,7 @@ static int launch_pp64_t(const GemmArgs& a_in, hipStream_t st) {
         return 0;
     }
 #endif
-    hipLaunchKernelGGL(gemm_bf16_pp64<EPI>, dim3(tiles_m * tiles_n), dim3(512), 131072, st, a, tiles_m, tiles_n);
+    hipLaunchKernelGGL((gemm_bf16_pp64<EPI, 0, false, T16>), dim3(tiles_m * tiles_n), dim3(512), 131072, st, a, tiles_m, tiles_n);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1200,11 +1188,11 @@ static int launch_w8_t(const GemmArgs& a, hipStream_t st) {
 }
 #endif
 
-template <int EPI>
+template <int EPI, typename T16 = bf16_t>
 static int launch_stag_t(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + RBM - 1) / RBM, tiles_n = (a.N + RBN - 1) / RBN;
-    S2V_TRY(ensure_lds_attr((const void*)gemm_bf16_stag<EPI>, 3 * RSTAGE));
-    hipLaunchKernelGGL(gemm_bf16_stag<EPI>, dim3(tiles_m * tiles_n), dim3(512), 3 * RSTAGE, st, a, tiles_m, tiles_n);
+    S2V_TRY(ensure_lds_attr((const void*)gemm_bf16_stag<EPI, T16>, 3 * RSTAGE));
+    hipLaunchKernelGGL((gemm_bf16_stag<EPI, T16>), dim3(tiles_m * tiles_n), dim3(512), 3 * RSTAGE, st, a, tiles_m, tiles_n);
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -1288,6 +1276,9 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
         return 0;
     }
     S2V_REQUIRE(a.K % BK == 0, "gemm_bf16: K must be a multiple of 64");
+    // a.f16 (round 5): the operands are fp16 -- the same dispatch on the kernels' fp16 instantiations (the four-wave asm loop with the fp16 mnemonic,
+    // the eight-wave ping-pong, the staggered 256 x 128 ring, the 128 x 128 kernel); not for fp16: gemm_g4t, split K, the fused q/k-norm epilogue
+    S2V_REQUIRE(!a.f16 || (epi != EPI_BIAS_QKNORM && a.splitk <= 1 && a.mx_out_q == nullptr), "gemm (fp16): no fused q/k norm, split K or MX output");
 #ifdef S2V_DIAG
     if (g_gemm_impl == 8 && !a.conv && (epi == EPI_BIAS || epi == EPI_BIAS_GELU) && w_tile_ok(a) && a.N % 64 == 0 && a.K >= 36 * 64 &&
         epi_vec_ok(a, epi) && a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM && a.lda % 8 == 0 && a.ldw % 8 == 0) {
@@ -1310,15 +1301,15 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     // 216 K-tiles, 0.52 PF, profiles/r04_vae_conv_rates.txt) runs on 256 x 128 tiles instead
     const bool conv_few = a.conv && out_tiles * 2 <= cus && epi != EPI_BIAS_QKNORM;
     const bool big_tiles = (a.tile == 0 && !conv_few) || (a.conv && !conv_few) || epi == EPI_BIAS_QKNORM;  // GemmArgs::tile: the caller asks for smaller tiles
-    if (g_gemm_impl == 9 && g_gemm_g4t && big_tiles && w_tile_ok(a) && gemm_g4_ok(a, epi) && gemm_g4t_ok(a, epi, (int)cus)) return launch_gemm_g4t(a, epi, st);
-    if (g_gemm_impl == 9 && big_tiles && g4_epi && w_tile_ok(a) && gemm_g4_ok(a, epi)) return launch_gemm_g4(a, epi, st);  // four-wave generated-asm K loop
+    if (g_gemm_impl == 9 && g_gemm_g4t && !a.f16 && big_tiles && w_tile_ok(a) && gemm_g4_ok(a, epi) && gemm_g4t_ok(a, epi, (int)cus)) return launch_gemm_g4t(a, epi, st);
+    if (g_gemm_impl == 9 && big_tiles && g4_epi && w_tile_ok(a) && gemm_g4_ok(a, epi)) return a.f16 ? launch_gemm_g4_f16(a, epi, st) : launch_gemm_g4(a, epi, st);  // four-wave generated-asm K loop
     if ((g_gemm_impl == 7 || g_gemm_impl == 8 || g_gemm_impl == 9) && big_tiles && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
-            case EPI_BIAS: return launch_pp64_t<EPI_BIAS>(a, st);
-            case EPI_BIAS_GELU: return launch_pp64_t<EPI_BIAS_GELU>(a, st);
-            case EPI_BIAS_GATE_RES: return launch_pp64_t<EPI_BIAS_GATE_RES>(a, st);
-            case EPI_BIAS_ADD: return launch_pp64_t<EPI_BIAS_ADD>(a, st);
+            case EPI_BIAS: return a.f16 ? launch_pp64_t<EPI_BIAS, f16_t>(a, st) : launch_pp64_t<EPI_BIAS>(a, st);
+            case EPI_BIAS_GELU: return a.f16 ? launch_pp64_t<EPI_BIAS_GELU, f16_t>(a, st) : launch_pp64_t<EPI_BIAS_GELU>(a, st);
+            case EPI_BIAS_GATE_RES: return a.f16 ? launch_pp64_t<EPI_BIAS_GATE_RES, f16_t>(a, st) : launch_pp64_t<EPI_BIAS_GATE_RES>(a, st);
+            case EPI_BIAS_ADD: return a.f16 ? launch_pp64_t<EPI_BIAS_ADD, f16_t>(a, st) : launch_pp64_t<EPI_BIAS_ADD>(a, st);
             case EPI_BIAS_QKNORM: return launch_pp64_t<EPI_BIAS_QKNORM>(a, st);
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
@@ -1338,10 +1329,10 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     if ((g_gemm_impl == 2 || g_gemm_impl >= 4) && (a.tile != 2 || a.conv) && epi != EPI_BIAS_QKNORM && (a.conv || a.a_rows_padded >= ((a.M + RBM - 1) / RBM) * RBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");
         switch (epi) {
-            case EPI_BIAS: return launch_stag_t<EPI_BIAS>(a, st);
-            case EPI_BIAS_GELU: return launch_stag_t<EPI_BIAS_GELU>(a, st);
-            case EPI_BIAS_GATE_RES: return launch_stag_t<EPI_BIAS_GATE_RES>(a, st);
-            case EPI_BIAS_ADD: return launch_stag_t<EPI_BIAS_ADD>(a, st);
+            case EPI_BIAS: return a.f16 ? launch_stag_t<EPI_BIAS, f16_t>(a, st) : launch_stag_t<EPI_BIAS>(a, st);
+            case EPI_BIAS_GELU: return a.f16 ? launch_stag_t<EPI_BIAS_GELU, f16_t>(a, st) : launch_stag_t<EPI_BIAS_GELU>(a, st);
+            case EPI_BIAS_GATE_RES: return a.f16 ? launch_stag_t<EPI_BIAS_GATE_RES, f16_t>(a, st) : launch_stag_t<EPI_BIAS_GATE_RES>(a, st);
+            case EPI_BIAS_ADD: return a.f16 ? launch_stag_t<EPI_BIAS_ADD, f16_t>(a, st) : launch_stag_t<EPI_BIAS_ADD>(a, st);
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }
@@ -1351,16 +1342,20 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     const size_t shmem = 4 * TILE_BYTES;
     switch (epi) {
         case EPI_BIAS:
-            hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            if (a.f16) hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS, f16_t>), dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            else hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
             break;
         case EPI_BIAS_GELU:
-            hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_GELU>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            if (a.f16) hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS_GELU, f16_t>), dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            else hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_GELU>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
             break;
         case EPI_BIAS_GATE_RES:
-            hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_GATE_RES>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            if (a.f16) hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS_GATE_RES, f16_t>), dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            else hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_GATE_RES>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
             break;
         case EPI_BIAS_ADD:
-            hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_ADD>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            if (a.f16) hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS_ADD, f16_t>), dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            else hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_ADD>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
             break;
         case EPI_BIAS_QKNORM:
             hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_QKNORM>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);

@@ -45,6 +45,7 @@ struct GemmArgs {
                         // (few-tile GEMMs: more, smaller workgroups fill the CUs that a single partial round of 256 x 256 tiles leaves idle)
     int ablate;         // diagnostics only
     long long* clk;     // profile pass only: shader-clock stamp slot (common.h clk_stamp; gemm_g4 / g4t / g4f), else null
+    int f16;            // launch_gemm_bf16: the 16-bit operands are fp16, not bf16 (set by launch_gemm_f16)
     int valu_only;      // fp32 only: stay on the VALU kernel gemm_simple_k (cfg.force_simple; the A/B reference of gemm_f32m, which returns the same bits)
     int a_rows_padded;  // plain mode: rows physically present behind A (>= M); the 256-row kernel needs ceil256(M)
     int m_begin;        // first output row of this launch (row-tail launches of a split GEMM; 128-row kernel only)
