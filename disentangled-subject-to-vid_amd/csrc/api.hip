@@ -659,6 +659,21 @@ static int g_fused_q8 = 1;
 extern "C" __attribute__((visibility("default"))) int s2v_set_fused_q8(int on) { g_fused_q8 = on; return 0; }
 static int g_fused_qk = 1;
 extern "C" __attribute__((visibility("default"))) int s2v_set_fused_qk(int on) { g_fused_qk = on; return 0; }
+// the fused QKV projection (EPI_BIAS_QKNORM) as an operator of the diagnostics build: A [M (rows allocated up to a multiple of 256)][K],
+// W [3 D][K], C [M][3 D], LayerNorm(64) parameters of q and k, paired rotary table [positions][32 cos | 32 sin] fp32 -- what the block
+// forward launches, so that the kernels that implement it (gemm_g4t's trickle, gemm_g4's / the eight-wave kernels' C++ epilogue) can be
+// compared bit for bit on real shapes (tests/test_gpu_gemm_schedules.py) and timed (tools/qkv_trickle_bench.py)
+extern "C" __attribute__((visibility("default"))) int s2v_diag_qkv_qknorm(const void* A, const void* W, const void* bias, const void* nq_w, const void* nq_b,
+                                                                           const void* nk_w, const void* nk_b, const float* cs, void* C, int32_t M, int32_t D,
+                                                                           int32_t K, int32_t tok_per_batch, int32_t text_len, float eps, s2v_stream stream) {
+    S2V_REQUIRE(A && W && bias && C && nq_w && nq_b && nk_w && nk_b, "s2v_diag_qkv_qknorm: null argument");
+    GemmArgs g{};
+    g.A = A; g.lda = K; g.W = W; g.ldw = K; g.bias = bias; g.C = C; g.ldc = 3 * D; g.M = M; g.N = 3 * D; g.K = K;
+    g.a_rows_padded = (int)rup(M, 256); g.w_rows_padded = (int)rup(3 * D, 256);
+    g.tok_per_batch = tok_per_batch; g.text_len = text_len;
+    g.qk_w[0] = nq_w; g.qk_b[0] = nq_b; g.qk_w[1] = nk_w; g.qk_b[1] = nk_b; g.qk_cs = cs; g.qk_D = D; g.qk_eps = eps;
+    return launch_gemm_bf16(g, EPI_BIAS_QKNORM, (hipStream_t)stream);
+}
 #endif
 // mx_out (fp8 engine, MFMA path): the attention kernel leaves its output as MX e4m3 in c->aq / c->hs for the out-projection instead of bf16 in Xn
 static bool attn_mx_out(const s2v_ctx* c) {

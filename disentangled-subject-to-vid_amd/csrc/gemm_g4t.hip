@@ -49,7 +49,24 @@ __global__ __launch_bounds__(256, 1) void gemm_g4t(const GemmArgs a, int tiles_m
         rec[0] = (unsigned long long)((const char*)a.A + 2 * (int64_t)m0 * a.lda);
         rec[1] = (unsigned long long)((const char*)a.W + 2 * (int64_t)n0 * a.ldw);
         rec[2] = (unsigned long long)((char*)a.C + 2 * ((int64_t)m0 * a.ldc + n0));
-        rec[3] = (unsigned long long)(unsigned)(2 * n0);
+        // qknorm: + (m0 << 2 | kind of the tile's heads: 0 q, 1 k, 2 v) for the trickle of the NEXT tile's K loop
+        const unsigned kind = EPI == EPI_BIAS_QKNORM ? (n0 >= 2 * a.qk_D ? 2u : n0 >= a.qk_D ? 1u : 0u) : 0u;
+        rec[3] = (unsigned long long)(unsigned)(2 * n0) | ((unsigned long long)(((unsigned)m0 << 2) | kind) << 32);
+    }
+    if constexpr (EPI == EPI_BIAS_QKNORM) {
+        // the trickle's constant block: rotary table, position arithmetic, eps; the LayerNorm weights / biases of q and k (4 x 64 bf16)
+        unsigned* cb = (unsigned*)(smem + G4T_QK_CONST_BASE);
+        if (tid == 0) {
+            const unsigned long long cs = (unsigned long long)a.qk_cs;
+            cb[0] = (unsigned)cs; cb[1] = (unsigned)(cs >> 32);
+            cb[2] = (unsigned)a.tok_per_batch; cb[3] = (unsigned)a.text_len;
+            cb[4] = __float_as_uint(1.0f / (float)a.tok_per_batch); cb[5] = __float_as_uint(a.qk_eps);
+        }
+        if (tid < 128) {
+            const int which = tid >> 5, e = tid & 31;  // 0: q weight, 1: k weight, 2: q bias, 3: k bias
+            const unsigned* src = (const unsigned*)(which < 2 ? a.qk_w[which] : a.qk_b[which - 2]);
+            cb[G4T_QK_LN_OFF / 4 + tid] = src[e];
+        }
     }
     __syncthreads();
 
@@ -76,6 +93,7 @@ __global__ __launch_bounds__(256, 1) void gemm_g4t(const GemmArgs a, int tiles_m
     vlane[1] = pbase + fr * 128 + ((fr & 7) << 4) + hi * 8;
     vlane[2] = pbase + (lane >> 3) * 128 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
     vlane[3] = hi * 8;
+    if constexpr (EPI == EPI_BIAS_QKNORM) vlane[3] |= (unsigned)(wm * 128 + (lane >> 3)) << 8;  // the q/k-norm trickle's first token row of the lane
     unsigned vtab = lds0 + G4T_TABLE_BASE;
     u32x4 ptr = {0, 0, 0, 0};
     const unsigned sin0 = lds0 + wave * 1024;
@@ -86,7 +104,15 @@ __global__ __launch_bounds__(256, 1) void gemm_g4t(const GemmArgs a, int tiles_m
     u32x2 sin4 = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)bp), (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(bp >> 32))};
 
     f32x32 AC[8];
-    if (EPI == EPI_BIAS_GELU) {
+    if constexpr (EPI == EPI_BIAS_QKNORM) {
+        const unsigned qcb = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + G4T_QK_CONST_BASE));
+        asm volatile(
+#include "gemm_g4t_body_qknorm.inc"
+            : "=" G4T_ACC0(AC[0]), "=" G4T_ACC1(AC[1]), "=" G4T_ACC2(AC[2]), "=" G4T_ACC3(AC[3]), "=" G4T_ACC4(AC[4]), "=" G4T_ACC5(AC[5]),
+              "=" G4T_ACC6(AC[6]), "=" G4T_ACC7(AC[7]), "+" G4T_PTR(ptr), "+" G4T_SIN1(sin1), "+" G4T_VTAB(vtab)
+            : G4T_VADDR(vaddr), G4T_VOFF(voff), G4T_VLANE(vlane), G4T_SIN0(sin0), G4T_SIN2(sin2), G4T_SIN3(sin3), G4T_SIN4(sin4), G4T_QK_CB(qcb)
+            : G4T_CLOBBERS, G4T_QK_CLOBBERS);
+    } else if (EPI == EPI_BIAS_GELU) {
         asm volatile(
 #include "gemm_g4t_body_gelu.inc"
             : "=" G4T_ACC0(AC[0]), "=" G4T_ACC1(AC[1]), "=" G4T_ACC2(AC[2]), "=" G4T_ACC3(AC[3]), "=" G4T_ACC4(AC[4]), "=" G4T_ACC5(AC[5]),
@@ -131,19 +157,23 @@ static int launch_g4t_t(const GemmArgs& a_in, hipStream_t st) {
     S2V_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
     const int grid = (ncu / 8) * 8;
     const void* fn = (const void*)gemm_g4t<EPI>;
-    S2V_TRY(ensure_lds_attr(fn, G4T_LDS_BYTES));
+    const int lds = G4T_LDS_BYTES + (EPI == EPI_BIAS_QKNORM ? G4T_QK_CONST_BYTES : 0);
+    S2V_TRY(ensure_lds_attr(fn, lds));
     void* args[] = {(void*)&a, (void*)&tiles_m, (void*)&tiles_n};
-    S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(grid), dim3(256), args, G4T_LDS_BYTES, st));
+    S2V_CHECK_HIP(hipLaunchKernel(fn, dim3(grid), dim3(256), args, lds, st));
     return 0;
 }
 
 // whole 256 x 256 tiles only (the engine splits a partial last row tile off before it gets here), a bias, enough K-tiles to carry the
 // trickle, at least two rounds of tiles (one round has nothing to hide an epilogue behind) and no more than the record table holds
 bool gemm_g4t_ok(const GemmArgs& a, int epi, int ncu) {
-    if (epi != EPI_BIAS_GELU && epi != EPI_BIAS) return false;
+    if (epi != EPI_BIAS_GELU && epi != EPI_BIAS && epi != EPI_BIAS_QKNORM) return false;
     if (a.conv || a.splitk > 1 || a.mx_out_q || !a.bias || a.m_begin != 0) return false;
     if (a.M % 256 != 0 || a.N % 256 != 0 || a.K % 128 != 0) return false;
-    const int tk = epi == EPI_BIAS_GELU ? G4T_TK_GELU : G4T_TK_BIAS;
+    // the trickled q/k-norm: whole tiles of q, k or v heads, a rotary table (the 2B model's no-rotary form stays on the C++ epilogue), rows
+    // that convert exactly to float
+    if (epi == EPI_BIAS_QKNORM && (a.qk_cs == nullptr || a.qk_D % 256 != 0 || a.N != 3 * a.qk_D || a.tok_per_batch <= 0 || a.M >= (1 << 24))) return false;
+    const int tk = epi == EPI_BIAS_GELU ? G4T_TK_GELU : epi == EPI_BIAS_QKNORM ? G4T_TK_QKNORM : G4T_TK_BIAS;
     if (a.K / 64 < tk + 4) return false;
     if (a.lda % 8 != 0 || a.ldw % 8 != 0 || a.ldc % 8 != 0 || !epi_vec_ok(a, epi)) return false;
     const int64_t ntile = (int64_t)(a.M / 256) * (a.N / 256), grid = (ncu / 8) * 8;
@@ -157,6 +187,7 @@ int launch_gemm_g4t(const GemmArgs& a, int epi, hipStream_t st) {
     switch (epi) {
         case EPI_BIAS: return launch_g4t_t<EPI_BIAS>(a, st);
         case EPI_BIAS_GELU: return launch_g4t_t<EPI_BIAS_GELU>(a, st);
+        case EPI_BIAS_QKNORM: return launch_g4t_t<EPI_BIAS_QKNORM>(a, st);
         default: return s2v_fail(__FILE__, __LINE__, "gemm_g4t: bad epilogue", -1);
     }
 }

@@ -102,6 +102,65 @@ def test_g4t_trickled_epilogue_kernel_is_bit_identical_to_g4(s2v, M, N, K, epi):
     assert rel <= 1e-2, rel
 
 
+def _qkv_qknorm(D_lib, L, A, W, b, ln, cs, M, D, K, tok, text_len):
+    C = torch.full((M, 3 * D), float("nan"), device=DEV, dtype=torch.bfloat16)
+    rc = D_lib.s2v_diag_qkv_qknorm(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(ln[0]), L.ptr(ln[1]), L.ptr(ln[2]), L.ptr(ln[3]), L.ptr(cs), L.ptr(C), M, D, K, tok,
+                                   text_len, ctypes.c_float(1e-6), L.stream_ptr())
+    assert rc == 0, D_lib.s2v_last_error()
+    torch.cuda.synchronize()
+    return C
+
+
+@pytest.mark.parametrize("M,D,K,tok,text", [(12288, 1024, 3072, 4096, 226), (16128, 768, 2304, 3000, 0), (9216, 1280, 3072, 1500, 1499), (12288, 1024, 4096, 12288, 12288)])
+def test_g4t_trickled_qk_norm_rope_epilogue_is_bit_identical_to_g4(s2v, M, D, K, tok, text):
+    """The fused QKV projection (bias, per-head LayerNorm(64) + affine, rotary embedding: attention_processor.py:2049-2080) with its epilogue
+    trickled through the next tile's K loop in generated asm (gemm_g4t<qknorm>, gen_gemm_g4t.py qk_program) against gemm_g4 with the C++
+    epilogue of gemm_epi.h: BIT-IDENTICAL -- the asm restates the C++ order of operations (octet sums, the three DPP steps, the correctly
+    rounded sqrt and reciprocal, the separately rounded normalisation and rotary pair).  Shapes: several samples per launch with text
+    rows inside tiles (tok 4096 / text 226), a token count that does not divide the tile (3000: tiles straddle samples) without text
+    rows, all but one row text (1499 of 1500), no video row at all; the minimum depth (K = 2304) and the 5B depth (3072)."""
+    L = s2v._lib
+    Dg = L.diag_lib()
+    Dg.s2v_set_gemm_g4t.argtypes = [ctypes.c_int]
+    assert (M // 256) * (3 * D // 256) >= 512 and K >= 2304 and D % 256 == 0  # gemm_g4t_ok: two rounds of tiles, the trickle's depth
+    g = torch.Generator().manual_seed(M + D + K)
+    A = (torch.randn(M, K, generator=g) * 0.5).bfloat16().to(DEV)
+    W = (torch.randn(3 * D, K, generator=g) * 0.05).bfloat16().to(DEV)
+    b = (torch.randn(3 * D, generator=g) * 0.2).bfloat16().to(DEV)
+    ln = [(1.0 + 0.3 * torch.randn(64, generator=g)).bfloat16().to(DEV), (0.2 * torch.randn(64, generator=g)).bfloat16().to(DEV),
+          (1.0 + 0.3 * torch.randn(64, generator=g)).bfloat16().to(DEV), (0.2 * torch.randn(64, generator=g)).bfloat16().to(DEV)]
+    ang = torch.rand(max(tok - text, 1), 32, generator=g) * 6.28
+    cs = torch.cat([ang.cos(), ang.sin()], dim=1).float().contiguous().to(DEV)
+    try:
+        Dg.s2v_set_gemm_g4t(0)
+        ref = _qkv_qknorm(Dg, L, A, W, b, ln, cs, M, D, K, tok, text)  # gemm_g4<qknorm>
+        assert torch.isfinite(ref.float()).all()
+        Dg.s2v_set_gemm_g4t(1)
+        for rep in range(3):
+            out = _qkv_qknorm(Dg, L, A, W, b, ln, cs, M, D, K, tok, text)
+            bad = (out != ref)
+            assert not bad.any(), (f"rep {rep}: {bad.sum().item()} elements differ, max {(out.float() - ref.float()).abs().max().item()}, first at "
+                                   f"{bad.nonzero()[0].tolist()}, by column block {bad.view(M, 3 * D // 64, 64).any(2).any(0).nonzero().flatten().tolist()[:12]}")
+    finally:
+        Dg.s2v_set_gemm_g4t(1)
+    # against plain torch: projection rounded to bf16, LayerNorm over each 64-column head of q and k, rotary on the video rows
+    y = (A.float() @ W.float().T + b.float()).bfloat16().float()
+    q = y[:, :2 * D].reshape(M, 2 * D // 64, 64)
+    w = torch.cat([ln[0].float().expand(D // 64, 64), ln[2].float().expand(D // 64, 64)])
+    bb = torch.cat([ln[1].float().expand(D // 64, 64), ln[3].float().expand(D // 64, 64)])
+    q = (torch.nn.functional.layer_norm(q, (64,), eps=1e-6) * w + bb).bfloat16().float()
+    r = torch.arange(M, device=DEV) % tok
+    vid = r >= text
+    pos = (r - text).clamp_min(0)
+    c, s_ = cs[pos, :32].unsqueeze(1), cs[pos, 32:].unsqueeze(1)
+    x0, x1 = q[..., 0::2], q[..., 1::2]
+    rot = torch.stack([x0 * c - x1 * s_, x1 * c + x0 * s_], dim=-1).reshape(M, 2 * D // 64, 64)
+    q = torch.where(vid[:, None, None], rot, q)
+    exp = torch.cat([q.reshape(M, 2 * D), y[:, 2 * D:]], dim=1)
+    rel = ((ref.float() - exp).norm() / exp.norm()).item()
+    assert rel <= 1e-2, rel
+
+
 @pytest.mark.parametrize("epi", [0, 1])
 def test_four_wave_persistent_kernel_matches_pingpong(s2v, epi):
     """gemm_q4 (diagnostics build only: persistent 4-wave kernel whose epilogue trickles through the next tile's K loop): 1536
