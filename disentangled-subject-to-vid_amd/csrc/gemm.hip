@@ -1301,7 +1301,11 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
     // 216 K-tiles, 0.52 PF, profiles/r04_vae_conv_rates.txt) runs on 256 x 128 tiles instead
     const bool conv_few = a.conv && out_tiles * 2 <= cus && epi != EPI_BIAS_QKNORM;
     const bool big_tiles = (a.tile == 0 && !conv_few) || (a.conv && !conv_few) || epi == EPI_BIAS_QKNORM;  // GemmArgs::tile: the caller asks for smaller tiles
-    if (g_gemm_impl == 9 && g_gemm_g4t && !a.f16 && big_tiles && w_tile_ok(a) && gemm_g4_ok(a, epi) && gemm_g4t_ok(a, epi, (int)cus)) return launch_gemm_g4t(a, epi, st);
+    bool g4t_epi = true;
+#ifdef S2V_DIAG
+    if (const char* e = getenv("S2V_G4T_EPI_MASK")) g4t_epi = (atoi(e) >> epi) & 1;  // same-box A/B: gemm_g4t for the epilogues of the mask only (tools/epi_mask_probe.py)
+#endif
+    if (g_gemm_impl == 9 && g_gemm_g4t && g4t_epi && !a.f16 && big_tiles && w_tile_ok(a) && gemm_g4_ok(a, epi) && gemm_g4t_ok(a, epi, (int)cus)) return launch_gemm_g4t(a, epi, st);
     if (g_gemm_impl == 9 && big_tiles && g4_epi && w_tile_ok(a) && gemm_g4_ok(a, epi)) return a.f16 ? launch_gemm_g4_f16(a, epi, st) : launch_gemm_g4(a, epi, st);  // four-wave generated-asm K loop
     if ((g_gemm_impl == 7 || g_gemm_impl == 8 || g_gemm_impl == 9) && big_tiles && w_tile_ok(a) && (a.conv || a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
         S2V_REQUIRE((a.conv ? a.cin % 64 == 0 : a.lda % 8 == 0) && a.ldw % 8 == 0, "gemm_bf16: bad leading dims");

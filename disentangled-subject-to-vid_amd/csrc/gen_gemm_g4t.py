@@ -366,6 +366,9 @@ def qk_program():
         nop(1)
         I(f"v_cndmask_b32 {vr(c[7])}, 0, {vr(c[7])}, {sm}")
         I(f"v_lshl_add_u32 {vr(c[7])}, {vr(c[7])}, 8, {vr(QK_C16)}")                 # 256 B per position + 16 B per octet
+        if "qk_noload" in ABLATE:   # timing ablation (wrong results): no rotary loads
+            P.append(([], 0, "vmgroup", ("cs", n), 0))
+            return
         P.append(([f"global_load_dwordx4 {vr(c[0], 4)}, {vr(c[7])}, s[{S_CS}:{S_CS + 1}]",
                    f"global_load_dwordx4 {vr(c[4], 4)}, {vr(c[7])}, s[{S_CS}:{S_CS + 1}] offset:128"], 2, "vmgroup", ("cs", n), 2))
 
@@ -375,6 +378,9 @@ def qk_program():
             I(f"v_add_f32_dpp {vr(reg)}, {vr(reg)}, {vr(reg)} {st} row_mask:0xf bank_mask:0xf bound_ctrl:1")
 
     def compute(n):
+        if "qk_nocompute" in ABLATE:   # timing ablation (wrong results): the rows go out as they were read back
+            P.append(("", 0, "vmwait", ("cs", n)))
+            return
         k = n & 3
         sl = slot_of(n)
         c = [QK_SLOT[sl] + e for e in range(8)]

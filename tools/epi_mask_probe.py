@@ -1,5 +1,6 @@
 """Same-box A/B (diagnostics library, eager steps) of which epilogues run on gemm_g4 (S2V_G4_EPI_MASK bit per epilogue: 1 bias, 2 GELU, 4 gate+residual,
-8 add, 16 q/k-norm; the rest on gemm_bf16_pp64).  Usage: python tools/epi_mask_probe.py <workload> <mask> [<mask> ...]"""
+8 add, 16 q/k-norm; the rest on gemm_bf16_pp64).  Usage: python tools/epi_mask_probe.py <workload> <mask> [<mask> ...]
+S2V_PROBE_VAR=S2V_G4T_EPI_MASK: the same for the persistent trickled-epilogue kernel gemm_g4t (3 = FF1 only, 19 = + the fused QKV projection)."""
 import importlib, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 s2v = importlib.import_module("disentangled-subject-to-vid_amd")
@@ -11,6 +12,7 @@ L._apply_sigs(diag, L._SIGS)
 L._lib = diag
 dev, dt = "cuda:0", torch.bfloat16
 name = sys.argv[1]
+VAR = os.environ.get("S2V_PROBE_VAR", "S2V_G4_EPI_MASK")
 masks = sys.argv[2:]
 preset, F, H, W, T = bench.WORKLOADS[name]
 cfg = s2v.config.PRESETS[preset]()
@@ -27,7 +29,7 @@ n = 6 if F > 3 else 40
 outs = []
 for rep in range(2):
     for mask in masks:
-        os.environ["S2V_G4_EPI_MASK"] = mask
+        os.environ[VAR] = mask
         lat = lat0.clone()
         for i in range(2):
             eng.denoise_step(lat, float(sch.timesteps[i]), coefs[i], use_graph=False)
@@ -37,5 +39,5 @@ for rep in range(2):
             eng.denoise_step(lat, float(sch.timesteps[(2 + i) % 50]), coefs[(2 + i) % 50], use_graph=False)
         torch.cuda.synchronize()
         outs.append(lat.clone())
-        print(f"{name} S2V_G4_EPI_MASK={mask}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step (eager)", flush=True)
+        print(f"{name} {VAR}={mask}: {(time.perf_counter() - t0) / n * 1e3:.3f} ms/step (eager)", flush=True)
 print("all latents bit-identical:", all(torch.equal(outs[0], o) for o in outs))
