@@ -379,7 +379,8 @@ static int alloc_workspace_set(s2v_vae* v, int th, int tw, int fz_max) {
 // The capacity fields (th / tw / fmax / ws_req) and v->ws are committed only AFTER the sets exist: a failed allocation leaves the
 // context at "no capacity" (the next decode allocates again instead of running on empty sets -- ADVICE r3), a failed set k > 0 is
 // freed and the decode proceeds with k sets.  The number of sets is bounded by 70 % of the free memory at this moment (other ranks
-// on the device and torch's caching allocator may move that figure: hence the retry-with-fewer path) and by S2V_VAE_WORKSPACE_MAX_GB.
+// on the device and torch's caching allocator may move that figure: hence the retry-with-fewer path) and by a byte cap (a quarter of the
+// device's memory unless S2V_VAE_WORKSPACE_MAX_GB says otherwise).
 static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws = 1) {
     if (v->th >= th && v->tw >= tw && v->fmax[0] >= fz_max && v->ws_req >= nws && !v->ws.empty()) return 0;
     S2V_CHECK_HIP(hipDeviceSynchronize());
@@ -409,11 +410,13 @@ static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws
         v->set_bytes = set_bytes;
         size_t free_b = 0, total_b = 0;
         double budget = -1.0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = 0.7 * (double)free_b;
-        if (const char* e = getenv("S2V_VAE_WORKSPACE_MAX_GB")) {
-            const double cap = atof(e) * 1e9;
-            if (cap > 0 && (budget < 0 || cap < budget)) budget = cap;
-        }
+        // default byte cap: a quarter of the device's memory (MI355X: 72 GB = three ~21.7 GB sets at the real widths, 602 ms per 49 x 480 x 720
+        // decode against 554 with six sets and 130 GB -- profiles/r03_vae_tiles_in_flight.txt; VERDICT r4: 130 GB of workspaces to save 0.15 s
+        // is not a default).  S2V_VAE_WORKSPACE_MAX_GB = n caps at n GB instead, <= 0 lifts the byte cap (70 % of the free memory remains).
+        double cap = -1.0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) { budget = 0.7 * (double)free_b; cap = 0.25 * (double)total_b; }
+        if (const char* e = getenv("S2V_VAE_WORKSPACE_MAX_GB")) cap = atof(e) * 1e9;
+        if (cap > 0 && (budget < 0 || cap < budget)) budget = cap;
         if (budget >= 0 && set_bytes > 0)
             nws = (int)std::max<int64_t>(1, std::min<int64_t>(nws, (int64_t)budget / set_bytes));
     }
@@ -671,7 +674,7 @@ extern "C" int s2v_vae_decode(s2v_vae* v, const void* latents, int32_t F, int32_
     for (int j = 0; j < w; j += t.ov_w) js.push_back(j);
     const size_t nt = is.size() * js.size();
     // tiles in flight: 49 x 480 x 720 at the real widths measured 928 / 684 / 602 / 605 / 554 / 590 ms with 1 / 2 / 3 / 4 / 6 / 9 sets of
-    // ~20 GB each (profiles/r03_vae_tiles_in_flight.txt); six when the device has the room, fewer otherwise (ws_fit)
+    // ~20 GB each (profiles/r03_vae_tiles_in_flight.txt); up to six, as many as the byte cap of prepare_tile_capacity holds (three by default)
     int nws_cap = 6;
     if (const char* e = getenv("S2V_VAE_TILES_IN_FLIGHT")) nws_cap = std::max(1, atoi(e));
     int nws = (int)std::min<size_t>(nt, (size_t)nws_cap);

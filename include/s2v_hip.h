@@ -231,7 +231,8 @@ S2V_API int s2v_vae_finalize(s2v_vae* vae);
 S2V_API int s2v_vae_weight_arena(s2v_vae* vae, void** dev_ptr, int64_t* bytes);
 S2V_API int s2v_vae_mark_weights_loaded(s2v_vae* vae);
 /* workspace sets (= tiles in flight) and bytes per set that the last tiled decode ran with: the count follows the free HBM
- * (at most six, S2V_VAE_TILES_IN_FLIGHT overrides); for reporting */
+ * and a byte cap of a quarter of the device's memory (S2V_VAE_WORKSPACE_MAX_GB overrides, <= 0 lifts it); at most six
+ * (S2V_VAE_TILES_IN_FLIGHT overrides); for reporting */
 S2V_API int s2v_vae_workspace_info(s2v_vae* vae, int32_t* sets, int64_t* bytes_per_set);
 /* output extent of s2v_vae_decode for latents [1,F,C,h,w] */
 S2V_API int s2v_vae_out_shape(s2v_vae* vae, int32_t F, int32_t h, int32_t w, int32_t tiling, int32_t* Fo, int32_t* Ho, int32_t* Wo);
