@@ -207,8 +207,8 @@ def cpu_baseline_vae(s2v, dev, cores):
 
 
 # kernel names as rocprofv3 prints them (template arguments included)
-KERNEL_OF_CLASS = {"attention": "attn_qx_persist_k<2>", "gemm_qkv": "gemm_g4<4>", "gemm_ff1_gelu": "gemm_g4<1>",
-                   "gemm_out": "gemm_g4<2>", "gemm_ff2": "gemm_g4<2>"}  # <4>: QKV with the fused q/k norm + rotary epilogue
+KERNEL_OF_CLASS = {"attention": "attn_qx_persist_k<2>", "gemm_qkv": "gemm_g4t<4>", "gemm_ff1_gelu": "gemm_g4t<1>",
+                   "gemm_out": "gemm_g4<2>", "gemm_ff2": "gemm_g4<2>"}  # <4>: QKV with the fused q/k norm + rotary epilogue; g4t: trickled epilogue
 
 
 # which committed rocprofv3 PMC passes belong to which workload (profiles/README.md): rNN_ = the default workload,
@@ -238,7 +238,7 @@ def pmc_traffic_bytes(kernel_class, workload):
     def mean_kb(path):
         tot = cnt = 0.0
         for row in csv.reader(open(path)):
-            got = row[0].replace("void ", "").replace(", 0, false>", ">").replace(", 0>", ">").replace(" ", "") if row else ""
+            got = row[0].replace("void ", "").replace(", 0, false>", ">").replace(", 0>", ">").replace(", unsigned short>", ">").replace(" ", "") if row else ""
             # default template arguments and the return type are printed too; the attention kernel's name carries its format flags
             # (<2, false, false> bf16 P, <2, false, true> fp16 P, <2, true, ...> fp8 QK^T): any four-wave form of the pass counts
             if got == name.replace(" ", "") or (name.startswith("attn_qx_persist_k<2") and got.startswith("attn_qx_persist_k<2")):
