@@ -37,3 +37,19 @@ def test_whole_run_c3_10_steps_vs_fp32_matrix_pipe(s2v):
     # fp16 probabilities / fp8 QK^T add nothing measurable on top of their base format over a whole run
     assert abs(res["bf16-p16"][-1][2] - res["bf16"][-1][2]) <= 1e-3
     assert abs(res["fp8-qk"][-1][2] - res["fp8"][-1][2]) <= 1e-3
+
+
+def test_whole_run_2b_c3_10_steps_bf16_and_fp16_vs_fp32_matrix_pipe(s2v):
+    """BASELINE configs[1] (CogVideoX-2B, 30 layers, 49 x 480 x 720 -> 19 126 tokens): the same comparison in bf16 and in the fp16 model dtype
+    (what the reference loads a 2B checkpoint in, inference.py:191,209).  Measured in round 5 (profiles/r05_whole_run_2b_c3_50steps.txt):
+    step 10 bf16 rel-L2 9.9e-3 / max-abs 0.125, fp16 1.19e-3 / 1.94e-2 (max|latent| 4.7); all 50 steps: bf16 2.0e-2, fp16 2.4e-3.
+    Bars = 2 x measured.  ~45 s."""
+    lines = []
+    res, secs = _tool().whole_run(s2v, "cogvideox_2b", "c3", steps=10, schedule=50, formats=("bf16", "f16"), log=lines.append, arith_ref=False)
+    print("\n".join(lines))
+    bars = {"bf16": (2e-2, 0.25), "f16": (2.4e-3, 4e-2)}
+    for name, rows in res.items():
+        assert len(rows) == 10, name
+        for (i, ma, rl, rm, _, _) in rows:
+            assert rl <= bars[name][0] and ma <= bars[name][1], f"{name} step {i + 1}: rel-L2 {rl}, max-abs {ma} (max|ref| {rm})"
+    assert res["f16"][-1][2] < 0.25 * res["bf16"][-1][2]  # three more mantissa bits in every stored tensor

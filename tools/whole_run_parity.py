@@ -31,7 +31,8 @@ if ROOT not in sys.path:
 DEV = "cuda:0"
 GEOMETRY = {"c3": (13, 60, 90, 226), "c5": (13, 90, 160, 226), "small": (3, 8, 12, 226), "c1": (3, 32, 32, 226)}
 #            label       weight_format  attn_p_format
-FORMATS = {"bf16": (None, "bf16"), "bf16-p16": (None, "f16"), "fp8": ("fp8", "bf16"), "fp8-qk": ("fp8-qk", "bf16"), "fp8-qk-p16": ("fp8-qk", "f16")}
+FORMATS = {"bf16": (None, "bf16"), "bf16-p16": (None, "f16"), "fp8": ("fp8", "bf16"), "fp8-qk": ("fp8-qk", "bf16"), "fp8-qk-p16": ("fp8-qk", "f16"),
+           "f16": (None, "bf16")}  # "f16": the fp16 MODEL dtype (inference.py:191: every non-5B checkpoint), latents stored in fp16 between steps
 
 
 def _run(s2v, cfg, sd, dt, geometry, steps, schedule, inputs, sink, guidance=6.0, use_graph=True, round_latents=False):
@@ -108,7 +109,7 @@ def whole_run(s2v, preset="cogvideox_5b", geometry="c3", steps=10, schedule=50, 
                 row[4], row[5] = (a - b2).abs().max().item(), ((a - b2).norm() / b2.norm()).item()
             rows.append(tuple(row))
 
-        secs[name] = _run(s2v, c, sd, torch.bfloat16, geo, steps, schedule, inputs, sink)
+        secs[name] = _run(s2v, c, sd, torch.float16 if name == "f16" else torch.bfloat16, geo, steps, schedule, inputs, sink)
         res[name] = rows
         for (i, ma, rl, rm, ama, arl) in rows:
             log(f"{name:10s} step {i + 1:2d}: latents max-abs {ma:.3e} (max|ref| {rm:.2f})  rel-L2 {rl:.3e}   | vs f32-bf16lat: max-abs {ama:.3e}  rel-L2 {arl:.3e}")
