@@ -693,9 +693,9 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     // MFMA path: the per-head LayerNorm + rotary embedding of q and k run in the projection's epilogue (EPI_BIAS_QKNORM), on the
     // rounded projection as the stand-alone kernel does; only the V^T production remains a pass of its own
 #ifdef S2V_DIAG
-    const bool fused_qk = c->mfma && D % 64 == 0 && (!c->have_rope || c->rope_paired) && g_fused_qk;  // A/B switch of the diagnostics build
+    const bool fused_qk = (c->mfma || c->h16) && D % 64 == 0 && (!c->have_rope || c->rope_paired) && g_fused_qk;  // A/B switch of the diagnostics build
 #else
-    const bool fused_qk = c->mfma && D % 64 == 0 && (!c->have_rope || c->rope_paired);
+    const bool fused_qk = (c->mfma || c->h16) && D % 64 == 0 && (!c->have_rope || c->rope_paired);
 #endif
     if (fused_qk) {
         g.tok_per_batch = c->Ntok; g.text_len = c->T;

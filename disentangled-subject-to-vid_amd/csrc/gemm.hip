@@ -1254,7 +1254,8 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
                     "gemm_bf16: fused qk-norm needs the vector epilogue, N = 3 * qk_D and the LayerNorm parameters");
         if (!(a.m_begin > 0) && !(w_tile_ok(a) && a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM)) {
             const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
-            hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_QKNORM>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, st, a, tiles_m, tiles_n);
+            if (a.f16) hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS_QKNORM, f16_t>), dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, st, a, tiles_m, tiles_n);
+            else hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_QKNORM>, dim3(tiles_m * tiles_n), dim3(256), 4 * TILE_BYTES, st, a, tiles_m, tiles_n);
             S2V_CHECK_HIP(hipGetLastError());
             return 0;
         }
@@ -1264,21 +1265,26 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
         const int tiles_m = (a.M - a.m_begin + BM - 1) / BM, tiles_n = (a.N + BN - 1) / BN;
         const size_t shmem = 4 * TILE_BYTES;
         const dim3 grid(tiles_m * tiles_n);
-        switch (epi) {
-            case EPI_BIAS: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
-            case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_GELU>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
-            case EPI_BIAS_GATE_RES: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_GATE_RES>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
-            case EPI_BIAS_ADD: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_ADD>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
-            case EPI_BIAS_QKNORM: hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_QKNORM>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n); break;
+#define S2V_TAIL128(E)                                                                                                              \
+    if (a.f16) hipLaunchKernelGGL((gemm_bf16_128<E, f16_t>), grid, dim3(256), shmem, st, a, tiles_m, tiles_n);                         \
+    else hipLaunchKernelGGL(gemm_bf16_128<E>, grid, dim3(256), shmem, st, a, tiles_m, tiles_n);                                        \
+    break;
+        switch (epi) {  // a.f16: the fp16 instantiation (until round 5's last day this branch launched the bf16 kernel on fp16 operands)
+            case EPI_BIAS: S2V_TAIL128(EPI_BIAS)
+            case EPI_BIAS_GELU: S2V_TAIL128(EPI_BIAS_GELU)
+            case EPI_BIAS_GATE_RES: S2V_TAIL128(EPI_BIAS_GATE_RES)
+            case EPI_BIAS_ADD: S2V_TAIL128(EPI_BIAS_ADD)
+            case EPI_BIAS_QKNORM: S2V_TAIL128(EPI_BIAS_QKNORM)
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
+#undef S2V_TAIL128
         S2V_CHECK_HIP(hipGetLastError());
         return 0;
     }
     S2V_REQUIRE(a.K % BK == 0, "gemm_bf16: K must be a multiple of 64");
     // a.f16 (round 5): the operands are fp16 -- the same dispatch on the kernels' fp16 instantiations (the four-wave asm loop with the fp16 mnemonic,
-    // the eight-wave ping-pong, the staggered 256 x 128 ring, the 128 x 128 kernel); not for fp16: gemm_g4t, split K, the fused q/k-norm epilogue
-    S2V_REQUIRE(!a.f16 || (epi != EPI_BIAS_QKNORM && a.splitk <= 1 && a.mx_out_q == nullptr), "gemm (fp16): no fused q/k norm, split K or MX output");
+    // the eight-wave ping-pong, the staggered 256 x 128 ring, the 128 x 128 kernel), the fused q/k-norm epilogue included; not for fp16: gemm_g4t, split K
+    S2V_REQUIRE(!a.f16 || (a.splitk <= 1 && a.mx_out_q == nullptr), "gemm (fp16): no split K or MX output");
 #ifdef S2V_DIAG
     if (g_gemm_impl == 8 && !a.conv && (epi == EPI_BIAS || epi == EPI_BIAS_GELU) && w_tile_ok(a) && a.N % 64 == 0 && a.K >= 36 * 64 &&
         epi_vec_ok(a, epi) && a.a_rows_padded >= ((a.M + WBM - 1) / WBM) * WBM && a.lda % 8 == 0 && a.ldw % 8 == 0) {
@@ -1314,7 +1320,7 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             case EPI_BIAS_GELU: return a.f16 ? launch_pp64_t<EPI_BIAS_GELU, f16_t>(a, st) : launch_pp64_t<EPI_BIAS_GELU>(a, st);
             case EPI_BIAS_GATE_RES: return a.f16 ? launch_pp64_t<EPI_BIAS_GATE_RES, f16_t>(a, st) : launch_pp64_t<EPI_BIAS_GATE_RES>(a, st);
             case EPI_BIAS_ADD: return a.f16 ? launch_pp64_t<EPI_BIAS_ADD, f16_t>(a, st) : launch_pp64_t<EPI_BIAS_ADD>(a, st);
-            case EPI_BIAS_QKNORM: return launch_pp64_t<EPI_BIAS_QKNORM>(a, st);
+            case EPI_BIAS_QKNORM: return a.f16 ? launch_pp64_t<EPI_BIAS_QKNORM, f16_t>(a, st) : launch_pp64_t<EPI_BIAS_QKNORM>(a, st);
             default: return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);
         }
     }
@@ -1362,7 +1368,8 @@ int launch_gemm_bf16(const GemmArgs& a0, int epi, hipStream_t st) {
             else hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_ADD>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
             break;
         case EPI_BIAS_QKNORM:
-            hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_QKNORM>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            if (a.f16) hipLaunchKernelGGL((gemm_bf16_128<EPI_BIAS_QKNORM, f16_t>), dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
+            else hipLaunchKernelGGL(gemm_bf16_128<EPI_BIAS_QKNORM>, dim3(grid), dim3(256), shmem, st, a, tiles_m, tiles_n);
             break;
         default:
             return s2v_fail(__FILE__, __LINE__, "gemm_bf16: bad epilogue", -1);

@@ -218,8 +218,8 @@ int gemm_choose_splitk(int64_t tiles, int K, int64_t ncu) {
     while (S > 1 && !(K % (128 * S) == 0 && K / (64 * S) >= 16)) --S;
     return S;
 }
-// fp16 operands: the same conditions as gemm_g4_ok without split K and without the fused q/k norm epilogue
-bool gemm_g4_f16_ok(const GemmArgs& a, int epi) { return a.splitk <= 1 && epi != EPI_BIAS_QKNORM && a.mx_out_q == nullptr && gemm_g4_ok(a, epi); }
+// fp16 operands: the same conditions as gemm_g4_ok without split K
+bool gemm_g4_f16_ok(const GemmArgs& a, int epi) { return a.splitk <= 1 && a.mx_out_q == nullptr && gemm_g4_ok(a, epi); }
 int launch_gemm_g4_f16(const GemmArgs& a, int epi, hipStream_t st) {
     S2V_REQUIRE(gemm_g4_f16_ok(a, epi), "gemm_g4 (fp16): shape / epilogue not supported");
     switch (epi) {
@@ -227,6 +227,7 @@ int launch_gemm_g4_f16(const GemmArgs& a, int epi, hipStream_t st) {
         case EPI_BIAS_GELU: return launch_g4_t<EPI_BIAS_GELU, f16_t>(a, st);
         case EPI_BIAS_GATE_RES: return launch_g4_t<EPI_BIAS_GATE_RES, f16_t>(a, st);
         case EPI_BIAS_ADD: return launch_g4_t<EPI_BIAS_ADD, f16_t>(a, st);
+        case EPI_BIAS_QKNORM: return launch_g4_t<EPI_BIAS_QKNORM, f16_t>(a, st);
         default: return s2v_fail(__FILE__, __LINE__, "gemm_g4 (fp16): bad epilogue", -1);
     }
 }

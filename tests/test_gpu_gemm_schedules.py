@@ -180,10 +180,12 @@ def test_four_wave_persistent_kernel_matches_pingpong(s2v, epi):
     assert (out != ref).float().mean().item() < 2e-2
 
 
-def test_fused_qk_norm_rope_epilogue_is_bit_identical_to_the_separate_kernel(s2v):
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
+def test_fused_qk_norm_rope_epilogue_is_bit_identical_to_the_separate_kernel(s2v, dtype):
     """EPI_BIAS_QKNORM (QKV projection + per-head LayerNorm + rotary embedding in the GEMM epilogue) against the plain projection
     followed by qk_norm_rope_k: the diagnostics build can switch the fusion off, everything else being equal the two forwards must
-    agree bit for bit -- with rotary tables (5B-style) and without (2B-style), ragged token count, text rows in the middle of a tile."""
+    agree bit for bit -- with rotary tables (5B-style) and without (2B-style), ragged token count, text rows in the middle of a tile;
+    in bf16 and (round 5) in the fp16 model dtype, whose engine takes the same fused epilogue on the kernels' fp16 instantiations."""
     L = s2v._lib
     diag = L.diag_lib()
     prev = L._lib
@@ -196,7 +198,7 @@ def test_fused_qk_norm_rope_epilogue_is_bit_identical_to_the_separate_kernel(s2v
             outs = []
             for fused in (1, 0):
                 diag.s2v_set_fused_qk(fused)
-                eng = s2v.S2VEngine(cfg, torch.bfloat16, DEV)
+                eng = s2v.S2VEngine(cfg, dtype, DEV)
                 eng.load_state_dict(sd)
                 eng.set_geometry(2, 5, 3, 10, 14)
                 eng.prepare_tables(80, 112)

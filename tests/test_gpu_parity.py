@@ -741,6 +741,50 @@ def test_fp16_engine_long_sequence_runs_the_four_wave_kernel_and_matches_fp32(s2
     assert_close(outs[torch.float16], outs[torch.float32], "f16", "fp16 engine at 5127 tokens vs fp32 engine")
 
 
+def test_fp16_engine_row_tail_of_a_split_projection(s2v):
+    """fp16 model dtype at a geometry whose QKV projection is split into full 256-row tiles + a row tail on the side stream (43 x 6 tiles would
+    spill into a second round of 256 CUs, 42 x 6 do not: api.hip linear()).  The tail launch (gemm_bf16_128 at m_begin > 0) must run the fp16
+    instantiation -- until the last day of round 5 that branch launched the bf16 kernel on fp16 operands, which no test geometry reached.
+    Product build (q/k-norm fused into the projection's epilogue, also for fp16) and diagnostics build with the fusion off (plain-bias tail +
+    qk_norm_rope_k) against the fp32 engine, and bit-identical to each other."""
+    cfg = s2v.tiny(use_rope=True, heads=8, layers=1, text_dim=128, temb=64)
+    cfg.max_text_seq_length = 7
+    g = torch.Generator().manual_seed(43)
+    F, H, W = 4, 64, 68   # 7 + 5 * 32 * 34 = 5447 tokens, CFG pair: 10 894 rows = 42 tiles + 142 rows
+    sd = {k: v.half().float() for k, v in s2v.weights.synthetic_state_dict(cfg, seed=8, parity=True).items()}
+    lat0 = torch.randn(1, F, 16, H, W, generator=g).half()
+    text = torch.randn(2, 7, 128, generator=g).half()
+    ref = (torch.randn(1, 1, 16, H, W, generator=g) * 0.7).half()
+    L = s2v._lib
+    diag = L.diag_lib()
+    prev = L._lib
+    L.lib()
+
+    def fwd(dt):
+        m = s2v.HipCogVideoXTransformer3DModel(cfg, dt, DEV)
+        m.load_state_dict(sd)
+        eng = m.engine
+        eng.set_geometry(2, 7, F, H, W)
+        eng.prepare_tables(H * 8, W * 8)
+        eng.set_conditioning(text.to(dt), ref.to(dt))
+        out = eng.forward(lat0.to(dt), torch.tensor([500.0, 500.0]), shared_latent=True).float().cpu()
+        torch.cuda.synchronize()
+        return out
+
+    f32 = fwd(torch.float32)
+    fused = fwd(torch.float16)
+    try:
+        L._lib = diag
+        diag.s2v_set_fused_qk(0)
+        unfused = fwd(torch.float16)
+    finally:
+        diag.s2v_set_fused_qk(1)
+        L._lib = prev
+    assert torch.isfinite(fused).all() and torch.isfinite(unfused).all()
+    assert_close(fused, f32, "f16", "fp16 engine (fused q/k-norm, split QKV) vs fp32 engine")
+    assert torch.equal(fused, unfused), (fused - unfused).abs().max().item()
+
+
 def test_attn_q4h_saturates_v_beyond_the_fp16_range(s2v):
     """|V| > 65504 (finite in bf16) must not become an fp16 infinity in V^T -- 0 * inf in P.V would turn the head-dim column of EVERY
     query into NaN.  The fp16 V^T pass saturates; the result stays finite, and equals the bf16-P kernel's wherever the huge key carries no weight."""
