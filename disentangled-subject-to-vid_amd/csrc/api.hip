@@ -692,11 +692,17 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     g.C = c->QKV; g.ldc = 3 * D; g.M = (int)c->M; g.N = 3 * D; g.K = D;
     // MFMA path: the per-head LayerNorm + rotary embedding of q and k run in the projection's epilogue (EPI_BIAS_QKNORM), on the
     // rounded projection as the stand-alone kernel does; only the V^T production remains a pass of its own
+    // fp8 QK^T (weight_format 2 / 3 beyond its token threshold): q and k reach the attention kernel only as MX e4m3 images, so their LayerNorm + rotary
+    // embedding ride in the pass that makes the images (qk_norm_quant_mx_k: the same bytes moved, the same bits produced) and the projection keeps the plain
+    // bias epilogue -- its exposed q/k-norm epilogue is 20-25 % of an fp8 tile, whose K loop is half as long as the bf16 one
 #ifdef S2V_DIAG
-    const bool fused_qk = (c->mfma || c->h16) && D % 64 == 0 && (!c->have_rope || c->rope_paired) && g_fused_qk;  // A/B switch of the diagnostics build
+    const bool fuse_any = (c->mfma || c->h16) && D % 64 == 0 && (!c->have_rope || c->rope_paired) && g_fused_qk != 0;  // A/B switch of the diagnostics build:
+    const bool norm_in_quant = fuse_any && c->fp8_qk && g_fused_qk != 3;                                               // 0 stand-alone kernel, 3 epilogue even for fp8 QK^T
 #else
-    const bool fused_qk = (c->mfma || c->h16) && D % 64 == 0 && (!c->have_rope || c->rope_paired);
+    const bool fuse_any = (c->mfma || c->h16) && D % 64 == 0 && (!c->have_rope || c->rope_paired);
+    const bool norm_in_quant = fuse_any && c->fp8_qk;
 #endif
+    const bool fused_qk = fuse_any && !norm_in_quant;
     if (fused_qk) {
         g.tok_per_batch = c->Ntok; g.text_len = c->T;
         g.qk_w[0] = w.nq_w; g.qk_b[0] = w.nq_b; g.qk_w[1] = w.nk_w; g.qk_b[1] = w.nk_b;
@@ -711,7 +717,7 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     }
     // fp16 P / V^T is the four-wave kernels' (attn_q4h / attn_q4fh); short sequences run attn_pp on bf16 V^T
     const bool p16 = c->attn_p16 && c->mfma && (c->fp8_qk || attn_runs_q4(c->Ntok, attn_mx_out(c)));
-    if (fused_qk) {
+    if (fused_qk || norm_in_quant) {
         ProfScope ps(c, PK_QKNORM, st);
         S2V_TRY(launch_v_transpose(c->QKV, 3 * D, c->B, c->cfg.num_heads, c->Ntok, c->VT, c->ntok_pad, st, p16));
     } else {
@@ -736,8 +742,16 @@ static int run_attention(s2v_ctx* c, int l, hipStream_t st, bool prequant = fals
     if (c->fp8_qk) {  // weight_format 2: q (times scale * log2 e) and k as MX e4m3, QK^T on the scaled fp8 MFMA (the pass is timed with the V^T pass)
         {
             ProfScope ps(c, PK_QKNORM, st);
-            S2V_TRY(launch_qk_quant_mx(c->QKV, 3 * D, c->B, c->cfg.num_heads, c->Ntok, c->ntok_pad, a.scale * 1.4426950408889634f, c->q8, c->q8s, c->k8,
-                                       c->k8s, st));
+            if (norm_in_quant) {
+                QkNormRopeArgs q{};
+                q.qkv = c->QKV; q.ld_qkv = 3 * D; q.B = c->B; q.H = c->cfg.num_heads; q.Ntok = c->Ntok; q.text_len = c->T; q.ntok_pad = c->ntok_pad;
+                q.nq_w = w.nq_w; q.nq_b = w.nq_b; q.nk_w = w.nk_w; q.nk_b = w.nk_b; q.eps = 1e-6f;
+                q.cos = c->have_rope ? c->rope_cos : nullptr; q.sin = c->have_rope ? c->rope_sin : nullptr;
+                S2V_TRY(launch_qk_norm_quant_mx(q, a.scale * 1.4426950408889634f, c->q8, c->q8s, c->k8, c->k8s, st));
+            } else {
+                S2V_TRY(launch_qk_quant_mx(c->QKV, 3 * D, c->B, c->cfg.num_heads, c->Ntok, c->ntok_pad, a.scale * 1.4426950408889634f, c->q8, c->q8s, c->k8,
+                                           c->k8s, st));
+            }
         }
         a.q8 = c->q8; a.q8s = c->q8s; a.k8 = c->k8; a.k8s = c->k8s;
         ProfScope ps(c, PK_ATTN, st);

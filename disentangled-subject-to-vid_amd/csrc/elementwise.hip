@@ -537,6 +537,114 @@ int launch_qk_quant_mx(const void* qkv, int ld_qkv, int B, int H, int Ntok, int 
     return 0;
 }
 
+// The fp8-QK^T engine's q / k pass with the per-head LayerNorm + rotary embedding folded in (round 5): the RAW q / k of the QKV projection (plain
+// bias epilogue) -> qk_norm_rope_k's arithmetic with its rounding points (the same bits as the stand-alone kernel and as the projection's fused
+// EPI_BIAS_QKNORM epilogue: octet sums in element order, the 8-lane butterfly -- here one in-lane add of the thread's two octets and two shuffles --,
+// correctly rounded sqrt / reciprocal, (d * rstd) * w + b rounded to bf16, the rotary pair on the rounded values) -> qk_quant_mx_k's MX e4m3 images.
+// The attention kernel reads q and k ONLY through these images (attn_q4f), so the normalised bf16 q / k are never written: the pass moves the bytes
+// the quantisation pass moved anyway, and the projection's epilogue -- exposed VALU work behind a K loop half as long as the bf16 one -- goes back
+// to bias + rounding.  Thread = 16 head-dim elements (octets 2 qt, 2 qt + 1) of a (token, head); grid as qk_quant_mx_k.
+__global__ __launch_bounds__(256) void qk_norm_quant_mx_k(const QkNormRopeArgs a, float q_prescale, unsigned char* q8, unsigned short* q8s, unsigned char* k8,
+                                                           unsigned* k8s, int hg) {
+    // a block = 64 tokens x hg heads of q or k: the rotary values and the LayerNorm parameters of a thread (its token, its 16 head-dim elements) are the
+    // same for every head, so they are fetched once per hg heads (one head per block read four times the q / k bytes in table values)
+    const int tile = blockIdx.x, h0 = blockIdx.y * hg, b = blockIdx.z >> 1, is_k = blockIdx.z & 1;
+    const int tid = threadIdx.x, kr = tid >> 2, qt = tid & 3, blk = qt >> 1;
+    const int n = tile * 64 + kr;
+    const int H = a.H, Ntok = a.Ntok, ntok_pad = a.ntok_pad;
+    if (!is_k && n >= Ntok) return;  // the four threads of a row leave together
+    const int D = H * 64;
+    const bool live = n < Ntok;
+    const bool rope = live && a.cos != nullptr && n >= a.text_len;
+    float cs[16], sn[16], wv[16], bv[16];
+    if (live) {
+        const size_t tab = (size_t)(rope ? n - a.text_len : 0) * 64 + qt * 16;
+        if (a.cos != nullptr) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 4) {
+                Vec16<float>::ld(a.cos + tab + e, cs + e);
+                Vec16<float>::ld(a.sin + tab + e, sn + e);
+            }
+        }
+        const bf16_t* w = (const bf16_t*)(is_k ? a.nk_w : a.nq_w) + qt * 16;
+        const bf16_t* bb = (const bf16_t*)(is_k ? a.nk_b : a.nq_b) + qt * 16;
+        Vec16<bf16_t>::ld(w, wv); Vec16<bf16_t>::ld(w + 8, wv + 8);
+        Vec16<bf16_t>::ld(bb, bv); Vec16<bf16_t>::ld(bb + 8, bv + 8);
+    }
+    const float c = is_k ? 1.0f : q_prescale;
+#pragma unroll 1
+    for (int h = h0; h < h0 + hg; ++h) {
+        float x[16];
+        if (live) {
+            const bf16_t* src = (const bf16_t*)a.qkv + (size_t)(b * Ntok + n) * a.ld_qkv + is_k * D + h * 64 + qt * 16;
+            Vec16<bf16_t>::ld(src, x);
+            Vec16<bf16_t>::ld(src + 8, x + 8);
+            float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s0 += x[e]; s1 += x[8 + e]; }
+            float s = s0 + s1;
+            s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64);
+            const float mean = s * (1.0f / 64.0f);
+            float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d0 = x[e] - mean, d1 = x[8 + e] - mean;
+                q0 += d0 * d0; q1 += d1 * d1;
+            }
+            float q = q0 + q1;
+            q += __shfl_xor(q, 1, 64); q += __shfl_xor(q, 2, 64);
+            const float rstd = 1.0f / sqrtf(q * (1.0f / 64.0f) + a.eps);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = ET<bf16_t>::rnd((x[e] - mean) * rstd * wv[e] + bv[e]);
+            if (rope) {
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const float x0 = x[e], x1 = x[e + 1];
+                    x[e] = ET<bf16_t>::rnd(x0 * cs[e] + (-x1) * sn[e]);
+                    x[e + 1] = ET<bf16_t>::rnd(x1 * cs[e + 1] + x0 * sn[e + 1]);
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] *= c;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) x[e] = 0.f;
+        }
+        float amax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) amax = fmaxf(amax, fabsf(x[e]));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        unsigned eb = (__float_as_uint(amax * (1.0f / 448.0f)) + 0x7fffffu) >> 23;
+        eb = live ? min(max(eb, 1u), 253u) : 127u;
+        const float inv = __uint_as_float((254u - eb) << 23);
+        u32x4 o;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            int r = 0;
+            r = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * w] * inv, x[4 * w + 1] * inv, r, false);
+            r = __builtin_amdgcn_cvt_pk_fp8_f32(x[4 * w + 2] * inv, x[4 * w + 3] * inv, r, true);
+            o[w] = (unsigned)r;
+        }
+        const size_t bh = (size_t)b * H + h;
+        if (is_k) {
+            *(u32x4*)(k8 + (bh * ntok_pad + n) * 64 + qt * 16) = o;
+            if ((qt & 1) == 0)
+                ((unsigned char*)k8s)[((bh * (ntok_pad / 64) + tile) * 64 + blk * 32 + (kr & 31)) * 4 + (kr >> 5)] = (unsigned char)eb;
+        } else {
+            *(u32x4*)(q8 + (bh * Ntok + n) * 64 + qt * 16) = o;
+            if ((qt & 1) == 0) ((unsigned char*)q8s)[(bh * Ntok + n) * 2 + blk] = (unsigned char)eb;
+        }
+    }
+}
+int launch_qk_norm_quant_mx(const QkNormRopeArgs& a, float q_prescale, unsigned char* q8, unsigned short* q8s, unsigned char* k8, unsigned* k8s, hipStream_t st) {
+    S2V_REQUIRE(a.ntok_pad % 64 == 0 && a.ntok_pad >= a.Ntok, "qk_norm_quant_mx: ntok_pad must be a multiple of 64 covering Ntok");
+    S2V_REQUIRE(a.nq_w && a.nq_b && a.nk_w && a.nk_b && (a.cos == nullptr) == (a.sin == nullptr), "qk_norm_quant_mx: LayerNorm parameters / rotary tables");
+    const int hg = a.H % 4 == 0 ? 4 : a.H % 2 == 0 ? 2 : 1;
+    hipLaunchKernelGGL(qk_norm_quant_mx_k, dim3(a.ntok_pad / 64, a.H / hg, 2 * a.B), dim3(256), 0, st, a, q_prescale, q8, q8s, k8, k8s, hg);
+    S2V_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_qk_norm_rope(const QkNormRopeArgs& a, int dtype, hipStream_t st) {
     dim3 grid((unsigned)(a.B * a.Ntok), (unsigned)((2 * a.H * 8 + 255) / 256));
     S2V_DT_DISPATCH(dtype, hipLaunchKernelGGL(qk_norm_rope_k<T>, grid, dim3(256), 0, st, a))

@@ -165,6 +165,10 @@ static inline bool attn_runs_q4(int Ntok, bool mx_out) { return mx_out || Ntok >
 // q / k of the (normalised, rotated) QKV buffer -> the MX e4m3 images above (elementwise.hip)
 int launch_qk_quant_mx(const void* qkv, int ld_qkv, int B, int H, int Ntok, int ntok_pad, float q_prescale, unsigned char* q8, unsigned short* q8s,
                        unsigned char* k8, unsigned* k8s, hipStream_t st);
+// the same images from the RAW q / k of the projection: per-head LayerNorm + rotary (qk_norm_rope_k's arithmetic) folded into the quantisation pass;
+// a.vt is ignored (V^T stays launch_v_transpose's); bf16 only (elementwise.hip)
+struct QkNormRopeArgs;
+int launch_qk_norm_quant_mx(const QkNormRopeArgs& a, float q_prescale, unsigned char* q8, unsigned short* q8s, unsigned char* k8, unsigned* k8s, hipStream_t st);
 // attn_q4 with QK^T on the scaled fp8 MFMA (attention_q4.hip); needs a.q8 / q8s / k8 / k8s and a.vt
 int launch_attn_q4f(const AttnArgs& a, bool persistent, hipStream_t st);
 // attn_q4 with P / V^T in fp16 (AttnArgs::p16 = 1)

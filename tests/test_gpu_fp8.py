@@ -377,6 +377,40 @@ def test_op_attention_fp8qk_matches_emulated_quantisation(s2v, B, H, N):
     assert rel1 <= 6e-2, rel1
 
 
+@pytest.mark.parametrize("use_rope", [True, False], ids=["rope", "sincos"])
+def test_fp8_qk_norm_folded_into_the_quantisation_pass_is_bit_identical(s2v, use_rope):
+    """under fp8 QK^T the attention kernel reads q and k only as MX e4m3 images, so the product folds their per-head LayerNorm + rotary embedding
+    into the pass that makes the images (qk_norm_quant_mx_k) and leaves the QKV projection its plain bias epilogue.  The diagnostics build can put
+    the normalisation back into the projection's epilogue (3) or into the stand-alone kernel (0): the same arithmetic at the same rounding points
+    in all three places -> the same forward, bit for bit (ragged token count, text rows inside a tile, with and without rotary tables)."""
+    import copy
+
+    L = s2v._lib
+    diag = L.diag_lib()
+    prev = L._lib
+    L.lib()
+    try:
+        L._lib = diag
+        cfg = s2v.tiny(use_rope=use_rope, heads=4, layers=2, text_dim=128, temb=64)
+        cfg.max_text_seq_length = 7
+        cfg.weight_format = "fp8-qk"
+        sd = s2v.weights.synthetic_state_dict(cfg, seed=5, parity=True)
+        g = torch.Generator().manual_seed(19)
+        lat = torch.randn(1, 3, 16, 18, 22, generator=g).bfloat16()
+        text = torch.randn(2, 7, 128, generator=g).bfloat16()
+        ref = (torch.randn(1, 1, 16, 18, 22, generator=g) * 0.7).bfloat16()
+        outs = []
+        for mode in (1, 3, 0):
+            diag.s2v_set_fused_qk(mode)
+            outs.append(_run_engine(s2v, copy.copy(cfg), sd, lat, text, ref, 300.0)[1].clone())
+        assert torch.isfinite(outs[0].float()).all()
+        assert torch.equal(outs[0], outs[1]), ("quantisation pass vs projection epilogue", (outs[0].float() - outs[1].float()).abs().max().item())
+        assert torch.equal(outs[0], outs[2]), ("quantisation pass vs stand-alone kernel", (outs[0].float() - outs[2].float()).abs().max().item())
+    finally:
+        diag.s2v_set_fused_qk(1)
+        L._lib = prev
+
+
 @pytest.mark.parametrize("lat_hw,frames", [((16, 24), 3), ((8, 12), 2), ((32, 48), 2)])
 def test_fp8_qk_engine_vs_fp8_and_bf16_engines(s2v, lat_hw, frames):
     """weight_format = "fp8-qk" (fp8 linears AND MX e4m3 QK^T, an option beyond configs[4]'s "fp8 weights"): against the bf16 engine within the
