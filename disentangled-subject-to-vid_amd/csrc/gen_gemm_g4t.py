@@ -26,9 +26,19 @@ The LAST tile of a workgroup leaves its accumulators to the C++ epilogue (gemm_e
 Arithmetic is that of gemm_epi.h instruction for instruction (y = acc + bias, one v_cvt_pk_bf16_f32; GELU = x * rcp(1 + exp2(x *
 fma(x * x, k1, k0))) on the rounded value): results are bit-identical to gemm_g4 (tests/test_gpu_gemm_schedules.py).
 
+Round 5, gemm_g4t_body_qknorm.inc: the fused QKV projection (EPI_BIAS_QKNORM).  Tiles whose previous tile held v heads take the bias trickle above;
+q / k tiles take qk_program(): the previous tile's rows get their per-head LayerNorm + affine + rotary embedding in the READ-BACK layout (lane = row,
+octet -- the layout and order of operations of gemm_epi.h, hence the same bits) between the patch read-back and the stores, ~165 VALU per row, 32 rows
+per lane, 32 K-tiles at three slots per MFMA.  Registers: the E registers of units already written to the patch (unit 0: the row's values + temporaries;
+units 1, 2: a four-row ring of rotary values requested three rows ahead); the lane constants, LayerNorm parameters and position arithmetic come from an LDS
+block and v99's upper bits because no SGPR or VGPR is left to pass them in.  Vector-memory instructions (rotary loads, stores) leave only in the loop's store
+steps: met elsewhere they are parked and the program runs on; consumers wait with vmcnt(number of vector-memory instructions issued since), which the
+generator counts (one in-order counter over loads, LDS-DMA and stores on gfx9).
+
 Hazards handled by hand (the assembler inserts nothing): v_exp / v_rcp results are never consumed by the next instruction (gfx950 trans-use
 hazard: the two chains of a packed pair are interleaved); SGPRs written by v_readfirstlane reach memory instructions only through s_mov /
-s_add; MFMA results are read (v_accvgpr_read) a barrier and 24 DMA issues after the last MFMA.
+s_add; (qknorm) two wait states between a VALU write and a DPP read of the register and between v_cmp and the v_cndmask that reads its mask, one after
+v_sqrt / v_rcp; MFMA results are read (v_accvgpr_read) a barrier and 24 DMA issues after the last MFMA.
 
 Registers.  a[0:255] accumulators.  v[0:63] fragments (bias + drain temporaries between tiles); v[64:79] IN fragment addresses; v[80:95] IN
 staging offsets; v96 IN store offset of the lane ((lane >> 3) * ldc + (lane & 7) * 8) * 2; v97 IN patch write address of the lane;
