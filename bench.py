@@ -43,9 +43,9 @@ WORKLOADS = {
     "cogvideox-5b-49x720x1280": ("cogvideox-5b", 13, 90, 160, 226),
     "cogvideox-5b-fp8-49x720x1280": ("cogvideox-5b-fp8", 13, 90, 160, 226),
     "cogvideox-5b-fp8-49x480x720": ("cogvideox-5b-fp8", 13, 60, 90, 226),
-    # weight_format "fp8" proper (linears only) at the configs[4] geometry, for comparison: the configs[4] preset itself is "fp8-auto" since round 5
-    # (fp8 QK^T from 40 000 tokens on; config.cogvideox_5b_fp8)
-    "cogvideox-5b-fp8lin-49x720x1280": ("cogvideox-5b-fp8lin", 13, 90, 160, 226),
+    # the opt-in throughput preset BEYOND configs[4]'s "fp8 weights" (config.cogvideox_5b_fp8_auto): fp8 QK^T from 40 000 tokens on + fp16 P
+    "cogvideox-5b-fp8auto-49x720x1280": ("cogvideox-5b-fp8-auto", 13, 90, 160, 226),
+    "cogvideox-5b-fp8lin-49x720x1280": ("cogvideox-5b-fp8lin", 13, 90, 160, 226),   # round-5 name of cogvideox-5b-fp8-49x720x1280
     # an option BEYOND configs[4]'s "fp8 weights": additionally q / k as MX e4m3 and QK^T on the scaled fp8 MFMA (weight_format 2)
     "cogvideox-5b-fp8qk-49x720x1280": ("cogvideox-5b-fp8qk", 13, 90, 160, 226),
     "cogvideox-5b-fp8qk-49x480x720": ("cogvideox-5b-fp8qk", 13, 60, 90, 226),

@@ -45,6 +45,7 @@ _SIGS = {
     "s2v_weight_slot": [_P, ctypes.c_char_p, ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64), ctypes.POINTER(_I64)],
     "s2v_mark_weights_loaded": [_P],
     "s2v_set_geometry": [_P, _I32, _I32, _I32, _I32, _I32],
+    "s2v_fp8_qk_active": [_P, ctypes.POINTER(_I32)],
     "s2v_set_rope": [_P, _P, _P, _P],
     "s2v_set_pos_embed": [_P, _P, _P],
     "s2v_set_conditioning": [_P, _P, _P, _P],
@@ -68,6 +69,7 @@ _SIGS = {
 }
 # replicas over RCCL behind the C ABI (csrc/rccl.hip); RCCL itself is bound at first use
 _SIGS.update({
+    "s2v_rccl_available": [],
     "s2v_rccl_unique_id": [_P],
     "s2v_rccl_comm_create": [_P, _I32, _I32, ctypes.POINTER(_P)],
     "s2v_rccl_bcast": [_P, _P, _I64, _I32, _P],

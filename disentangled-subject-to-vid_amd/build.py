@@ -45,6 +45,13 @@ def _read(path):
 
 
 DIAG_LIB = os.path.join(HERE, "libs2v_hip_diag.so")
+# generated asm (outputs are committed): generator -> EVERY file it writes (a missing one of them re-runs the generator).
+# tests/test_host_cpu.py holds this table to the truth twice: every `#include "*.inc"` / `*_regs.h` under csrc/ must appear here, and each
+# generator, re-run into a scratch directory (S2V_GEN_OUT), must write exactly these files with exactly the committed bytes.
+GENERATORS = [("gen_attn_q4.py", ["attn_q4_body.inc", "attn_q4h_body.inc", "attn_q4f_body.inc", "attn_q4fh_body.inc", "attn_q4hh_body.inc", "attn_q8_body.inc", "attn_q4_regs.h"]),
+              ("gen_gemm_g4.py", ["gemm_g4_body.inc", "gemm_g4_body_f16.inc", "gemm_g4_sk_sum.inc", "gemm_g4_regs.h"]),
+              ("gen_gemm_g4t.py", ["gemm_g4t_body_gelu.inc", "gemm_g4t_body_bias.inc", "gemm_g4t_body_qknorm.inc", "gemm_g4t_regs.h"]),
+              ("gen_gemm_g4f.py", ["gemm_g4f_body_a3.inc", "gemm_g4f_body_mx.inc", "gemm_g4f_regs.h"])]
 
 
 def build_library(force=False, verbose=True, diag=False):
@@ -59,11 +66,7 @@ def build_library(force=False, verbose=True, diag=False):
     objdir = os.path.join(HERE, "build_diag" if diag else "build")
     LIB = DIAG_LIB if diag else globals()["LIB"]
     FLAGS = globals()["FLAGS"] + (["-DS2V_DIAG"] if diag else [])
-    # generated asm (outputs are committed): generator -> EVERY file it writes (a missing one of them re-runs the generator)
-    gens = [("gen_attn_q4.py", ["attn_q4_body.inc", "attn_q4h_body.inc", "attn_q4f_body.inc", "attn_q4fh_body.inc", "attn_q4hh_body.inc", "attn_q8_body.inc", "attn_q4_regs.h"]),
-            ("gen_gemm_g4.py", ["gemm_g4_body.inc", "gemm_g4_body_f16.inc", "gemm_g4_sk_sum.inc", "gemm_g4_regs.h"]),
-            ("gen_gemm_g4t.py", ["gemm_g4t_body_gelu.inc", "gemm_g4t_body_bias.inc", "gemm_g4t_regs.h"]),
-            ("gen_gemm_g4f.py", ["gemm_g4f_body_a3.inc", "gemm_g4f_body_mx.inc", "gemm_g4f_regs.h"])]
+    gens = GENERATORS
     headers = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith((".h", ".inc"))]
     headers.append(os.path.join(HERE, "..", "include", "s2v_hip.h"))
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]

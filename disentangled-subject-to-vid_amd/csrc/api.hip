@@ -46,8 +46,8 @@ struct s2v_ctx {
     s2v_model_config cfg;
     int D = 0, L = 0, dtype = 0, esz = 0, temb = 0;
     bool mfma = false;
-    int attn_order = 0;          // AttnArgs::order (S2V_ATTN_ORDER at s2v_create: an experiment knob, default 0)
-    int attn_stagger = 0;        // AttnArgs::stagger (S2V_ATTN_STAGGER at s2v_create: an experiment knob, default 0)
+    int attn_order = 0;          // AttnArgs::order (S2V_ATTN_ORDER at s2v_create of the DIAGNOSTICS build: an experiment knob, 0 in the product)
+    int attn_stagger = 0;        // AttnArgs::stagger (S2V_ATTN_STAGGER, same: 0 in the product)
     bool h16 = false;            // fp16 model dtype: linears on v_mfma_f32_32x32x16_f16 (gemm_f16), attention on attn_f32m<f16_t>
     int mc = 6;                  // modulation chunks per norm{1,2}.linear in the stack: 6, or 9 under lora_adaln_scope = 1 (+ the
                                  // reference-image copy of chunks 0-2: cond_shift, cond_scale, cond_gate)
@@ -179,8 +179,10 @@ extern "C" int s2v_create(const s2v_model_config* cfg, s2v_ctx** out) {
     }
     c->mfma = (cfg->dtype == S2V_DTYPE_BF16) && !cfg->force_simple;
     c->h16 = (cfg->dtype == S2V_DTYPE_F16) && !cfg->force_simple;
-    if (const char* e = getenv("S2V_ATTN_STAGGER")) c->attn_stagger = atoi(e);
+#ifdef S2V_DIAG  // experiment knobs of the diagnostics build only; clamped: slot * stagger * 64 cycles of s_sleep per launch
+    if (const char* e = getenv("S2V_ATTN_STAGGER")) c->attn_stagger = std::min(std::max(atoi(e), 0), 64);
     if (const char* e = getenv("S2V_ATTN_ORDER")) c->attn_order = atoi(e) ? 1 : 0;
+#endif
     if (hipMalloc((void**)&c->attn_stats, 4096) != hipSuccess || hipMemset(c->attn_stats, 0, 4096) != hipSuccess) {
         s2v_destroy(c);
         return s2v_fail(__FILE__, __LINE__, "s2v_create: attention census allocation failed", -2);
@@ -513,6 +515,12 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     c->hq = (unsigned char*)(w + ohq); c->hs = (unsigned char*)(w + ohs);
     c->q8 = (unsigned char*)(w + oq8); c->q8s = (unsigned short*)(w + oq8s); c->k8 = (unsigned char*)(w + ok8); c->k8s = (unsigned*)(w + ok8s);
     c->sk_ws = (float*)(w + osk); c->sk_cnt = (unsigned*)(w + oskc);
+    return 0;
+}
+
+extern "C" int s2v_fp8_qk_active(s2v_ctx* c, int32_t* active) {
+    S2V_REQUIRE(c && active, "s2v_fp8_qk_active: null argument");
+    *active = c->fp8_qk ? 1 : 0;
     return 0;
 }
 
@@ -1016,6 +1024,8 @@ extern "C" int s2v_profile_read_clocks(s2v_ctx* c, float* mhz_by_class, int32_t 
     }
     for (int k = 0; k < nclass && k < PK_NUM; ++k) mhz_by_class[k] = ticks[k] > 0 ? (float)(cyc[k] / ticks[k] * 100.0) : 0.f;
     c->clk_rec.clear();
+    // the slots are handed out again from 0: a later pass that did not go through s2v_profile_enable(1) must not read these stamps
+    if (c->clk_buf) S2V_CHECK_HIP(hipMemset(c->clk_buf, 0, sizeof(long long) * 4 * CLK_SLOTS));
     return 0;
 }
 // Synchronises, then returns total milliseconds and launch counts per class since the last read; resets.

@@ -324,8 +324,9 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
     // Start stagger (round 5, configs[4] locality experiment): the 32 workgroups of an XCD walk consecutive q-blocks of one head, i.e. the SAME
     // K / V^T tiles, and every item costs the same -- started together they request each tile within the latency of its first miss.  With
     // a.stagger > 0 slot s of the XCD starts s * stagger * 64 cycles late, once per launch: a convoy in which the leader misses in L2 and the
-    // followers find the tile there.  0 = start together (the default; profiles/r05_attn_stagger.txt for what it measured).
-#ifndef S2V_NO_CLK_STAMP
+    // followers find the tile there.  0 = start together (the default; profiles/r05_attn_stagger.txt for what it measured: slower).  The
+    // diagnostics build only: the product kernel carries neither this knob nor the a.order experiment below.
+#ifdef S2V_DIAG
     if (a.stagger > 0) {
         const int slot = (int)(blockIdx.x >> 3);
         for (int i = 0; i < slot * a.stagger; i += 64) __builtin_amdgcn_s_sleep(64);
@@ -340,13 +341,18 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
                 int first, cnt;
                 // a.order 0: XCD y owns a contiguous range of items (a head's q-blocks stay on one XCD); 1 (experiment, round 5): a head's q-blocks
                 // are dealt round-robin over the XCDs (q-block qb on XCD qb & 7), so all 32 workgroups of an XCD are on the SAME head at any time
-                const int per = a.order ? (nqb > y ? (nqb - y + 7) >> 3 : 0) : 0;
-                if (a.order) { first = 0; cnt = (total / nqb) * per; }
+#ifdef S2V_DIAG
+                const bool dealt = a.order != 0;
+#else
+                constexpr bool dealt = false;
+#endif
+                const int per = dealt ? (nqb > y ? (nqb - y + 7) >> 3 : 0) : 0;
+                if (dealt) { first = 0; cnt = (total / nqb) * per; }
                 else attn_xcd_range(total, y, first, cnt);
                 if (__hip_atomic_load(&queue[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cnt) continue;
                 const int i = atomicAdd(&queue[y], 1);
                 if (i < cnt) {
-                    if (a.order) { const int bh = i / per, j = i - bh * per; wg = bh * nqb + y + 8 * j; }
+                    if (dealt) { const int bh = i / per, j = i - bh * per; wg = bh * nqb + y + 8 * j; }
                     else wg = first + i;
                 }
             }

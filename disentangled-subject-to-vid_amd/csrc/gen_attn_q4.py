@@ -602,7 +602,7 @@ def gen():
 
 
 def main():
-    here = os.path.dirname(os.path.abspath(__file__))
+    here = os.environ.get("S2V_GEN_OUT") or os.path.dirname(os.path.abspath(__file__))  # S2V_GEN_OUT: tests/test_host_cpu.py regenerates into a scratch directory
     with open(os.path.join(here, "attn_q4_regs.h"), "w") as f:
         f.write("// generated by gen_attn_q4.py: the physical registers the bodies of attn_q4 (JB = 2) / attn_q8 (JB = 1) own\n#pragma once\n")
         for jb, name, f8, p16, h16 in ((2, "Q4", False, False, False), (1, "Q8", False, False, False), (2, "Q4F", True, False, False), (2, "Q4H", False, True, False),

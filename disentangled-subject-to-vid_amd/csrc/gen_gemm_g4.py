@@ -511,7 +511,7 @@ def gen_sk_sum():
 
 
 def main():
-    here = os.path.dirname(os.path.abspath(__file__))
+    here = os.environ.get("S2V_GEN_OUT") or os.path.dirname(os.path.abspath(__file__))  # S2V_GEN_OUT: tests/test_host_cpu.py regenerates into a scratch directory
     body = gen_reg() if STAGE == "reg" else gen()
     with open(os.path.join(here, "gemm_g4_body.inc"), "w") as f:
         for ln in body:

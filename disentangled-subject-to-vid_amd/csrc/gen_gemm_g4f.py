@@ -175,7 +175,7 @@ def gen(mx):
 
 
 def main():
-    here = os.path.dirname(os.path.abspath(__file__))
+    here = os.environ.get("S2V_GEN_OUT") or os.path.dirname(os.path.abspath(__file__))  # S2V_GEN_OUT: tests/test_host_cpu.py regenerates into a scratch directory
     maps = {}
     for mx in (False, True):
         body, M = gen(mx)

@@ -723,7 +723,7 @@ def gen(epi):
 
 
 def main():
-    here = os.path.dirname(os.path.abspath(__file__))
+    here = os.environ.get("S2V_GEN_OUT") or os.path.dirname(os.path.abspath(__file__))  # S2V_GEN_OUT: tests/test_host_cpu.py regenerates into a scratch directory
     tks = {}
     for epi in EPI:
         body, tk = gen(epi)

@@ -81,6 +81,8 @@ struct s2v_rccl_comm {
     int rank = 0, world = 1, device = 0;
 };
 
+extern "C" int s2v_rccl_available(void) { return need_rccl(); }
+
 extern "C" int s2v_rccl_unique_id(void* id128) {
     S2V_REQUIRE(id128, "s2v_rccl_unique_id: null argument");
     S2V_TRY(need_rccl());

@@ -81,15 +81,15 @@ def init_from_env(backend=None, timeout_s=None):
 
 
 def rccl_available_everywhere():
-    """True when EVERY rank can bind librccl through the library (s2v_rccl_unique_id dlopens it): the native-broadcast decision has to be
-    the same on all ranks, or some would enter ncclBroadcast and the others torch.distributed.broadcast."""
-    import ctypes
-
+    """(ok, bad): ok is True when EVERY rank can bind librccl through the library; bad lists (rank, reason) of those that cannot.  The
+    native-broadcast decision has to be the same on all ranks, or some would enter ncclBroadcast and the others torch.distributed.broadcast.
+    The probe is s2v_rccl_available: dlopen + symbol lookup only -- no unique id is drawn, so no bootstrap thread or listening socket is left
+    behind on the ranks whose id would never be used."""
     from . import _lib
 
     ok, why = 1, ""
     try:
-        _lib.check(_lib.lib().s2v_rccl_unique_id(ctypes.create_string_buffer(128)))
+        _lib.check(_lib.lib().s2v_rccl_available())
     except Exception as e:
         ok, why = 0, str(e)
     if dist.is_initialized() and dist.get_world_size() > 1:

@@ -136,17 +136,15 @@ class S2VEngine:
         for k in kinds:
             self.epoch[k] += 1
 
-    FP8_QK_AUTO_TOKENS = 40000   # csrc/api.hip S2V_FP8_QK_AUTO_TOKENS
-
     @property
     def fp8_qk_active(self):
-        """whether QK^T of the attention runs in fp8 at the current geometry ("fp8-qk": always; "fp8-auto": from 40 000 tokens per sample on)"""
-        if self.cfg.weight_format == "fp8-qk":
-            return True
-        if self.cfg.weight_format == "fp8-auto" and self.geometry is not None:
-            B, T, F, H, W = self.geometry
-            return T + (F + 1) * (H // 2) * (W // 2) >= self.FP8_QK_AUTO_TOKENS
-        return False
+        """whether QK^T of the attention runs in fp8 at the current geometry ("fp8-qk": always; "fp8-auto": from the library's token threshold on).
+        The library took the decision at s2v_set_geometry and is asked for it (s2v_fp8_qk_active): nothing is re-derived here."""
+        if self.cfg.weight_format not in ("fp8-qk", "fp8-auto"):
+            return False
+        on = ctypes.c_int32()
+        _lib.check(_lib.lib().s2v_fp8_qk_active(self._h, ctypes.byref(on)))
+        return bool(on.value)
 
     def set_geometry(self, B, T, F, H, W):
         new = self.geometry != (B, T, F, H, W)

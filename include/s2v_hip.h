@@ -32,8 +32,9 @@ extern "C" {
 typedef struct s2v_ctx s2v_ctx;
 typedef void* s2v_stream; /* hipStream_t */
 
-/* F16 (round 5): the dtype the reference selects for every non-5B checkpoint (src/inference.py:191,209).  Transformer contexts
- * (s2v_create), the scheduler step and the operator-level entry points take it; the VAE / T5 contexts are fp32 / bf16. */
+/* F16 (round 5): the dtype the reference selects for every non-5B checkpoint (src/inference.py:191,209: transformer, VAE and text
+ * encoder alike).  Transformer contexts (s2v_create), the VAE decoder / encoder (s2v_vae_create, s2v_vae_enc_create), the T5 encoder
+ * (s2v_t5_create), the scheduler step and the operator-level entry points all take it. */
 enum { S2V_DTYPE_F32 = 0, S2V_DTYPE_BF16 = 1, S2V_DTYPE_F16 = 2 };
 
 /* CogVideoXTransformer3DModel.__init__ hyper-parameters
@@ -54,13 +55,14 @@ typedef struct s2v_model_config {
                                * (fused QKV, attention out, FF1, FF2) keep OCP e4m3 weights with per-output-channel scales
                                * (quantised by s2v_finalize_weights after any LoRA merge) and take per-token e4m3 activations,
                                * on v_mfma_scale_f32_32x32x64_f8f6f4; bf16 model dtype only, inner_dim % 128 == 0;
-                               * 2 = 1 plus fp8 QK^T (an option beyond "fp8 weights", off unless asked for): after the per-head LayerNorm and
+                               * 2 = 1 plus fp8 QK^T (an option BEYOND configs[4]'s "fp8 weights", off unless asked for): after the per-head LayerNorm and
                                * rotary embedding q (times scale * log2 e) and k are re-quantised as MX e4m3 (one power-of-two scale per
                                * 32 head-dim elements) and S = K.Q^T of the attention runs on the same scaled fp8 MFMA; softmax, P and P.V
                                * stay fp32 / bf16;
                                * 3 = 1 below 40 000 tokens per sample, 2 from there on (decided at s2v_set_geometry): at the configs[4] geometry
                                * (N = 50 626) the attention is > 80 % of the step, fp8 QK^T takes 11-14 % off it and adds nothing measurable to the
-                               * fp8 engine's whole-run drift (profiles/r05_whole_run_c5_10steps.txt) -- what the package's configs[4] preset uses.
+                               * fp8 engine's whole-run drift on synthetic weights (profiles/r05_whole_run_c5_10steps.txt).  Opt-in like 2: the package's
+                               * configs[4] preset is 1; its "cogvideox-5b-fp8-auto" preset asks for 3.  s2v_fp8_qk_active reports the decision.
                                * The reference has no fp8 path: parity unpinned, tolerance stated in tests/test_gpu_fp8.py */
     int32_t lora_adaln_scope; /* where the subject-LoRA acts inside CogVideoXLayerNormZero (normalization.py:467-484):
                                * 0 = as shipped: `enable_lora([self.linear], False)` sets an attribute nothing reads, so the LoRA
@@ -109,6 +111,10 @@ S2V_API int s2v_weight_slot(s2v_ctx* ctx, const char* name, int64_t* offset_byte
  * (R = (H/2)(W/2) reference-image tokens, V = F*R video tokens, sequence order [text | ref | video]).
  * Allocates the activation workspace (no allocation happens inside the compute calls). */
 S2V_API int s2v_set_geometry(s2v_ctx* ctx, int32_t B, int32_t T, int32_t F, int32_t H, int32_t W);
+
+/* whether QK^T of the attention runs in MX e4m3 at the current geometry: weight_format 2 always, 3 from its token threshold on (the decision
+ * s2v_set_geometry took), 0 otherwise -- callers report this instead of re-deriving the threshold */
+S2V_API int s2v_fp8_qk_active(s2v_ctx* ctx, int32_t* active);
 
 /* RoPE tables, fp32 [R + V, 64] (reference rows first): cos/sin as produced by
  * get_3d_rotary_pos_embed (embeddings.py:505-570) and sliced in custom_cogvideox_pipe.py:223-235.
@@ -189,6 +195,9 @@ S2V_API int s2v_mark_weights_loaded(s2v_ctx* ctx);
  * to the other ranks by any means (a file, a socket, torch.distributed's store), every rank -- with ITS GPU current -- calls
  * s2v_rccl_comm_create, then s2v_bcast_weights / s2v_rccl_bcast on a stream of that GPU. */
 typedef struct s2v_rccl_comm s2v_rccl_comm;
+/* 0 when librccl and every symbol this file needs can be bound (dlopen + dlsym only: no bootstrap thread, no socket, no communicator);
+ * < 0 with the reason in s2v_last_error() otherwise.  What every rank calls before the ranks agree on the native path. */
+S2V_API int s2v_rccl_available(void);
 S2V_API int s2v_rccl_unique_id(void* id128 /* out: 128 bytes */);
 S2V_API int s2v_rccl_comm_create(const void* id128, int32_t rank, int32_t world, s2v_rccl_comm** out);
 S2V_API void s2v_rccl_comm_destroy(s2v_rccl_comm* comm);

@@ -63,6 +63,9 @@ def case(s2v):
     return dict(cfg=cfg, sd=sd, lat0=lat0, pe=pe, ne=ne, ref=ref, vcfg=vcfg, sdv=sdv, per_step=per_step, video=video)
 
 
+FP16_LATENT_BAR, FP16_VIDEO_BAR = 7.5e-3, 2.5e-2   # round 6: to be set at 2 x measured once the fp16-VAE decode has run on the GPU
+
+
 def run_hip(s2v, case, dt, use_graph, vae_dt=None):
     m = s2v.HipCogVideoXTransformer3DModel(case["cfg"], dt, DEV)
     m.load_state_dict(case["sd"])
@@ -102,11 +105,12 @@ def test_c1_bf16_drift_is_bounded_and_reported(s2v, case):
 
 def test_c1_fp16_drift_is_bounded_and_reported(s2v, case):
     """the fp16 model dtype (src/inference.py:191,209: what the reference loads a 2B checkpoint in) at configs[0]'s real depth: 30 layers x 10
-    steps against the fp32 oracle; the decode runs in fp32 (the VAE context is fp32 / bf16)"""
-    got, video = run_hip(s2v, case, torch.float16, use_graph=True, vae_dt=torch.float32)
+    steps against the fp32 oracle, and the decode through an fp16 VAE as the reference moves it (src/inference.py:239) -- the fp16 latents into the
+    fp16 decoder at real width (the test used to decode in fp32)"""
+    got, video = run_hip(s2v, case, torch.float16, use_graph=True, vae_dt=torch.float16)
     drift = [rel_l2(a, b) for a, b in zip(got, case["per_step"])]
     print("fp16 per-step relative-L2 drift of the latents vs the fp32 oracle:", " ".join(f"{e:.2e}" for e in drift))
-    assert torch.isfinite(got[-1]).all() and drift[-1] <= 7.5e-3, drift   # bf16 bar / 8
+    assert torch.isfinite(got[-1]).all() and drift[-1] <= FP16_LATENT_BAR, drift
     vr = rel_l2(video, case["video"])
-    print(f"fp16 latents decoded in fp32: video relative L2 vs the fp32 oracle: {vr:.2e}")
-    assert torch.isfinite(video).all() and vr <= 1.25e-2, vr
+    print(f"fp16 latents decoded by the fp16 VAE: video relative L2 vs the fp32 oracle: {vr:.2e}")
+    assert torch.isfinite(video).all() and vr <= FP16_VIDEO_BAR, vr

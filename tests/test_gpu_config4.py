@@ -117,9 +117,12 @@ def test_config4_fp8_engine_full_geometry(s2v, fmt):
 
 
 def test_fp8_auto_is_fp8_below_40k_tokens_and_fp8_qk_above(s2v):
-    """weight_format "fp8-auto" (the configs[4] preset since round 5, config.cogvideox_5b_fp8): bit-identical to "fp8" at a short sequence and to
-    "fp8-qk" at configs[4]'s 50 626 tokens (the decision is taken at s2v_set_geometry)"""
-    assert s2v.config.cogvideox_5b_fp8().weight_format == "fp8-auto"
+    """weight_format "fp8-auto" (the opt-in config.cogvideox_5b_fp8_auto preset; the configs[4] preset config.cogvideox_5b_fp8 is "fp8 weights" =
+    linears only again since round 6): bit-identical to "fp8" at a short sequence and to "fp8-qk" at configs[4]'s 50 626 tokens (the
+    decision is taken at s2v_set_geometry and read back through s2v_fp8_qk_active)"""
+    assert s2v.config.cogvideox_5b_fp8().weight_format == "fp8" and s2v.config.PRESETS["cogvideox-5b-fp8"]().attn_p_format == "bf16"
+    auto = s2v.config.PRESETS["cogvideox-5b-fp8-auto"]()
+    assert auto.weight_format == "fp8-auto" and auto.attn_p_format == "f16"
     cfg = s2v.cogvideox_5b()
     cfg.num_layers = 1
     sd = s2v.weights.synthetic_state_dict(cfg, seed=47, device=DEV, parity=True)

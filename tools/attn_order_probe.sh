@@ -1,5 +1,7 @@
 #!/bin/bash
 # configs[4] attention locality, second experiment: a head's q-blocks on ONE XCD (S2V_ATTN_ORDER=0, the default) against dealt over the eight XCDs (1).
+# the knob is read by the DIAGNOSTICS build only since round 6: S2V_LIB selects it
+export S2V_LIB="$(cd "$(dirname "$0")/.." && pwd)/disentangled-subject-to-vid_amd/libs2v_hip_diag.so"
 export TMPDIR=/tmp S2V_BENCH_SKIP_PFMT=1 S2V_BENCH_SKIP_PARITY_PASS=1
 for W in cogvideox-5b-fp8lin-49x720x1280 cogvideox-5b-fp8-49x720x1280 cogvideox-5b-49x480x720; do
  for o in 0 1; do

@@ -1,5 +1,7 @@
 #!/bin/bash
 # configs[4] attention locality experiment: start stagger of the persistent attention launch (S2V_ATTN_STAGGER = units of 64
+# the knob is read by the DIAGNOSTICS build only since round 6: S2V_LIB selects it
+export S2V_LIB="$(cd "$(dirname "$0")/.." && pwd)/disentangled-subject-to-vid_amd/libs2v_hip_diag.so"
 # cycles per XCD slot) at N = 50 626 -- ms per launch + shader clock from the bench's profile pass, FETCH_SIZE from a --pmc pass.
 export TMPDIR=/tmp S2V_BENCH_SKIP_PFMT=1 S2V_BENCH_SKIP_PARITY_PASS=1
 W=${W:-cogvideox-5b-fp8-49x720x1280}
