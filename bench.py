@@ -117,57 +117,106 @@ def best_cpu_threads():
     return best
 
 
-def cpu_baseline(s2v, cfg, F, H, W, T, dev):
-    """the oracle (CPU restatement, torch fp32, on the thread count best_cpu_threads() picks) timed on a bounded sample: ONE transformer block for
-    ONE of the two CFG samples at the full token count, extrapolated x2 x num_layers.  The block's output is then compared with
-    the HIP path (bf16, s2v_block_forward) on the same bf16-rounded weights and inputs: the oracle is the checker here."""
+FULL_STEP_MAX_TOKENS = 2048   # "full runs only for C1" (1250 tokens, ~15 s per step on 8 cores); larger geometries time one block
+
+
+def cpu_baseline(s2v, cfg, F, H, W, T, dev, dt=torch.bfloat16):
+    """the oracle (CPU restatement, torch fp32, on the thread count best_cpu_threads() picks) timed beside EVERY workload:
+      * configs[0]'s geometry (N <= FULL_STEP_MAX_TOKENS): the FULL denoise step -- all layers, the CFG pair, CFG + DDIM step -- and its latents are
+        compared with s2v_denoise_step in the line's model dtype on the same weights (fp32 line: un-rounded fp32 weights, the CPU-reference-parity mode);
+      * every other geometry: ONE transformer block for ONE of the two CFG samples at the full token count, extrapolated x2 x num_layers, its
+        output compared with s2v_block_forward in the line's dtype / weight format on the same (bf16- / fp16-rounded) weights and inputs.
+    fp8 engines: the oracle holds the bf16-rounded weights -- there is no fp8 reference arithmetic, the comparison is labelled unpinned.
+    The oracle is the checker here, never the thing shipped."""
     import copy
 
-    from oracle import transformer_ref as tr
+    from oracle import sched_ref, transformer_ref as tr
 
     cores = best_cpu_threads()
     torch.set_num_threads(cores)
-    c1 = copy.copy(cfg)
-    c1.num_layers = 1
-    D, heads = c1.inner_dim, c1.num_attention_heads
     R = (H // 2) * (W // 2)
     V = F * R
-    dt = torch.bfloat16
-    sd = {k: v.to(dt).float() for k, v in s2v.weights.synthetic_state_dict(c1, seed=21, parity=True).items()}
-    g = torch.Generator().manual_seed(22)
-    h, e0, e1 = (torch.randn(1, n, D, generator=g).to(dt).float() for n in (V, T, R))
-    temb = torch.randn(1, c1.time_embed_dim, generator=g).to(dt).float()
-    rope = ref_rope = None
-    if c1.use_rotary_positional_embeddings:
-        ref_rope, rope = tr.pipeline_rope(H * 8, W * 8, F)
-    with torch.no_grad():
-        t0 = time.time()
-        exp = tr.block_forward(sd, "transformer_blocks.0.", heads, h, e0, e1, temb, rope, ref_rope)
-        dts = time.time() - t0
-    m = s2v.HipCogVideoXTransformer3DModel(c1, dt, dev)
-    m.load_state_dict(sd)
-    kw = {}
-    if rope is not None:
-        kw = dict(image_rotary_emb=tuple(x.to(dev) for x in rope), ref_image_rotary_emb=tuple(x.to(dev) for x in ref_rope))
-    got = m.transformer_blocks[0](hidden_states=h.to(dev, dt), encoder_hidden_states=e0.to(dev, dt), temb=temb.to(dev, dt),
-                                  enc_hidden_states1=e1.to(dev, dt), embed_ref_img=True, ref_img_seq_start=T,
-                                  ref_img_seq_end=T + R, position_delta=0, timestep=None, layer=0, **kw)
-    torch.cuda.synchronize()
-    y, e = torch.cat([x.float().cpu().flatten() for x in got]), torch.cat([x.flatten() for x in exp])
-    step_s = dts * 2 * cfg.num_layers
     N = T + R + V
+    D, heads = cfg.inner_dim, cfg.num_attention_heads
+    fp8 = cfg.weight_format is not None
+    rnd = (lambda x: x.float()) if dt == torch.float32 else (lambda x: x.to(dt).float())
     blk_flop = 2 * N * D * 12 * D + 4 * N * N * D  # one block, one sample: QKV + out + FF1 + FF2 linears, QK^T + PV
-    vae_leg = cpu_baseline_vae(s2v, dev, cores)
-    return {"value": 1.0 / step_s, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"1 of {cfg.num_layers} transformer blocks x 1 of 2 CFG samples at the full token count, torch "
-                      f"fp32 on {cores} threads: {dts:.1f} s, extrapolated x{2 * cfg.num_layers}",
-            "gflops": round(blk_flop / dts / 1e9, 1), "vae_decode": vae_leg,
-            "max_abs_vs_hip": round((y - e).abs().max().item(), 5), "rel_l2_vs_hip": round(((y - e).norm() / e.norm()).item(), 6),
-            "max_abs_ref": round(e.abs().max().item(), 3),
-            "vs_hip_note": "the same block through s2v_block_forward in bf16 on the same bf16-rounded weights / inputs"}
+    vae_leg = cpu_baseline_vae(s2v, dev, cores, vae_scaling=cfg.vae_scaling_factor, F=F, H=H, W=W)
+    rope = ref_rope = None
+    if cfg.use_rotary_positional_embeddings:
+        ref_rope, rope = tr.pipeline_rope(H * 8, W * 8, F)
+    dname = {torch.float32: "fp32", torch.bfloat16: "bf16", torch.float16: "fp16"}[dt]
+    if N <= FULL_STEP_MAX_TOKENS:
+        sd = {k: rnd(v) for k, v in s2v.weights.synthetic_state_dict(cfg, seed=21, parity=True).items()}
+        g = torch.Generator().manual_seed(22)
+        lat = rnd(torch.randn(1, F, cfg.in_channels, H, W, generator=g))
+        text = rnd(torch.randn(2, T, cfg.text_embed_dim, generator=g))
+        ref = rnd(torch.randn(1, 1, cfg.in_channels, H, W, generator=g) * 0.7)
+        ocfg = dict(num_heads=heads, num_layers=cfg.num_layers, use_rope=cfg.use_rotary_positional_embeddings, norm_eps=cfg.norm_eps,
+                    spatial_scale=cfg.spatial_interpolation_scale, temporal_scale=cfg.temporal_interpolation_scale)
+        sch = s2v.CogVideoXDDIMScheduler(snr_shift_scale=cfg.snr_shift_scale)
+        sch.set_timesteps(10)
+        t = sch.timesteps[1]
+        with torch.no_grad():
+            t0 = time.time()
+            npred = tr.transformer_forward(sd, ocfg, torch.cat([lat] * 2), text, ref, torch.tensor([int(t), int(t)]), rope, ref_rope)
+            v = sched_ref.cfg_combine(npred, 6.0)
+            exp, _ = sched_ref.ddim_step(sched_ref.alphas_cumprod(cfg.snr_shift_scale), 10, v, int(t), lat)
+            dts = time.time() - t0
+        m = s2v.HipCogVideoXTransformer3DModel(cfg, dt, dev)
+        m.load_state_dict(sd)
+        eng = m.engine
+        eng.set_geometry(2, T, F, H, W)
+        eng.prepare_tables(H * 8, W * 8)
+        eng.set_conditioning(text, ref)
+        x = lat.to(dev, dt).contiguous().clone()
+        eng.denoise_step(x, float(t), sch.coef(t, dt, 6.0))
+        torch.cuda.synchronize()
+        y, e = x.float().cpu().flatten(), exp.float().flatten()
+        eng.close()
+        step_s = dts
+        sample = (f"the FULL denoise step (all {cfg.num_layers} layers, the CFG pair of {N} tokens each, CFG + DDIM step) through oracle.transformer_ref / "
+                  f"sched_ref, torch fp32 on {cores} threads: {dts:.1f} s, nothing extrapolated")
+        note = f"the same step through s2v_denoise_step in {dname} on the same weights / inputs: deviation of the latents after the step"
+        gflops = 2 * cfg.num_layers * blk_flop / dts / 1e9
+    else:
+        c1 = copy.copy(cfg)
+        c1.num_layers = 1
+        sd = {k: rnd(v) for k, v in s2v.weights.synthetic_state_dict(c1, seed=21, parity=True).items()}
+        g = torch.Generator().manual_seed(22)
+        h, e0, e1 = (rnd(torch.randn(1, n, D, generator=g)) for n in (V, T, R))
+        temb = rnd(torch.randn(1, c1.time_embed_dim, generator=g))
+        with torch.no_grad():
+            t0 = time.time()
+            exp = tr.block_forward(sd, "transformer_blocks.0.", heads, h, e0, e1, temb, rope, ref_rope)
+            dts = time.time() - t0
+        m = s2v.HipCogVideoXTransformer3DModel(c1, dt, dev)
+        m.load_state_dict(sd)
+        kw = {}
+        if rope is not None:
+            kw = dict(image_rotary_emb=tuple(x.to(dev) for x in rope), ref_image_rotary_emb=tuple(x.to(dev) for x in ref_rope))
+        got = m.transformer_blocks[0](hidden_states=h.to(dev, dt), encoder_hidden_states=e0.to(dev, dt), temb=temb.to(dev, dt),
+                                      enc_hidden_states1=e1.to(dev, dt), embed_ref_img=True, ref_img_seq_start=T,
+                                      ref_img_seq_end=T + R, position_delta=0, timestep=None, layer=0, **kw)
+        torch.cuda.synchronize()
+        y, e = torch.cat([x.float().cpu().flatten() for x in got]), torch.cat([x.flatten() for x in exp])
+        m.engine.close()
+        step_s = dts * 2 * cfg.num_layers
+        sample = (f"1 of {cfg.num_layers} transformer blocks x 1 of 2 CFG samples at the full token count ({N}), torch "
+                  f"fp32 on {cores} threads: {dts:.1f} s, extrapolated x{2 * cfg.num_layers}")
+        note = (f"the same block through s2v_block_forward in {dname}" + (f" with weight_format {cfg.weight_format!r}" if fp8 else "")
+                + f" on the same {dname}-rounded weights / inputs")
+        gflops = blk_flop / dts / 1e9
+    out = {"value": 1.0 / step_s, "unit": "steps/s", "cores": cores, "kind": "port", "sample": sample,
+           "gflops": round(gflops, 1), "vae_decode": vae_leg,
+           "max_abs_vs_hip": float(f"{(y - e).abs().max().item():.3e}"), "rel_l2_vs_hip": float(f"{((y - e).norm() / e.norm()).item():.3e}"),
+           "max_abs_ref": round(e.abs().max().item(), 3), "vs_hip_note": note}
+    if fp8:
+        out["parity"] = "unpinned: the reference has no fp8 arithmetic (SURVEY 8c-7); the oracle computes the bf16 model the fp8 engine quantises"
+    return out
 
 
-def cpu_baseline_vae(s2v, dev, cores):
+def cpu_baseline_vae(s2v, dev, cores, vae_scaling=0.7, F=13, H=60, W=90):
     """the second half of the metric (wall-clock per video) on the host cores: ONE frame batch (2 latent frames -> 8 frames) of a
     12 x 16 latent window (96 x 128 pixels) on the threads of the transformer leg, at most 16 -- with all 256 host threads torch's conv3d
     on windows of this size collapses to 10 GFLOP/s (87 s for a 6 x 8 window that eight threads finish in 0.5 s) --
@@ -176,7 +225,7 @@ def cpu_baseline_vae(s2v, dev, cores):
     window through s2v_vae_decode is the check"""
     from oracle import vae_ref
 
-    vcfg = s2v.VAEConfig(scaling_factor=0.7)
+    vcfg = s2v.VAEConfig(scaling_factor=vae_scaling)
     cfgd = dict(block_out_channels=tuple(vcfg.block_out_channels), layers_per_block=vcfg.layers_per_block, norm_num_groups=vcfg.norm_num_groups,
                 latent_channels=vcfg.latent_channels, out_channels=vcfg.out_channels, temporal_compression_ratio=vcfg.temporal_compression_ratio,
                 sample_height=vcfg.sample_height, sample_width=vcfg.sample_width, scaling_factor=vcfg.scaling_factor)
@@ -197,11 +246,15 @@ def cpu_baseline_vae(s2v, dev, cores):
     got = vae.decode_latents(lat.to(dev, dt)).float().cpu()
     torch.cuda.synchronize()
     vae.close()
-    units = 9 * (5 + 1.5) * (30 * 45) / (wh * ww)
-    unit_flop = 441e12 / units  # 441 TFLOP for the tiled decode of 49 x 480 x 720
-    return {"value": round(units * dts, 1), "unit": "s per tiled decode of 49 x 480 x 720 (extrapolated)", "cores": cores, "kind": "port",
+    # tiles of tiled_decode (autoencoder_kl_cogvideox.py:1400-1406: 30 x 45 latent tiles every 25 rows / 36 columns, the last ones partial), each
+    # decoded in F / 2 two-frame-batch units (one 3-frame batch = 1.5, then 2-frame batches: :1237-1245)
+    tiles = [(min(30, H - r), min(45, W - c)) for r in range(0, H, 25) for c in range(0, W, 36)] if (H > 30 or W > 45) else [(H, W)]
+    units = (F / 2.0) * sum(th * tw for th, tw in tiles) / (wh * ww)
+    unit_flop = 441e12 / (6.5 * 7560 / (wh * ww))  # 441 TFLOP for the tiled decode of 49 x 480 x 720 = 6.5 units x 7560 latent pixels
+    # (its nine tiles are 30/30/10 rows x 45/45/18 columns: 1.4 x the 5400 pixels of the untiled 315 TFLOP; until round 5 this leg extrapolated with nine FULL tiles, 1.6 x too much CPU time)
+    return {"value": round(units * dts, 1), "unit": f"s per tiled decode of {(F - 1) * 4 + 1} x {H * 8} x {W * 8} (extrapolated)", "cores": cores, "kind": "port",
             "sample": f"one two-frame batch of a {wh} x {ww} latent window of the real-width decoder, torch fp32 on {cores} threads: {dts:.1f} s, "
-                      f"extrapolated x{units:.0f} (area, 9 tiles, 6.5 two-frame batches)",
+                      f"extrapolated x{units:.0f} (area of the {len(tiles)} tiles, {F / 2.0:g} two-frame batches)",
             "gflops": round(unit_flop / dts / 1e9, 1), "rel_l2_vs_hip": round(((got - exp).norm() / exp.norm()).item(), 6),
             "max_abs_vs_hip": round((got - exp).abs().max().item(), 5), "max_abs_ref": round(exp.abs().max().item(), 3)}
 
@@ -373,11 +426,20 @@ def main(argv=None):
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"], help="model dtype of the engine, VAE and T5: bf16 = the headline (and every "
                     "5B configuration); f32 = configs[0] as BASELINE names it (the CPU-reference-parity mode, on the fp32 matrix pipe); f16 = what the "
                     "reference loads non-5B checkpoints in (src/inference.py:191).  Non-bf16 lines skip the format A/B passes and the CPU baseline")
+    ap.add_argument("--batch", type=int, default=2, choices=[1, 2], help="2 = the CFG pair on one GPU (the metric); 1 = ONE sample of the pair: what each of the two "
+                    "GPUs of a CFG-parallel pair runs per step (s2v_denoise_split_begin + the CFG / scheduler step; the peer's half is a local copy) -- "
+                    "reported as projected_cfg_parallel_ms, the step time of one video on two GPUs less the 2.2 MB all-gather")
+    ap.add_argument("--cfg-parallel", action="store_true", help="--gpus N (even): ranks 2p, 2p+1 run video p TOGETHER (dist.CfgPair: B = 1 engines, one all-gather "
+                    "of noise_pred per step, CFG + scheduler step on both); value = video steps/s over all pairs")
     ap.add_argument("--dist-selftest", action="store_true", help="no GPU: exercise the rank launcher, the rendezvous, the chunked broadcast and its "
                     "watchdog with gloo on CPU tensors (tests/test_dist_gloo.py)")
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.cfg_parallel and (args.gpus < 2 or args.gpus % 2):
+        raise SystemExit("--cfg-parallel pairs the ranks up: --gpus must be even and >= 2 (one GPU: --batch 1 gives the projection)")
+    if args.cfg_parallel:
+        args.batch = 1
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         rc = spawn_ranks(args.gpus, argv)
@@ -416,9 +478,11 @@ def main(argv=None):
     dt = {"bf16": torch.bfloat16, "f32": torch.float32, "f16": torch.float16}[args.dtype]
     if fp8 and args.dtype != "bf16":
         raise SystemExit("fp8 workloads are bf16 engines (weight_format needs the bf16 MFMA path)")
-    if args.dtype != "bf16":  # the A/B passes are about the bf16 asm kernels; the CPU-baseline check compares against a bf16 block
+    if args.dtype != "bf16":  # the A/B passes are about the bf16 asm kernels
         os.environ["S2V_BENCH_SKIP_PFMT"] = os.environ["S2V_BENCH_SKIP_PARITY_PASS"] = "1"
-        args.no_cpu_baseline = True
+    if args.batch == 1:  # the half-step lines carry the step and its per-kernel table; formats, video and CPU baseline belong to the metric's own line
+        os.environ["S2V_BENCH_SKIP_PFMT"] = os.environ["S2V_BENCH_SKIP_PARITY_PASS"] = "1"
+        args.no_vae = args.no_cpu_baseline = True
     PEAK_DT = {"bf16": PEAK_BF16_TFLOPS, "f16": PEAK_BF16_TFLOPS, "f32": PEAK_F32_TFLOPS}[args.dtype]
     vae = None
     if rank == 0 and not args.no_vae:
@@ -477,15 +541,42 @@ def main(argv=None):
     text = torch.randn(2, T, cfg.text_embed_dim, generator=g, device=dev)
     ref = torch.randn(1, 1, cfg.in_channels, H, W, generator=g, device=dev) * 0.7
     latents = torch.randn(1, F, cfg.in_channels, H, W, generator=g, device=dev).to(dt).contiguous()
-    eng.set_geometry(2, T, F, H, W)
-    eng.prepare_tables(H * 8, W * 8)
-    eng.set_conditioning(text, ref)
+    cfg_pair = None
+    if args.cfg_parallel:
+        # video p on ranks 2p, 2p + 1: the pair shares ONE prompt, reference latent and start latents (drawn from the pair's seed); rank slot holds half slot
+        cfg_pair = s2v.dist.CfgPair(native=native_bcast)   # --native-bcast also selects s2v_rccl_allgather for the per-step exchange
+        g = torch.Generator(device=dev).manual_seed(100 + cfg_pair.pair)
+        text = torch.randn(2, T, cfg.text_embed_dim, generator=g, device=dev)
+        ref = torch.randn(1, 1, cfg.in_channels, H, W, generator=g, device=dev) * 0.7
+        latents = torch.randn(1, F, cfg.in_channels, H, W, generator=g, device=dev).to(dt).contiguous()
     sch = s2v.CogVideoXDDIMScheduler(snr_shift_scale=cfg.snr_shift_scale)
     sch.set_timesteps(50)
     coefs = [sch.coef(t, dt, 6.0) for t in sch.timesteps]
 
+    def set_batch(nb, slot=1):
+        """geometry + tables + conditioning of the CFG pair on this GPU (nb = 2) or of ONE sample of it (nb = 1: half `slot` of [negative | positive])"""
+        eng.set_geometry(nb, T, F, H, W)
+        eng.prepare_tables(H * 8, W * 8)
+        eng.set_conditioning(text if nb == 2 else text[slot:slot + 1], ref)
+
+    def step_b1(i, graph, x=None):
+        """what ONE GPU of a CFG-parallel pair does per step, on one GPU: the B = 1 forward (graph replay) into its half of the pair buffer, the peer's
+        half stood in for by a device copy of its own (the all-gather's local traffic; guidance on two equal halves is the identity), CFG + scheduler step"""
+        x = latents if x is None else x
+        eng.denoise_split_begin(x, float(sch.timesteps[i % 50]), coefs[i % 50], 1, use_graph=graph)
+        pair = eng.cfg_pair()
+        pair[0].copy_(pair[1], non_blocking=True)
+        eng.denoise_split_end(x)
+
+    set_batch(args.batch, cfg_pair.slot if cfg_pair else 1)
+
     def step(i, graph):
-        eng.denoise_step(latents, float(sch.timesteps[i % 50]), coefs[i % 50], use_graph=graph)
+        if cfg_pair is not None:
+            cfg_pair.step(eng, latents, float(sch.timesteps[i % 50]), coefs[i % 50], use_graph=graph)
+        elif args.batch == 1:
+            step_b1(i, graph)
+        else:
+            eng.denoise_step(latents, float(sch.timesteps[i % 50]), coefs[i % 50], use_graph=graph)
 
     def timed(graph, nsteps, nwarm):
         """W untimed + K timed steps between barrier + synchronize on both sides; max over ranks"""
@@ -571,13 +662,14 @@ def main(argv=None):
         ms, cnt, mhz, prof_elapsed = profile_pass(eng, prof_steps, lambda i: step(i, False))
         N = T + (F + 1) * (H // 2) * (W // 2)
         D = cfg.inner_dim
-        flops = {"gemm_qkv": 2 * 2 * N * D * 3 * D, "attention": 4 * 2 * N * N * D, "gemm_out": 2 * 2 * N * D * D,
-                 "gemm_ff1_gelu": 2 * 2 * N * D * 4 * D, "gemm_ff2": 2 * 2 * N * D * 4 * D}
+        NB = args.batch  # samples per forward on this GPU: 2 = the CFG pair, 1 = one sample of it (--batch 1 / --cfg-parallel)
+        flops = {"gemm_qkv": 2 * NB * N * D * 3 * D, "attention": 4 * NB * N * N * D, "gemm_out": 2 * NB * N * D * D,
+                 "gemm_ff1_gelu": 2 * NB * N * D * 4 * D, "gemm_ff2": 2 * NB * N * D * 4 * D}
         # HBM-bound kernels: algorithmic bytes per launch: LayerNorm + modulate reads and writes the residual
         # stream once; the V transpose reads V and writes V^T; the modulation GEMV streams every norm linear's weights once per step
         E = 4 if args.dtype == "f32" else 2
         mod_rows = 2 * cfg.num_layers * 6 * D + 2 * D
-        hbm_bytes = {"ln_modulate": 2 * (2 * N * D * E), "qknorm_rope_vt": 2 * (2 * N * D * E), "mod_gemv": mod_rows * cfg.time_embed_dim * E}
+        hbm_bytes = {"ln_modulate": 2 * (NB * N * D * E), "qknorm_rope_vt": 2 * (NB * N * D * E), "mod_gemv": mod_rows * cfg.time_embed_dim * E}
         per_kernel = {}
         for k, name in enumerate(CLASSES):
             if cnt[k] == 0:
@@ -605,7 +697,7 @@ def main(argv=None):
         # unique operand bytes of one launch (bf16 activations; fp8 engines read 1-byte weights / activations on the GEMMs):
         # attention reads Q, K, V^T and writes O; a GEMM reads A [M,K] and W [N,K] and writes C [M,N]
         Eg = 1 if fp8 else 2
-        Mr = 2 * N
+        Mr = NB * N
         algo_bytes = {"attention": 4 * Mr * D * 2, "gemm_qkv": Mr * D * Eg + 3 * D * D * Eg + Mr * 3 * D * 2,
                       "gemm_out": Mr * D * Eg + D * D * Eg + Mr * D * 2, "gemm_ff1_gelu": Mr * D * Eg + 4 * D * D * Eg + Mr * 4 * D * Eg,
                       "gemm_ff2": Mr * 4 * D * Eg + 4 * D * D * Eg + Mr * D * 2}
@@ -623,7 +715,7 @@ def main(argv=None):
         if rank == 0:
             # (a) CALIBRATED peak: what the vendor library reaches in this process, on this box, now, on the FF1 shape -- the part is
             # power-managed (shader_clock_mhz above), so the datasheet's 2.5 PF at 2.4 GHz is not what the matrix pipe can deliver under load
-            Mr2, Kc, Nc = 2 * N, D, 4 * D
+            Mr2, Kc, Nc = 2 * N, D, 4 * D   # always the B = 2 FF1 shape: the calibration is about the box, not the batch
             xa = torch.randn(Mr2, Kc, device=dev, dtype=dt)
             xw = torch.randn(Kc, Nc, device=dev, dtype=dt)
             for _ in range(3):
@@ -691,6 +783,33 @@ def main(argv=None):
                 eng2.close()
                 del eng2, lat2
                 torch.cuda.empty_cache()
+
+    # ---- CFG-parallel projection: the step ONE GPU of a pair runs, timed here on one GPU the same way as the metric
+    cfgp = None
+    if rank == 0 and world == 1 and args.batch == 2 and not args.single_mode and not os.environ.get("S2V_BENCH_SKIP_CFGP"):
+        keep = latents.clone()
+        set_batch(1)
+        nb1 = min(args.steps, 10)
+        for i in range(2):
+            step_b1(i, True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(nb1):
+            step_b1(2 + i, True)
+        torch.cuda.synchronize()
+        b1_ms = (time.perf_counter() - t1) / nb1 * 1e3
+        cfgp = {"b1_step_ms": round(b1_ms, 2), "ratio_to_cfg_pair_step": round(b1_ms / (elapsed / args.steps * 1e3), 4),
+                "projected_cfg_parallel_ms": round(b1_ms, 2), "projected_steps_per_s_per_video_on_2_gpus": round(1e3 / b1_ms, 4),
+                "note": f"{nb1} hipGraph steps of ONE sample of the CFG pair (s2v_denoise_split_begin, the peer's half stood in for by a device copy, "
+                        "s2v_denoise_split_end) on this GPU: what each GPU of a CFG-parallel pair runs per step, less the 2.2 MB all-gather over xGMI; "
+                        "`python bench.py --batch 1` gives the per-kernel table of this step, `--gpus 2 --cfg-parallel` the real thing"}
+        if not args.no_roofline:
+            msb, cntb, _, _ = profile_pass(eng, 1, lambda i: step_b1(i, False))
+            cfgp["per_kernel_avg_ms"] = {name: round(msb[k] / cntb[k], 4) for k, name in enumerate(CLASSES) if cntb[k]}
+            cfgp["per_kernel_ratio_to_cfg_pair"] = {name: round(v / roofline["per_kernel"][name]["avg_ms"], 4)
+                                                    for name, v in cfgp["per_kernel_avg_ms"].items() if name in roofline["per_kernel"]}
+        set_batch(2)
+        latents.copy_(keep)
 
     video = None
     if rank == 0 and not args.no_vae:
@@ -765,24 +884,32 @@ def main(argv=None):
                  "frames": list(frames.shape), "frames_finite": bool(torch.isfinite(frames.float()).all().item())}
     if rank == 0:
         out = {
-            "metric": "denoise steps/sec (CogVideoX-5B, 49f 720x480; one step = CFG-pair transformer forward + CFG + "
-                      "scheduler step)" if "5b" in args.workload else f"denoise steps/sec ({args.workload})",
-            "value": round(total_steps / elapsed, 4),  # sum over ranks of the steps they ran / max over ranks of the elapsed time
+            "metric": ("denoise steps/sec (CogVideoX-5B, 49f 720x480; one step = CFG-pair transformer forward + CFG + "
+                       "scheduler step)" if "5b" in args.workload else f"denoise steps/sec ({args.workload})")
+                      + ("" if args.batch == 2 else "; each step of a video runs on TWO GPUs (CFG-parallel), one sample of the pair per GPU"
+                         if args.cfg_parallel else "; --batch 1: ONE sample of the CFG pair per step on this GPU = half a step (the CFG-parallel projection)"),
+            # sum over ranks of the steps they ran / max over ranks of the elapsed time; a rank of a CFG-parallel pair (and a --batch 1 run) does HALF of every step
+            "value": round(total_steps / elapsed / (1 if args.batch == 2 else 2), 4),
             "unit": "steps/s",
             "n_gpus": n_devices, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if (args.cfg_parallel and world == 2) else "weak", "vs_baseline": None,
             "dtype": ("fp8 (e4m3 W8A8 block linears, MX e4m3 QK^T) + bf16" if eng.fp8_qk_active else "fp8 (e4m3 W8A8 block linears) + bf16") if fp8 else args.dtype, "data": "synthetic (seeded N(0,0.02^2) weights, N(0,1) latents / prompt embeddings)",
             "config": {"workload": args.workload, "latent_frames": F, "latent_hw": [H, W], "tokens": T + (F + 1) * (H // 2) * (W // 2),
-                       "cfg_pair": 2, "scheduler": "ddim-trailing-50", "weight_format": cfg.weight_format, "fp8_qk_active": eng.fp8_qk_active if fp8 else None, "attn_p_format": cfg.attn_p_format if cfg.attn_p_format != "auto" else f"auto -> {eng.attn_p_format}",
-                       "attn_slow_path_fraction": eng.attn_slow_fraction, "parallelism": f"replicas x{world}",
+                       "cfg_pair": 2, "samples_per_gpu_per_step": args.batch, "scheduler": "ddim-trailing-50",
+                       "projected_cfg_parallel_ms": round(elapsed / args.steps * 1e3, 2) if (args.batch == 1 and not args.cfg_parallel) else (cfgp or {}).get("projected_cfg_parallel_ms"),
+                       "cfg_parallel_projection": cfgp,
+                       "cfg_parallel": None if not args.cfg_parallel else {"pairs": world // 2, "exchange": "s2v_rccl_allgather (the library's own communicator)" if native_bcast
+                                                                           else f"torch.distributed.all_gather in the pair's sub-group ({dist.get_backend()})",
+                                                                           "bytes_per_rank_per_step": int(latents.numel() * latents.element_size())}, "weight_format": cfg.weight_format, "fp8_qk_active": eng.fp8_qk_active if fp8 else None, "attn_p_format": cfg.attn_p_format if cfg.attn_p_format != "auto" else f"auto -> {eng.attn_p_format}",
+                       "attn_slow_path_fraction": eng.attn_slow_fraction, "parallelism": f"cfg-parallel pairs x{world // 2}" if args.cfg_parallel else f"replicas x{world}",
                        "rccl_ranks": world, "backend": (dist.get_backend() if dist.is_initialized() else None),
                        "launcher": "self-spawned" if os.environ.get("S2V_BENCH_SPAWNED") == "1" else ("torchrun env" if env_world is not None else "single process"),
                        "ranks": ranks_info,
                        "one_device_functional_check": True if (one_dev and world > 1) else None,
                        "hipgraph": bool(args.graph), "graph_ms_per_step": None if graph_ms is None else round(graph_ms, 2),
                        "eager_ms_per_step": None if eager_ms is None else round(eager_ms, 2),
-                       "per_gpu_steps_per_s": round(total_steps / elapsed / n_devices, 4),
+                       "per_gpu_steps_per_s": round(total_steps / elapsed / n_devices / (1 if args.batch == 2 else 2), 4),
                        "lora_merged": f"rank-128 synthetic adapter on {n_lora} weights (alpha / r = 0.5)" if n_lora else None, "weight_load_s": round(t_load, 2), "weight_broadcast_s": None if bcast_s is None else round(bcast_s, 3),
                        "weight_broadcast_via": None if bcast_s is None else ("s2v_bcast_weights (the library's own RCCL communicator)" if native_bcast else f"torch.distributed.broadcast ({dist.get_backend()}), 256-MiB chunks"),
                        "weight_broadcast_note": bcast_note,
@@ -793,8 +920,8 @@ def main(argv=None):
             "roofline": roofline,
             "wall_clock_per_video": video,
         }
-        if not args.no_cpu_baseline and world == 1 and not fp8:
-            out["cpu_baseline"] = cpu_baseline(s2v, cfg, F, H, W, T, dev)
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(s2v, cfg, F, H, W, T, dev, dt)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

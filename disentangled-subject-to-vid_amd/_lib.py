@@ -55,6 +55,10 @@ _SIGS = {
     "s2v_sched_step": [_P, ctypes.POINTER(SchedCoefC), _P, _I32, _P, _P, _P, _P, _I64, _I32, _P],
     "s2v_denoise_step": [_P, _P, _F, ctypes.POINTER(SchedCoefC), _P, _P, _I32, _P],
     "s2v_last_noise_pred": [_P, ctypes.POINTER(_P)],
+    "s2v_denoise_split_begin": [_P, _P, _F, ctypes.POINTER(SchedCoefC), _I32, _I32, _P],
+    "s2v_cfg_pair": [_P, ctypes.POINTER(_P), ctypes.POINTER(_I64)],
+    "s2v_denoise_split_end": [_P, _P, _P, _P, _P],
+    "s2v_denoise_step_cfg_parallel": [_P, _P, _I32, _P, _F, ctypes.POINTER(SchedCoefC), _P, _P, _I32, _P],
     "s2v_profile_enable": [_P, _I32],
     "s2v_profile_read": [_P, ctypes.POINTER(_F), ctypes.POINTER(_I32), _I32],
     "s2v_profile_read_clocks": [_P, ctypes.POINTER(_F), _I32],
@@ -73,6 +77,7 @@ _SIGS.update({
     "s2v_rccl_unique_id": [_P],
     "s2v_rccl_comm_create": [_P, _I32, _I32, ctypes.POINTER(_P)],
     "s2v_rccl_bcast": [_P, _P, _I64, _I32, _P],
+    "s2v_rccl_allgather": [_P, _P, _P, _I64, _P],
     "s2v_bcast_weights": [_P, _P, _I32, _P],
 })
 # VAE entry points are registered by vae.py through register_sigs()

@@ -39,7 +39,8 @@ struct LayerW {
 
 struct GraphKey {
     void* latents; float* x0; const void* noise;
-    bool operator==(const GraphKey& o) const { return latents == o.latents && x0 == o.x0 && noise == o.noise; }
+    int slot;   // -1: the whole step (s2v_denoise_step); 0 / 1: the forward-only graph of s2v_denoise_split_begin writing that half of the CFG pair
+    bool operator==(const GraphKey& o) const { return latents == o.latents && x0 == o.x0 && noise == o.noise && slot == o.slot; }
 };
 
 struct s2v_ctx {
@@ -96,7 +97,7 @@ struct s2v_ctx {
     // graph
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
-    GraphKey gkey{nullptr, nullptr, nullptr};
+    GraphKey gkey{nullptr, nullptr, nullptr, -1};
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py's live roofline figure)
     // + shader-clock stamps (s_memtime / s_memrealtime pairs written by a one-lane kernel right before and right after every profiled launch)
     long long* clk_buf = nullptr;                    // device: CLK_SLOTS x [memtime0, realtime0, memtime1, realtime1]
@@ -489,7 +490,8 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     const int64_t opat = carve(BVp * Cin4 * E), otail = carve(BVp * D * E), oproj = carve(BVp * Cout4 * E);
     const int64_t omod = carve((int64_t)B * c->mod_rows * E);
     const int64_t ote = carve(((int64_t)B * D + (int64_t)B * c->temb) * E), oemb = carve((int64_t)B * c->temb * E);
-    const int64_t onp = carve((int64_t)B * F * c->cfg.out_channels * H * W * E);
+    // room for the CFG pair even when the geometry holds ONE sample of it (CFG-parallel, s2v_denoise_split_*: the peer's half arrives here)
+    const int64_t onp = carve((int64_t)std::max(B, 2) * F * c->cfg.out_channels * H * W * E);
     const int64_t ocos = carve((int64_t)(c->R + c->V) * 64 * 4), osin = carve((int64_t)(c->R + c->V) * 64 * 4);
     const int64_t opk = carve((int64_t)(c->R + c->V) * 64 * 4);
     const int64_t opos = carve((int64_t)c->V * D * E);
@@ -981,7 +983,7 @@ extern "C" int s2v_denoise_step(s2v_ctx* c, void* latents, float timestep, const
     S2V_CHECK_HIP(hipMemcpyAsync(c->t_dev, sg.t, sizeof(float) * 4, hipMemcpyHostToDevice, st));
     S2V_CHECK_HIP(hipMemcpyAsync(c->coef_dev, &sg.c, sizeof(SchedCoef), hipMemcpyHostToDevice, st));
     if (!use_graph) return step_launches(c, latents, x0_hist, noise, st);
-    GraphKey key{latents, x0_hist, noise};
+    GraphKey key{latents, x0_hist, noise, -1};
     if (!c->gexec || !(c->gkey == key)) {
         if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
         hipGraph_t graph = nullptr;
@@ -997,6 +999,75 @@ extern "C" int s2v_denoise_step(s2v_ctx* c, void* latents, float timestep, const
     }
     S2V_CHECK_HIP(hipGraphLaunch(c->gexec, st));
     return 0;
+}
+
+// ---- CFG-parallel (round 6): ONE video on TWO GPUs ---------------------------------------------------------------------------------
+// The CFG pair of custom_cogvideox_pipe.py:255-279 is two independent forwards that meet only in `noise_pred_uncond + g * (noise_pred_text -
+// noise_pred_uncond)` (:266-279).  Each rank of a pair holds a B = 1 geometry with ITS half of the prompt embeddings (slot 0 = negative /
+// unconditional, slot 1 = positive: the order of :196) and the un-duplicated reference tokens (cogvideox_transformer_3d.py:503-504 duplicates them
+// only to fill the pair).  begin: the rank's forward into half `slot` of the context-owned pair buffer (a forward-only hipGraph);  the caller
+// exchanges the halves (s2v_rccl_allgather in place, or any transport -- the collective stays OUTSIDE the captured graph);  end: fp32 CFG +
+// scheduler step + round on the pair, run REDUNDANTLY by both ranks (:266-296): both hold bit-identical latents without a second collective.
+static int64_t pair_half_bytes(const s2v_ctx* c) { return (int64_t)c->F * c->cfg.out_channels * c->H * c->W * c->esz; }
+
+extern "C" int s2v_denoise_split_begin(s2v_ctx* c, const void* latents, float timestep, const s2v_sched_coef* coef_host, int32_t slot,
+                                       int32_t use_graph, s2v_stream stream) {
+    S2V_REQUIRE(c && latents && coef_host, "s2v_denoise_split_begin: null argument");
+    S2V_REQUIRE(c->ws && c->B == 1, "s2v_denoise_split_begin: a geometry with B = 1 (one sample of the CFG pair per rank) is required");
+    S2V_REQUIRE(slot == 0 || slot == 1, "s2v_denoise_split_begin: slot must be 0 (unconditional) or 1 (conditional)");
+    S2V_REQUIRE(c->cfg.in_channels == c->cfg.out_channels, "s2v_denoise_split_begin: in/out channels must match");
+    hipStream_t st = (hipStream_t)stream;
+    s2v_ctx::Stage& sg = c->ring[c->ring_pos];
+    c->ring_pos = (c->ring_pos + 1) % RING;
+    for (int i = 0; i < 4; ++i) sg.t[i] = timestep;
+    fill_coef(sg.c, *coef_host);
+    S2V_CHECK_HIP(hipMemcpyAsync(c->t_dev, sg.t, sizeof(float) * 4, hipMemcpyHostToDevice, st));
+    S2V_CHECK_HIP(hipMemcpyAsync(c->coef_dev, &sg.c, sizeof(SchedCoef), hipMemcpyHostToDevice, st));
+    char* out = c->noise_pred + (int64_t)slot * pair_half_bytes(c);
+    if (!use_graph) return forward_impl(c, latents, 0, c->t_dev, out, st);
+    GraphKey key{(void*)latents, nullptr, nullptr, slot};
+    if (!c->gexec || !(c->gkey == key)) {
+        if (c->gexec) { hipGraphExecDestroy(c->gexec); c->gexec = nullptr; }
+        hipGraph_t graph = nullptr;
+        S2V_CHECK_HIP(hipStreamBeginCapture(c->cap_stream, hipStreamCaptureModeThreadLocal));
+        int r = forward_impl(c, latents, 0, c->t_dev, out, c->cap_stream);
+        hipError_t e = hipStreamEndCapture(c->cap_stream, &graph);
+        if (r != 0) { if (graph) hipGraphDestroy(graph); return r; }
+        S2V_CHECK_HIP(e);
+        e = hipGraphInstantiate(&c->gexec, graph, nullptr, nullptr, 0);
+        hipGraphDestroy(graph);
+        S2V_CHECK_HIP(e);
+        c->gkey = key;
+    }
+    S2V_CHECK_HIP(hipGraphLaunch(c->gexec, st));
+    return 0;
+}
+
+extern "C" int s2v_cfg_pair(s2v_ctx* c, void** dev_ptr, int64_t* bytes_per_half) {
+    S2V_REQUIRE(c && c->ws && dev_ptr && bytes_per_half, "s2v_cfg_pair: no workspace");
+    *dev_ptr = c->noise_pred;
+    *bytes_per_half = pair_half_bytes(c);
+    return 0;
+}
+
+extern "C" int s2v_denoise_split_end(s2v_ctx* c, void* latents, float* x0_hist, const void* noise, s2v_stream stream) {
+    S2V_REQUIRE(c && latents, "s2v_denoise_split_end: null argument");
+    S2V_REQUIRE(c->ws && c->B == 1, "s2v_denoise_split_end: a geometry with B = 1 is required (s2v_denoise_split_begin ran before)");
+    SchedArgs a{};
+    a.noise_pred = c->noise_pred; a.latents_in = latents; a.latents_out = latents; a.x0_hist = x0_hist; a.noise = noise;
+    a.n = (int64_t)c->F * c->cfg.out_channels * c->H * c->W; a.cfg = 1; a.coef = c->coef_dev;  // the coefficients s2v_denoise_split_begin uploaded
+    return launch_sched_step(a, c->dtype, (hipStream_t)stream);
+}
+
+extern "C" int s2v_denoise_step_cfg_parallel(s2v_ctx* c, s2v_rccl_comm* comm, int32_t slot, void* latents, float timestep,
+                                             const s2v_sched_coef* coef_host, float* x0_hist, const void* noise, int32_t use_graph,
+                                             s2v_stream stream) {
+    S2V_REQUIRE(c && comm && latents && coef_host, "s2v_denoise_step_cfg_parallel: null argument");
+    S2V_REQUIRE(coef_host->kind == 0 || (noise && x0_hist), "s2v_denoise_step_cfg_parallel: DPM needs noise and x0_hist");
+    S2V_TRY(s2v_denoise_split_begin(c, latents, timestep, coef_host, slot, use_graph, stream));
+    const int64_t half = pair_half_bytes(c);
+    S2V_TRY(s2v_rccl_allgather(comm, c->noise_pred + (int64_t)slot * half, c->noise_pred, half, stream));  // in place: rank r owns half r
+    return s2v_denoise_split_end(c, latents, x0_hist, noise, stream);
 }
 
 // Per-kernel-class timing (HIP events recorded on the launch stream around every launch of the class).

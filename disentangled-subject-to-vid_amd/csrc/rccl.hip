@@ -25,6 +25,7 @@ typedef int (*GetUniqueIdFn)(UniqueId*);
 typedef int (*CommInitRankFn)(Comm*, int, UniqueId, int);
 typedef int (*CommDestroyFn)(Comm);
 typedef int (*BroadcastFn)(const void*, void*, size_t, int, int, Comm, hipStream_t);
+typedef int (*AllGatherFn)(const void*, void*, size_t, int, Comm, hipStream_t);
 typedef const char* (*GetErrorStringFn)(int);
 typedef int (*GroupFn)(void);
 
@@ -34,6 +35,7 @@ struct Rccl {
     CommInitRankFn comm_init_rank = nullptr;
     CommDestroyFn comm_destroy = nullptr;
     BroadcastFn broadcast = nullptr;
+    AllGatherFn all_gather = nullptr;
     GetErrorStringFn error_string = nullptr;
     GroupFn group_start = nullptr, group_end = nullptr;
     std::string why;
@@ -53,7 +55,7 @@ void bind_rccl() {
     if (!g_rccl.so) return;
     struct { const char* name; void** fn; } syms[] = {
         {"ncclGetUniqueId", (void**)&g_rccl.get_unique_id}, {"ncclCommInitRank", (void**)&g_rccl.comm_init_rank},
-        {"ncclCommDestroy", (void**)&g_rccl.comm_destroy}, {"ncclBroadcast", (void**)&g_rccl.broadcast},
+        {"ncclCommDestroy", (void**)&g_rccl.comm_destroy}, {"ncclBroadcast", (void**)&g_rccl.broadcast}, {"ncclAllGather", (void**)&g_rccl.all_gather},
         {"ncclGetErrorString", (void**)&g_rccl.error_string}, {"ncclGroupStart", (void**)&g_rccl.group_start},
         {"ncclGroupEnd", (void**)&g_rccl.group_end}};
     for (auto& s : syms) {
@@ -132,6 +134,17 @@ extern "C" int s2v_rccl_bcast(s2v_rccl_comm* c, void* dev_ptr, int64_t bytes, in
     const int rc_end = g_rccl.group_end();
     if (rc) return nccl_fail("ncclBroadcast", rc);
     if (rc_end) return nccl_fail("ncclGroupEnd", rc_end);
+    return 0;
+}
+
+// The per-step exchange of CFG-parallel (api.hip s2v_denoise_step_cfg_parallel): every rank contributes `bytes_per_rank`, `recv` holds
+// world x bytes_per_rank in rank order on every rank; send == recv + rank * bytes_per_rank is the in-place form.  2.2 MB per rank at
+// 49 x 480 x 720: latency-bound on one xGMI hop, never inside a captured graph.
+extern "C" int s2v_rccl_allgather(s2v_rccl_comm* c, const void* send, void* recv, int64_t bytes_per_rank, s2v_stream stream) {
+    S2V_REQUIRE(c && c->comm && send && recv && bytes_per_rank >= 0, "s2v_rccl_allgather: bad argument");
+    if (bytes_per_rank == 0) return 0;
+    const int rc = g_rccl.all_gather(send, recv, (size_t)bytes_per_rank, /*ncclUint8*/ 1, c->comm, (hipStream_t)stream);
+    if (rc) return nccl_fail("ncclAllGather", rc);
     return 0;
 }
 

@@ -1,7 +1,8 @@
 """Data-parallel replicas of the denoise path over the GPUs of one node (the path does not
 shard inside a video, every prompt is an independent unit).  One process per GPU; the only collective is the one-off
 broadcast of the packed weight arena rank0 -> all (RCCL over xGMI when the backend is "nccl"), plus an optional
-gather of results.  No per-step communication.  The host logic is backend-agnostic and covered with gloo on CPU
+gather of results.  No per-step communication -- unless the caller asks for CFG-parallel (CfgPair, round 6): the two
+samples of a video's CFG pair on two GPUs, one 2.2 MB all-gather per step, for single-video latency.  The host logic is backend-agnostic and covered with gloo on CPU
 (tests/test_dist_gloo.py)."""
 import os
 
@@ -125,13 +126,14 @@ class RcclComm:
     path -- what a C / C++ host of libs2v_hip.so would do.  torch.distributed (any backend, gloo included) only carries the 128-byte
     unique id from rank 0 to the others.  One process per GPU; the communicator binds to the CURRENT device."""
 
-    def __init__(self, rank=None, world=None, device=None):
+    def __init__(self, rank=None, world=None, device=None, group=None):
+        """group: a torch.distributed sub-group (the two ranks of a CFG pair): rank / world are then the group's, and the id travels inside it"""
         import ctypes
 
         from . import _lib
 
-        self.rank = dist.get_rank() if rank is None else rank
-        self.world = dist.get_world_size() if world is None else world
+        self.rank = dist.get_rank(group) if rank is None else rank
+        self.world = dist.get_world_size(group) if world is None else world
         if device is not None:
             torch.cuda.set_device(device)
         buf = ctypes.create_string_buffer(128)
@@ -139,7 +141,7 @@ class RcclComm:
             _lib.check(_lib.lib().s2v_rccl_unique_id(buf))
         box = [buf.raw if self.rank == 0 else None]
         if self.world > 1:
-            dist.broadcast_object_list(box, src=0)
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         self._h = ctypes.c_void_p()
         _lib.check(_lib.lib().s2v_rccl_comm_create(ctypes.create_string_buffer(box[0], 128), self.rank, self.world, ctypes.byref(self._h)))
 
@@ -150,6 +152,14 @@ class RcclComm:
         flat = arena.view(-1)
         _lib.check(_lib.lib().s2v_rccl_bcast(self._h, _lib.ptr(flat), flat.numel() * flat.element_size(), src, _lib.stream_ptr()))
         return flat.numel() * flat.element_size()
+
+    def allgather(self, recv, rank_bytes):
+        """in place on torch's current stream: rank r contributed bytes [r * rank_bytes, (r + 1) * rank_bytes) of `recv`"""
+        from . import _lib
+
+        flat = recv.view(-1).view(torch.uint8)
+        send = flat[self.rank * rank_bytes:(self.rank + 1) * rank_bytes]
+        _lib.check(_lib.lib().s2v_rccl_allgather(self._h, _lib.ptr(send), _lib.ptr(flat), int(rank_bytes), _lib.stream_ptr()))
 
     def broadcast_weights(self, engine, src=0):
         """s2v_bcast_weights: the transformer engine's arena, receivers marked loaded by the library itself"""
@@ -169,6 +179,60 @@ class RcclComm:
             self.close()
         except Exception:
             pass
+
+
+def cfg_pair_layout(rank, world):
+    """CFG-parallel over `world` ranks (even): ranks 2p and 2p + 1 run video p together -> (pair index p, slot, peer rank, number of pairs).
+    slot 0 = the unconditional half (negative prompt), slot 1 = the conditional one: the order custom_cogvideox_pipe.py:196 concatenates and
+    :266 chunks.  Composes with replicas: prompt q runs on pair q mod (world // 2)."""
+    if world < 2 or world % 2:
+        raise ValueError(f"CFG-parallel needs an even number of ranks >= 2, got {world}")
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside 0..{world - 1}")
+    return rank // 2, rank % 2, rank ^ 1, world // 2
+
+
+class CfgPair:
+    """The two ranks that run ONE video together: each holds a B = 1 engine with its half of the prompt embeddings; per step they
+    exchange their halves of noise_pred (2.2 MB bf16 at 49 x 480 x 720) and both run CFG + the scheduler step, so their latents stay bit-identical
+    with ONE collective per step.  The exchange is s2v_rccl_allgather through the library's own communicator (native=True; RCCL, one process per
+    GPU) or torch.distributed.all_gather in the pair's sub-group (any backend: what the gloo tests run); neither is ever inside the captured graph."""
+
+    def __init__(self, native=False):
+        if not dist.is_initialized():
+            raise RuntimeError("CfgPair needs an initialised process group")
+        rank, world = dist.get_rank(), dist.get_world_size()
+        self.pair, self.slot, self.peer, self.pairs = cfg_pair_layout(rank, world)
+        # new_group is collective over ALL ranks, for every group, in the same order
+        self.group = None
+        for p in range(self.pairs):
+            g = dist.new_group([2 * p, 2 * p + 1])
+            if p == self.pair:
+                self.group = g
+        self.comm = RcclComm(group=self.group) if native else None
+
+    def exchange(self, engine):
+        """after denoise_split_begin: fill the peer's half of the engine's pair buffer"""
+        pair = engine.cfg_pair()
+        if self.comm is not None:
+            self.comm.allgather(pair, pair[0].numel() * pair.element_size())
+            return
+        mine = pair[self.slot].clone()
+        dist.all_gather([pair[0], pair[1]], mine, group=self.group)
+
+    def step(self, engine, latents, timestep, coef, x0_hist=None, noise=None, use_graph=False):
+        """one denoise step of the pair's video; latents (identical on both ranks) updated in place on both"""
+        if self.comm is not None:
+            engine.denoise_step_cfg_parallel(self.comm, self.slot, latents, timestep, coef, x0_hist, noise, use_graph)
+            return
+        engine.denoise_split_begin(latents, timestep, coef, self.slot, use_graph)
+        self.exchange(engine)
+        engine.denoise_split_end(latents, x0_hist, noise)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
 
 
 def broadcast_components(components, src=0, comm=None):

@@ -281,6 +281,31 @@ class S2VEngine:
                 self.set_attn_p_format("bf16")
             self._attn_auto_pending = False
 
+    # ---- CFG-parallel: this engine holds ONE sample of the CFG pair (geometry B = 1); include/s2v_hip.h, dist.CfgPair ---------------------------
+    def cfg_pair(self):
+        """the context-owned pair buffer [2, F, C, H, W] (model dtype): half `slot` is written by denoise_split_begin, the other by the exchange"""
+        B, T, F, H, W = self.geometry
+        p, n = ctypes.c_void_p(), ctypes.c_int64()
+        _lib.check(_lib.lib().s2v_cfg_pair(self._h, ctypes.byref(p), ctypes.byref(n)))
+        raw = torch.as_tensor(_ArenaView(p.value, 2 * n.value), device=self.device)
+        return raw.view(self.dtype).view(2, F, self.cfg.out_channels, H, W)
+
+    def denoise_split_begin(self, latents, timestep, coef, slot, use_graph=False):
+        if latents.dtype != self.dtype or not latents.is_contiguous():
+            raise _lib.S2VError("latents must be a contiguous model-dtype tensor")
+        _lib.check(_lib.lib().s2v_denoise_split_begin(self._h, _lib.ptr(latents), float(timestep), ctypes.byref(coef), int(slot), int(use_graph),
+                                                      _lib.stream_ptr()))
+
+    def denoise_split_end(self, latents, x0_hist=None, noise=None):
+        _lib.check(_lib.lib().s2v_denoise_split_end(self._h, _lib.ptr(latents), _lib.ptr(x0_hist), _lib.ptr(noise), _lib.stream_ptr()))
+
+    def denoise_step_cfg_parallel(self, comm, slot, latents, timestep, coef, x0_hist=None, noise=None, use_graph=False):
+        """begin + s2v_rccl_allgather + end in ONE library call over an RcclComm of the two ranks of the pair"""
+        if latents.dtype != self.dtype or not latents.is_contiguous():
+            raise _lib.S2VError("latents must be a contiguous model-dtype tensor (it is updated in place)")
+        _lib.check(_lib.lib().s2v_denoise_step_cfg_parallel(self._h, comm._h, int(slot), _lib.ptr(latents), float(timestep), ctypes.byref(coef),
+                                                            _lib.ptr(x0_hist), _lib.ptr(noise), int(use_graph), _lib.stream_ptr()))
+
     def last_noise_pred(self):
         B, T, F, H, W = self.geometry
         p = ctypes.c_void_p()

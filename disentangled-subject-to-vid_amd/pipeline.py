@@ -58,7 +58,10 @@ class S2VPipeline:
     def __call__(self, prompt_embeds=None, negative_prompt_embeds=None, ref_img_states=None, height=480, width=720,
                  num_frames=49, num_inference_steps=50, guidance_scale=6.0, use_dynamic_cfg=False, generator=None,
                  latents=None, output_type="latent", return_dict=True, fused=True, use_graph=False,
-                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",)):
+                 callback_on_step_end=None, callback_on_step_end_tensor_inputs=("latents",), cfg_parallel=None):
+        """cfg_parallel: a dist.CfgPair -- this process runs ONE sample of the CFG pair (slot 0: negative prompt, slot 1: prompt) on its GPU and its
+        peer the other; every rank of the pair passes the SAME arguments (embeddings, reference latent, latents or an equally seeded generator) and
+        returns the same latents / video bit for bit.  fused mode only."""
         if num_frames > 49:
             raise ValueError("The number of frames must be less than or equal to 49 due to static positional embeddings.")
         self.check_inputs(height, width, prompt_embeds, negative_prompt_embeds)
@@ -92,10 +95,14 @@ class S2VPipeline:
             cos, sin = torch.from_numpy(cos).to(dev), torch.from_numpy(sin).to(dev)
             ref_rope, rope = (cos[:n], sin[:n]), (cos[n:], sin[n:])
 
+        if cfg_parallel is not None and not fused:
+            raise ValueError("cfg_parallel runs the fused step (one sample of the CFG pair per rank); fused=False is the reference's seam sequence")
         if fused:
-            eng.set_geometry(2, text.shape[1], F, H, W)
+            # CFG-parallel: B = 1 with this rank's half of [negative | positive] (custom_cogvideox_pipe.py:196) and the un-duplicated reference tokens
+            my_text = text if cfg_parallel is None else text[cfg_parallel.slot:cfg_parallel.slot + 1]
+            eng.set_geometry(2 if cfg_parallel is None else 1, text.shape[1], F, H, W)
             eng.prepare_tables(height, width)
-            eng.set_conditioning(text, ref)
+            eng.set_conditioning(my_text, ref)
             x0_hist = torch.zeros(latents.shape, dtype=torch.float32, device=dev) if is_dpm else None
             noise = torch.empty_like(latents) if is_dpm else None
         old = None
@@ -114,7 +121,10 @@ class S2VPipeline:
                         self._draw(noise, generator)  # the reference discards its first draw on multistep steps
                 else:
                     coef = sch.coef(t, dt, g)
-                eng.denoise_step(latents, float(t), coef, x0_hist, noise, use_graph)
+                if cfg_parallel is None:
+                    eng.denoise_step(latents, float(t), coef, x0_hist, noise, use_graph)
+                else:
+                    cfg_parallel.step(eng, latents, float(t), coef, x0_hist, noise, use_graph)
             else:
                 x = torch.cat([latents] * 2)
                 x = sch.scale_model_input(x, t)
@@ -145,8 +155,8 @@ class S2VPipeline:
                 new_text = outs.get("prompt_embeds", text)
                 if new_text is not text:
                     text = new_text.to(dev, dt)
-                    if fused:
-                        eng.set_conditioning(text, ref)  # the hoisted text projection follows the new embeddings
+                    if fused:  # the hoisted text projection follows the new embeddings
+                        eng.set_conditioning(text if cfg_parallel is None else text[cfg_parallel.slot:cfg_parallel.slot + 1], ref)
                 negative_prompt_embeds = outs.get("negative_prompt_embeds", negative_prompt_embeds)
         # attn_p_format "auto" settled on the census of the FIRST step; the whole run's census is kept for the caller and, should later (less
         # noisy, sharper) steps have taken the fp16 kernel's slow path too often, the next video of this engine runs on bf16 probabilities

@@ -203,8 +203,32 @@ S2V_API int s2v_rccl_comm_create(const void* id128, int32_t rank, int32_t world,
 S2V_API void s2v_rccl_comm_destroy(s2v_rccl_comm* comm);
 /* any device range (s2v_vae_weight_arena, s2v_t5_weight_arena ...), in place, asynchronous on `stream`, 256-MiB collectives */
 S2V_API int s2v_rccl_bcast(s2v_rccl_comm* comm, void* dev_ptr, int64_t bytes, int32_t root, s2v_stream stream);
+/* ncclAllGather of bytes: every rank contributes bytes_per_rank from `send`; `recv` (world x bytes_per_rank, rank order) is the same on every
+ * rank afterwards; send == recv + rank * bytes_per_rank is the in-place form.  The per-step exchange of CFG-parallel below. */
+S2V_API int s2v_rccl_allgather(s2v_rccl_comm* comm, const void* send, void* recv, int64_t bytes_per_rank, s2v_stream stream);
 /* the transformer's finalized arena (merged LoRA, fused QKV, fp8 copies + scales) root -> all; receivers are marked loaded */
 S2V_API int s2v_bcast_weights(s2v_ctx* ctx, s2v_rccl_comm* comm, int32_t root, s2v_stream stream);
+
+/* ---- CFG-parallel: ONE video on TWO GPUs (SURVEY.md section 8e "noted for later"; round 6) -----------------------------------------
+ * The CFG pair the reference batches (custom_cogvideox_pipe.py:255-265: latents duplicated, [negative | positive] embeddings, reference tokens
+ * duplicated x2 at cogvideox_transformer_3d.py:503-504) is two independent forwards that meet only in the guidance formula (:266-279).  Each rank
+ * of a pair sets a B = 1 geometry, s2v_set_conditioning with ITS half of the embeddings ([1,T,text_embed_dim]) and the one reference latent, and
+ * runs per step:
+ *   s2v_denoise_split_begin  the rank's forward into half `slot` (0 = unconditional / negative prompt, 1 = conditional) of the context's pair
+ *                            buffer; use_graph != 0 replays a captured forward-only hipGraph;
+ *   the exchange             s2v_rccl_allgather on s2v_cfg_pair's buffer in place (or any other transport), OUTSIDE the graph;
+ *   s2v_denoise_split_end    fp32 CFG + scheduler step + round to the model dtype (:266-296) on the pair, by BOTH ranks redundantly: their latents
+ *                            stay bit-identical without a second collective (DPM: the caller hands both ranks the same `noise`).
+ * s2v_denoise_step_cfg_parallel is the three in one call over the library's own communicator (a 2-rank s2v_rccl_comm).  Per sample the arithmetic
+ * is the B = 2 engine's: tests/test_gpu_cfg_parallel.py holds the pair to s2v_denoise_step bit for bit. */
+S2V_API int s2v_denoise_split_begin(s2v_ctx* ctx, const void* latents, float timestep, const s2v_sched_coef* coef_host, int32_t slot,
+                                    int32_t use_graph, s2v_stream stream);
+/* the pair buffer [2][F,C,H,W] (model dtype, context-owned) and the bytes of one half */
+S2V_API int s2v_cfg_pair(s2v_ctx* ctx, void** dev_ptr, int64_t* bytes_per_half);
+S2V_API int s2v_denoise_split_end(s2v_ctx* ctx, void* latents, float* x0_hist, const void* noise, s2v_stream stream);
+S2V_API int s2v_denoise_step_cfg_parallel(s2v_ctx* ctx, s2v_rccl_comm* comm, int32_t slot, void* latents, float timestep,
+                                          const s2v_sched_coef* coef_host, float* x0_hist, const void* noise, int32_t use_graph,
+                                          s2v_stream stream);
 
 /* ---- CogVideoX 3-D causal VAE decode ------------------------------------------------------------------------- */
 typedef struct s2v_vae s2v_vae;

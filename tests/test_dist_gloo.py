@@ -329,3 +329,100 @@ def _mismatch_worker(rank, world, port, q):
         dist.destroy_process_group()
     except Exception as e:  # pragma: no cover
         q.put((rank, f"exception: {e!r}"))
+
+
+# ---- CFG-parallel host logic (dist.cfg_pair_layout / dist.CfgPair) -----------------------------------------------
+class FakeCfgEngine:
+    """stand-in for a B = 1 S2VEngine on CPU tensors: "forward" = a deterministic function of (latents, this rank's text half); the CFG combine and
+    the DDIM step are the oracle's (oracle.sched_ref), i.e. what custom_cogvideox_pipe.py:266-296 computes on the pair"""
+
+    def __init__(self, text_half):
+        self.text = text_half
+        self.pair = torch.zeros(2, 2, 4, 6, 6)
+        self.coef = None
+
+    def cfg_pair(self):
+        return self.pair
+
+    def denoise_split_begin(self, latents, timestep, coef, slot, use_graph=False):
+        self.coef = (timestep, coef)
+        self.pair[slot] = torch.tanh(latents[0] * self.text.mean() + self.text.std() * 0.1 * timestep / 1000.0)
+
+    def denoise_split_end(self, latents, x0_hist=None, noise=None):
+        from oracle import sched_ref
+
+        t, (ac, n, g) = self.coef
+        v = sched_ref.cfg_combine(self.pair.clone(), g)
+        out, _ = sched_ref.ddim_step(ac, n, v, int(t), latents)
+        latents.copy_(out.float())
+
+
+def _cfg_run(pairs_text, slot_engines_step, steps=3):
+    from oracle import sched_ref
+
+    ac = sched_ref.alphas_cumprod(1.0)
+    lat = torch.randn(1, 2, 4, 6, 6, generator=torch.Generator().manual_seed(7))
+    for t in sched_ref.trailing_timesteps(steps):
+        slot_engines_step(lat, float(t), (ac, steps, 6.0))
+    return lat
+
+
+def _cfg_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    d = importlib.import_module("disentangled-subject-to-vid_amd.dist")
+    d.init_from_env("gloo")
+    cp = d.CfgPair(native=False)
+    assert (cp.pair, cp.slot, cp.peer, cp.pairs) == (rank // 2, rank % 2, rank ^ 1, world // 2)
+    # video p of pair p: embeddings [negative | positive] seeded by p; this rank holds half `slot`
+    text = torch.randn(2, 5, 8, generator=torch.Generator().manual_seed(100 + cp.pair))
+    eng = FakeCfgEngine(text[cp.slot:cp.slot + 1])
+    lat = _cfg_run(None, lambda x, t, coef: cp.step(eng, x, t, coef))
+    q.put((rank, cp.pair, lat.numpy(), eng.pair.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_cfg_parallel_pairs_exchange_halves_and_agree_bitwise(world):
+    """world 2: one video on two ranks; world 4: two videos, two sub-groups (composes with replicas).  Both ranks of a pair end with identical
+    latents, equal to ONE process computing both halves itself"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cfg_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=120) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for pair in range(world // 2):
+        text = torch.randn(2, 5, 8, generator=torch.Generator().manual_seed(100 + pair))
+        e0, e1 = FakeCfgEngine(text[0:1]), FakeCfgEngine(text[1:2])
+
+        def both(x, t, coef):
+            e0.denoise_split_begin(x, t, coef, 0)
+            e1.denoise_split_begin(x, t, coef, 1)
+            e0.pair[1] = e1.pair[1]
+            e0.denoise_split_end(x)
+
+        exp = _cfg_run(None, both).numpy()
+        a, b = got[2 * pair], got[2 * pair + 1]
+        assert a[1] == b[1] == pair
+        assert (a[2] == b[2]).all() and (a[3] == b[3]).all(), "the two ranks of a pair must hold identical latents and pair buffers"
+        assert (a[2] == exp).all(), "pair result differs from one process computing both halves"
+    if world == 4:
+        assert not (got[0][2] == got[2][2]).all(), "the two videos must differ"
+
+
+def test_cfg_pair_layout_rejects_odd_worlds():
+    d = importlib.import_module("disentangled-subject-to-vid_amd.dist")
+    assert d.cfg_pair_layout(5, 8) == (2, 1, 4, 4)
+    for bad in (1, 3, 7):
+        with pytest.raises(ValueError):
+            d.cfg_pair_layout(0, bad)
+    with pytest.raises(ValueError):
+        d.cfg_pair_layout(2, 2)

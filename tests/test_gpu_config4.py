@@ -21,6 +21,10 @@ from oracle import transformer_ref as tr
 from oracle import vae_ref
 
 pytestmark = pytest.mark.gpu
+# 2 x measured (round 6, gpurun r06a): one bf16 block at N = 50 626 against the CPU oracle rel-L2 2.43e-3, max-abs 6.0e-3 max|ref| (until round 5: 2e-2 / 6e-2);
+# the fp8 engine against the bf16 engine at the configs[4] geometry 6.3e-3 (until round 5: 5e-2)
+C4_BLOCK_BARS = (5e-3, 1.2e-2)
+C4_FP8_BAR = 1.3e-2
 DEV = "cuda:0"
 F4, H4, W4, T4 = 13, 90, 160, 226  # 49 frames 720 x 1280
 N4 = T4 + (H4 // 2) * (W4 // 2) * (1 + F4)
@@ -62,7 +66,8 @@ def test_config4_one_block_50626_tokens_vs_oracle(s2v):
         y = y.float().cpu()
         assert torch.isfinite(y).all(), name
         r, err = rel_l2(y, e), (y - e).abs().max().item()
-        assert r <= 2e-2 and err <= 6e-2 * e.abs().max().item(), f"{name}: rel-l2 {r}, max-abs {err}"
+        print(f"MEASURED config4 block {name}: rel-l2 {r:.3e} max-abs/max|ref| {err / e.abs().max().item():.3e}")
+        assert r <= C4_BLOCK_BARS[0] and err <= C4_BLOCK_BARS[1] * e.abs().max().item(), f"{name}: rel-l2 {r}, max-abs {err}"
     print(f"configs[4] block: oracle took {t_cpu:.1f} s on the host cores")
 
 
@@ -99,7 +104,8 @@ def test_config4_fp8_engine_full_geometry(s2v, fmt):
     assert torch.isfinite(y8.float()).all()
     assert torch.equal(y8[0], y8[1]), "CFG pair with identical conditioning must be symmetric"
     rel = rel_l2(y8.float(), y16.float())
-    assert 0 < rel <= 5e-2, rel  # > 0: the fp8 path really ran
+    print(f"MEASURED config4 fp8 vs bf16 engine: rel-l2 {rel:.3e}")
+    assert 0 < rel <= C4_FP8_BAR, rel  # > 0: the fp8 path really ran
     eng = m8.engine
     y8b = eng.forward(lat, torch.tensor([500.0, 500.0]), shared_latent=True)
     torch.cuda.synchronize()

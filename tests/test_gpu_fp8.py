@@ -10,6 +10,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+FP8_ENGINE_BAR = 1.4e-2   # 2 x measured (round 6, gpurun r06a): fp8 / fp8-qk engines against the bf16 engine 6.3e-3 ... 6.9e-3 rel-L2 over the five sites (until round 5: 5e-2); parity unpinned
 DEV = "cuda:0"
 
 
@@ -87,7 +88,8 @@ def test_fp8_engine_medium_model_vs_bf16_engine(s2v):
     m8, y8 = _run_engine(s2v, cfg8, sd, lat, text, ref, 500.0)
     assert torch.isfinite(y8.float()).all()
     rel = ((y8.float() - y16.float()).norm() / y16.float().norm()).item()
-    assert 0 < rel <= 5e-2, rel  # > 0: the fp8 path really ran
+    print(f"MEASURED fp8 engine vs bf16 (site A): rel-l2 {rel:.3e}")
+    assert 0 < rel <= FP8_ENGINE_BAR, rel  # > 0: the fp8 path really ran
     # a replica that receives the arena (fp8 copies and scales included) reproduces the result bit for bit
     m2 = s2v.HipCogVideoXTransformer3DModel(cfg8, torch.bfloat16, DEV)
     m2.engine.weight_arena().copy_(m8.engine.weight_arena())
@@ -128,7 +130,8 @@ def test_fp8_engine_short_sequences_vs_bf16_engine(s2v, lat_hw, frames):
     _, y8 = _run_engine(s2v, cfg8, sd, lat, text, ref, 500.0)
     assert torch.isfinite(y8.float()).all()
     rel = ((y8.float() - y16.float()).norm() / y16.float().norm()).item()
-    assert 0 < rel <= 5e-2, (ntok, rel)
+    print(f"MEASURED fp8 engine vs bf16 (site B, ntok {ntok}): rel-l2 {rel:.3e}")
+    assert 0 < rel <= FP8_ENGINE_BAR, (ntok, rel)
     u, c = y8.chunk(2)
     assert not torch.equal(u, c)  # the CFG pair saw different text
 
@@ -154,7 +157,8 @@ def test_fp8_engine_full_tokens_properties_and_closeness(s2v):
     assert torch.isfinite(y8.float()).all()
     assert torch.equal(y8[0], y8[1])
     rel = ((y8.float() - y16.float()).norm() / y16.float().norm()).item()
-    assert 0 < rel <= 5e-2, rel
+    print(f"MEASURED fp8 engine vs bf16 (site C): rel-l2 {rel:.3e}")
+    assert 0 < rel <= FP8_ENGINE_BAR, rel
     eng = m8.engine
     sch = s2v.CogVideoXDDIMScheduler(snr_shift_scale=1.0)
     sch.set_timesteps(50)
@@ -436,8 +440,9 @@ def test_fp8_qk_engine_vs_fp8_and_bf16_engines(s2v, lat_hw, frames):
     assert torch.isfinite(yq.float()).all()
     rel16 = ((yq.float() - y16.float()).norm() / y16.float().norm()).item()
     rel8 = ((yq.float() - y8.float()).norm() / y8.float().norm()).item()
-    assert 0 < rel16 <= 5e-2, rel16
-    assert 0 < rel8 <= 5e-2, rel8
+    print(f"MEASURED fp8-qk engine vs bf16: rel-l2 {rel16:.3e}; vs fp8 engine: {rel8:.3e}")
+    assert 0 < rel16 <= FP8_ENGINE_BAR, rel16
+    assert 0 < rel8 <= FP8_ENGINE_BAR, rel8
     eng = mq.engine
     y2 = eng.forward(lat, torch.tensor([500.0, 500.0]), shared_latent=True)
     torch.cuda.synchronize()

@@ -25,7 +25,12 @@ F_, H_, W_, T_ = 13, 60, 90, 226  # 49 frames 480 x 720
 # until round 4: 1e-3 and 2e-2 / 6e-2.  North star for fp32: 1e-3.
 F32_BAR = 2e-5
 BF16_BARS = (5e-3, 1.1e-2)
-F16_BARS = (6.5e-4, 1.4e-3)   # the bf16 bars / 8 (fp16 has three more mantissa bits); tightened to 2 x measured once measured
+F16_BARS = (6.2e-4, 1.5e-3)   # 2 x measured (round 6): 2B fp16 block rel-L2 3.07e-4, max-abs 7.1e-4 max|ref|
+
+
+ATTN_C4_BARS = (8.2e-3, 1.4e-2)  # attention alone at N = 50 626 against fp32 SDPA: 2 x measured (round 6: 4.1e-3 / 7.0e-3; until round 5: 2e-2 / 2e-2)
+F32_DEPTH_BAR = 2e-5           # four chained blocks on the fp32 matrix pipe against the CPU oracle: 2 x measured (round 6: 7.5e-6, 8.2e-6, 8.3e-6, 8.3e-6 after
+                               # blocks 1-4 -- the max-abs error does not grow with depth, rel-L2 3.1e-7 -> 6.1e-7)
 
 
 def rel_l2(a, b):
@@ -88,6 +93,43 @@ def test_one_block_full_tokens_vs_oracle(s2v, preset, dt_name, simple):
     print(f"{preset} {dt_name}: oracle block took {t_cpu:.1f} s")
 
 
+def test_four_blocks_full_tokens_f32m_vs_oracle(s2v):
+    """The link the whole-run parity figures hang on: bf16 / fp16 / fp8 whole runs are compared with the SAME loop on the fp32
+    matrix-pipe kernels (tests/test_gpu_whole_run.py), which until round 5 were pinned to the CPU oracle over ONE block at the full token count.  Here:
+    FOUR chained CogVideoXBlocks (cogvideox_transformer_3d.py:122-186,519-533) at 5B width, N = 19 126 tokens, B = 1, gemm_f32m / attn_f32m against
+    oracle.transformer_ref -- the error of the fp32 path over depth at the size the whole-run reference runs is measured per block, not inferred."""
+    cfg = s2v.cogvideox_5b()
+    cfg.num_layers = 4
+    D, heads = cfg.inner_dim, cfg.num_attention_heads
+    R = (H_ // 2) * (W_ // 2)
+    V = F_ * R
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=23, parity=True)
+    g = torch.Generator().manual_seed(24)
+    h, e0, e1 = torch.randn(1, V, D, generator=g), torch.randn(1, T_, D, generator=g), torch.randn(1, R, D, generator=g)
+    temb = torch.randn(1, cfg.time_embed_dim, generator=g)
+    ref_rope, rope = tr.pipeline_rope(H_ * 8, W_ * 8, F_)
+    m = s2v.HipCogVideoXTransformer3DModel(cfg, torch.float32, DEV)
+    m.load_state_dict(sd)
+    kw = dict(image_rotary_emb=tuple(x.to(DEV) for x in rope), ref_image_rotary_emb=tuple(x.to(DEV) for x in ref_rope))
+    gh, g0, g1 = h.to(DEV), e0.to(DEV), e1.to(DEV)
+    t0 = time.time()
+    worst = 0.0
+    for l in range(cfg.num_layers):
+        with torch.no_grad():
+            h, e0, e1 = tr.block_forward(sd, f"transformer_blocks.{l}.", heads, h, e0, e1, temb, rope, ref_rope)
+        gh, g0, g1 = m.transformer_blocks[l](hidden_states=gh, encoder_hidden_states=g0, temb=temb.to(DEV), enc_hidden_states1=g1, embed_ref_img=True,
+                                             ref_img_seq_start=T_, ref_img_seq_end=T_ + R, position_delta=0, timestep=None, layer=l, **kw)
+        torch.cuda.synchronize()
+        for name, y, e in zip(("video", "text", "ref"), (gh, g0, g1), (h, e0, e1)):
+            y = y.float().cpu()
+            assert torch.isfinite(y).all(), (l, name)
+            err = (y - e).abs().max().item()
+            worst = max(worst, err)
+            print(f"MEASURED 4-block f32m depth {l + 1} {name}: rel-l2 {rel_l2(y, e):.3e} max-abs {err:.3e} max|ref| {e.abs().max().item():.3f}")
+    print(f"four oracle blocks took {time.time() - t0:.1f} s; worst max-abs {worst:.3e}")
+    assert worst <= F32_DEPTH_BAR, worst
+
+
 def test_attention_50626_tokens_two_heads_vs_sdpa(s2v):
     """BASELINE configs[4] geometry (49 frames 720 x 1280: N = 226 + 3600 + 46800), attention only, bf16"""
     B, H, N = 1, 2, 226 + 14 * 45 * 80
@@ -108,4 +150,6 @@ def test_attention_50626_tokens_two_heads_vs_sdpa(s2v):
     got = out.float().cpu()
     assert torch.isfinite(got).all()
     r = rel_l2(got, ref)
-    assert r <= 2e-2 and (got - ref).abs().max() <= 2e-2 * max(1.0, ref.abs().max().item()), r
+    e = (got - ref).abs().max().item() / max(1.0, ref.abs().max().item())
+    print(f"MEASURED attention 50626 tokens: rel-l2 {r:.3e} max-abs/scale {e:.3e}")
+    assert r <= ATTN_C4_BARS[0] and e <= ATTN_C4_BARS[1], (r, e)
