@@ -1161,8 +1161,9 @@ extern "C" int s2v_op_linear(const void* A, const void* W, const void* bias, voi
         g.a_rows_padded = M; g.w_rows_padded = N;
         return launch_gemm_f16(g, epilogue, (hipStream_t)stream);
     }
-    if (impl == 3) {  // fp32 operands on the fp32 matrix pipe (what the fp32 engine runs; bit-identical to impl 1)
-        S2V_REQUIRE(dtype == S2V_DTYPE_F32, "s2v_op_linear: impl 3 is fp32 only");
+    if (impl == 3 || (impl >= 30 && impl <= 33)) {  // fp32 operands on the fp32 matrix pipe (what the fp32 engine runs; bit-identical to impl 1)
+        S2V_REQUIRE(dtype == S2V_DTYPE_F32, "s2v_op_linear: impl 3 / 30 .. 33 are fp32 only");
+        if (impl >= 30) g.tile = impl;  // 30 .. 33: force the 128 x 128 / 128 x 64 / 64 x 128 / 64 x 64 tile (3: the launcher's own choice)
         return launch_gemm_f32m(g, epilogue, (hipStream_t)stream);
     }
     g.valu_only = 1;

@@ -7,9 +7,14 @@
 // kernel runs the C3 step in minutes, this one in seconds.
 //
 // Tile 128 (m) x 128 (n) x 16 (k), four waves (2 x 2) of 64 x 64 = 2 x 2 MFMA blocks, two workgroups per CU.  Operands are staged
-// through registers into TRANSPOSED LDS images [k][row] (pitch 160 floats: the two k-rows a wave reads per instruction -- lanes 0-31
+// through registers into TRANSPOSED LDS images [k][row] (pitch rows + 32 floats: the two k-rows a wave reads per instruction -- lanes 0-31
 // take k, lanes 32-63 take k + 1 -- fall into the two halves of the banks), so a fragment read is one ds_read_b32 of 64 consecutive
-// floats per half.  The MFMA is issued swapped (first operand = weight rows): a lane then owns four consecutive output columns of one
+// floats per half.
+// Round 6: the tile is a template parameter (128 or 64 rows x 128 or 64 columns, still 2 x 2 waves): a GEMM whose 128 x 128
+// tiles leave the CUs unevenly loaded (configs[0]: M = 2500, N = 1920 -> 300 tiles on 256 CUs, i.e. the time of TWO tiles per CU for 1.17 tiles
+// of work) runs on smaller tiles -- the fp32 MFMA is slow enough (64 cycles for 32 x 32 x 2) that the fragment traffic of a 64 x 64 tile is no
+// bound, and the bits do not depend on the tile (every output element is the same k-ordered chain): f32m_pick_tile, tests/test_gpu_f32m.py.
+// The MFMA is issued swapped (first operand = weight rows): a lane then owns four consecutive output columns of one
 // token row, which is what epilogue4 takes.  Tile order: XCD-aware (each XCD walks a contiguous range of tiles) and grouped by 8 row
 // tiles so the 64 workgroups resident on an XCD share A / W tiles through its L2.
 #define S2V_HOST
@@ -17,10 +22,7 @@
 #include "kernels.h"
 #include "gemm_epi.h"
 
-#define FBM 128
-#define FBN 128
 #define FBK 16
-#define FPITCH 160
 
 // element offsets of A (plain or implicit-GEMM convolution; the same arithmetic as gemm.hip's a_row_base / a_k_off)
 __device__ __forceinline__ int64_t f32m_row_base(const GemmArgs& a, int m) {
@@ -40,10 +42,13 @@ __device__ __forceinline__ int64_t f32m_k_off(const GemmArgs& a, int k) {
     return (((int64_t)dt * a.Hp + dy) * a.Wp + dx) * a.cin + ci;
 }
 
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_f32m_k(const GemmArgs a, int tiles_m, int tiles_n) {
-    __shared__ float sA[2][FBK][FPITCH];
-    __shared__ float sW[2][FBK][FPITCH];
+template <int EPI, int FBM, int FBN>
+__global__ __launch_bounds__(256, (FBM * FBN <= 64 * 64 ? 4 : 2)) void gemm_f32m_k(const GemmArgs a, int tiles_m, int tiles_n) {
+    static_assert((FBM == 128 || FBM == 64) && (FBN == 128 || FBN == 64), "gemm_f32m: tile sides are 64 or 128");
+    constexpr int WM = FBM / 2, WN = FBN / 2, MJ = WM / 32, NI = WN / 32;  // wave tile and its 32 x 32 MFMA blocks
+    constexpr int CA = FBM * 4 / 256, CW = FBN * 4 / 256;                    // 4-float chunks of a 16-float K-tile row each thread stages
+    __shared__ float sA[2][FBK][FBM + 32];
+    __shared__ float sW[2][FBK][FBN + 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // tile of this workgroup: hardware deals workgroup ids round-robin over the 8 XCDs -> XCD x gets the contiguous range x of tiles
     const int total = tiles_m * tiles_n;
@@ -62,42 +67,45 @@ __global__ __launch_bounds__(256, 2) void gemm_f32m_k(const GemmArgs a, int tile
 
     const float* A = (const float*)a.A;
     const float* W = (const float*)a.W;
-    // staging: thread t copies the 4-float chunks c0 and c0 + 2 (of the 4 chunks of a 16-float K-tile) of row t & 127 of either operand
-    const int r = tid & 127, c0 = tid >> 7;
-    const int64_t baseA = f32m_row_base(a, min(m0 + r, a.M - 1));
-    const int64_t baseW = (int64_t)min(n0 + r, a.N - 1) * a.ldw;
-    f32x4 ra[2], rw[2];
+    // staging: thread t copies chunks c, c + 256 / rows, ... (of the 4 four-float chunks of a 16-float K-tile) of row t % rows of either operand:
+    // two chunks per thread for a 128-row side, one for a 64-row side
+    const int rA = tid % FBM, cA = tid / FBM, rW = tid % FBN, cW = tid / FBN;
+    const int64_t baseA = f32m_row_base(a, min(m0 + rA, a.M - 1));
+    const int64_t baseW = (int64_t)min(n0 + rW, a.N - 1) * a.ldw;
+    f32x4 ra[CA], rw[CW];
     auto gload = [&](int kt) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int k = kt * FBK + (c0 + 2 * j) * 4;
-            if (k < a.K) {
-                ra[j] = *(const f32x4*)(A + baseA + f32m_k_off(a, k));
-                rw[j] = *(const f32x4*)(W + baseW + k);
-            } else {
-                ra[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                rw[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int j = 0; j < CA; ++j) {
+            const int k = kt * FBK + (cA + (256 / FBM) * j) * 4;
+            ra[j] = k < a.K ? *(const f32x4*)(A + baseA + f32m_k_off(a, k)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+            const int k = kt * FBK + (cW + (256 / FBN) * j) * 4;
+            rw[j] = k < a.K ? *(const f32x4*)(W + baseW + k) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int kc = (c0 + 2 * j) * 4;
+        for (int j = 0; j < CA; ++j) {
+            const int kc = (cA + (256 / FBM) * j) * 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sA[buf][kc + e][r] = ra[j][e];
-                sW[buf][kc + e][r] = rw[j][e];
-            }
+            for (int e = 0; e < 4; ++e) sA[buf][kc + e][rA] = ra[j][e];
+        }
+#pragma unroll
+        for (int j = 0; j < CW; ++j) {
+            const int kc = (cW + (256 / FBN) * j) * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sW[buf][kc + e][rW] = rw[j][e];
         }
     };
-    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int wm = (wave >> 1) * WM, wn = (wave & 1) * WN;
     const int fr = lane & 31, hi = lane >> 5;
-    f32x16 acc[2][2];  // [n block][m block]: D[i = n][j = m]
+    f32x16 acc[NI][MJ];  // [n block][m block]: D[i = n][j = m]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < MJ; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -110,22 +118,25 @@ __global__ __launch_bounds__(256, 2) void gemm_f32m_k(const GemmArgs a, int tile
         if (kt + 1 < nkt) gload(kt + 1);
 #pragma unroll
         for (int kk = 0; kk < FBK; kk += 2) {
-            const float w0 = sW[buf][kk + hi][wn + fr], w1 = sW[buf][kk + hi][wn + 32 + fr];
-            const float a0 = sA[buf][kk + hi][wm + fr], a1 = sA[buf][kk + hi][wm + 32 + fr];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, a0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, a1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, a0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, a1, acc[1][1], 0, 0, 0);
+            float wv[NI], av[MJ];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wv[i] = sW[buf][kk + hi][wn + 32 * i + fr];
+#pragma unroll
+            for (int j = 0; j < MJ; ++j) av[j] = sA[buf][kk + hi][wm + 32 * j + fr];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[i], av[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nkt) lstore(buf ^ 1);
         __syncthreads();
     }
     // D register e of a lane: i = (e & 3) + 8 * (e >> 2) + 4 * hi (output column), j = fr (token row)
 #pragma unroll
-    for (int bj = 0; bj < 2; ++bj) {
+    for (int bj = 0; bj < MJ; ++bj) {
         const int m = m0 + wm + bj * 32 + fr;
 #pragma unroll
-        for (int bi = 0; bi < 2; ++bi)
+        for (int bi = 0; bi < NI; ++bi)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int n = n0 + wn + bi * 32 + 8 * g + 4 * hi;
@@ -141,21 +152,62 @@ bool gemm_f32m_ok(const GemmArgs& a) {
     if (a.K % 4 != 0 || a.ldw % 4 != 0) return false;
     if (a.conv ? (a.cin % 4 != 0) : (a.lda % 4 != 0)) return false;
     if (((uintptr_t)a.A & 15) != 0 || ((uintptr_t)a.W & 15) != 0) return false;
-    const int64_t tiles = (int64_t)((a.M + FBM - 1) / FBM) * ((a.N + FBN - 1) / FBN);
+    const int64_t tiles = (int64_t)((a.M + 63) / 64) * ((a.N + 63) / 64);
     return tiles < (1 << 30);
 }
 
-int launch_gemm_f32m(const GemmArgs& a, int epi, hipStream_t st) {
-    S2V_REQUIRE(gemm_f32m_ok(a), "gemm_f32m: shape / alignment not supported (K, lda, ldw multiples of 4 floats, 16-byte aligned operands)");
+// Tile choice (round 6).  The matrix pipe of a CU is what the workgroups on it share, and the dispatcher deals tiles to CUs as evenly as their count
+// allows: a launch takes about ceil(tiles / CUs) tiles' time.  Cost of a candidate = ceil(tiles / CUs) x tile area x (1 + a small penalty for the
+// shorter sides: more operand traffic per MFMA and more prologues); the cheapest wins, ties go to the larger tile.  At C3 sizes (thousands of tiles)
+// every candidate costs the same within the penalty and 128 x 128 stays; at configs[0] (M = 2500) the N = 1920 GEMMs go from 300 tiles (2 per CU on
+// 44 CUs, 1 on the rest) to 1200 tiles of 64 x 64 (5 quarter tiles per CU at most: 1.25 tile times instead of 2).
+static int f32m_cus() {
+    static int cus[64] = {0};
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) d = 0;
+    if (!cus[d]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+        cus[d] = n;
+    }
+    return cus[d];
+}
+int f32m_pick_tile(int M, int N, int cus) {
+    static const int bm[4] = {128, 128, 64, 64}, bn[4] = {128, 64, 128, 64};
+    static const double pen[4] = {1.0, 1.04, 1.04, 1.08};
+    int best = 0;
+    double best_cost = 0;
+    for (int t = 0; t < 4; ++t) {
+        const int64_t tiles = (int64_t)((M + bm[t] - 1) / bm[t]) * ((N + bn[t] - 1) / bn[t]);
+        const double cost = (double)((tiles + cus - 1) / cus) * bm[t] * bn[t] * pen[t];
+        if (t == 0 || cost < best_cost) { best = t; best_cost = cost; }
+    }
+    return best;
+}
+
+template <int FBM, int FBN>
+static int launch_f32m_t(const GemmArgs& a, int epi, hipStream_t st) {
     const int tiles_m = (a.M + FBM - 1) / FBM, tiles_n = (a.N + FBN - 1) / FBN;
     const dim3 grid(tiles_m * tiles_n);
     switch (epi) {
-        case EPI_BIAS: hipLaunchKernelGGL(gemm_f32m_k<EPI_BIAS>, grid, dim3(256), 0, st, a, tiles_m, tiles_n); break;
-        case EPI_BIAS_GELU: hipLaunchKernelGGL(gemm_f32m_k<EPI_BIAS_GELU>, grid, dim3(256), 0, st, a, tiles_m, tiles_n); break;
-        case EPI_BIAS_GATE_RES: hipLaunchKernelGGL(gemm_f32m_k<EPI_BIAS_GATE_RES>, grid, dim3(256), 0, st, a, tiles_m, tiles_n); break;
-        case EPI_BIAS_ADD: hipLaunchKernelGGL(gemm_f32m_k<EPI_BIAS_ADD>, grid, dim3(256), 0, st, a, tiles_m, tiles_n); break;
+        case EPI_BIAS: hipLaunchKernelGGL((gemm_f32m_k<EPI_BIAS, FBM, FBN>), grid, dim3(256), 0, st, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_GELU: hipLaunchKernelGGL((gemm_f32m_k<EPI_BIAS_GELU, FBM, FBN>), grid, dim3(256), 0, st, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_GATE_RES: hipLaunchKernelGGL((gemm_f32m_k<EPI_BIAS_GATE_RES, FBM, FBN>), grid, dim3(256), 0, st, a, tiles_m, tiles_n); break;
+        case EPI_BIAS_ADD: hipLaunchKernelGGL((gemm_f32m_k<EPI_BIAS_ADD, FBM, FBN>), grid, dim3(256), 0, st, a, tiles_m, tiles_n); break;
         default: return s2v_fail(__FILE__, __LINE__, "gemm_f32m: bad epilogue", -1);
     }
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+int launch_gemm_f32m(const GemmArgs& a, int epi, hipStream_t st) {
+    S2V_REQUIRE(gemm_f32m_ok(a), "gemm_f32m: shape / alignment not supported (K, lda, ldw multiples of 4 floats, 16-byte aligned operands)");
+    // GemmArgs::tile 30 .. 33 (s2v_op_linear impl 30 .. 33: tests and tools/f32m_bench.py) forces a candidate; otherwise the cost model picks
+    const int t = (a.tile >= 30 && a.tile <= 33) ? a.tile - 30 : f32m_pick_tile(a.M, a.N, f32m_cus());
+    switch (t) {
+        case 1: return launch_f32m_t<128, 64>(a, epi, st);
+        case 2: return launch_f32m_t<64, 128>(a, epi, st);
+        case 3: return launch_f32m_t<64, 64>(a, epi, st);
+        default: return launch_f32m_t<128, 128>(a, epi, st);
+    }
 }

@@ -344,7 +344,8 @@ S2V_API int s2v_t5_encode(s2v_t5* t5, const int64_t* input_ids_dev, int32_t B, i
 
 /* ---- operator-level entry points (used by the parity tests and micro-benchmarks) ------------------------- */
 /* C[M,N] = A[M,K] . W[N,K]^T + bias, epilogue 0 = bias, 1 = bias + GELU(tanh); impl 0 = MFMA bf16, 1 = generic (VALU),
- * 3 = fp32 operands on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; what the fp32 engine runs, bit-identical to impl 1),
+ * 3 = fp32 operands on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; what the fp32 engine runs, bit-identical to impl 1; the launcher picks the
+ *     tile; 30 .. 33 force 128 x 128 / 128 x 64 / 64 x 128 / 64 x 64, all with the same bits),
  * 4 = fp16 operands on v_mfma_f32_32x32x16_f16 (what the fp16 engine runs; M, N multiples of 128),
  * 2 = MFMA bf16 with K split over several workgroups per output tile, as the engine runs GEMMs with few tiles and a long
  * reduction (M, N multiples of 256; fails if the shape does not qualify; allocates its workspace, synchronous) */

@@ -20,6 +20,17 @@ def timed(fn, n=3):
     return a.elapsed_time(b) / n
 
 
+if "c1" in sys.argv:  # configs[0] (2B, 9 x 256 x 256: M = 2500 rows, D = 1920): every tile shape the launcher can pick, and its pick (impl 3)
+    M = 2500
+    for name, N, K, epi in (("qkv", 5760, 1920, 0), ("out", 1920, 1920, 0), ("ff1+gelu", 7680, 1920, 1), ("ff2", 1920, 7680, 0)):
+        A = torch.randn(M, K, device=DEV)
+        W = torch.randn(N, K, device=DEV) * 0.02
+        b = torch.randn(N, device=DEV)
+        C = torch.empty(M, N, device=DEV)
+        for impl, tag in ((30, "128x128"), (31, "128x64"), (32, "64x128"), (33, "64x64"), (3, "launcher")):
+            ms = timed(lambda: L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, epi, L.DTYPE_F32, impl, L.stream_ptr())), n=20)
+            print(f"gemm_c1 {name:9s} {tag:9s}: M {M} N {N} K {K}: {ms * 1e3:8.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    sys.exit(0)
 M = 38252
 for name, N, K, epi in (("qkv", 9216, 3072, 0), ("out", 3072, 3072, 0), ("ff1+gelu", 12288, 3072, 1), ("ff2", 3072, 12288, 0)):
     A = torch.randn(M, K, device=DEV)
