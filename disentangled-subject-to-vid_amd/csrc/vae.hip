@@ -14,6 +14,7 @@
 #include "common.h"
 #include "kernels.h"
 #include <algorithm>
+#include <type_traits>
 #include "vae_kernels.h"
 
 template <typename T> struct V16;
@@ -460,6 +461,190 @@ int launch_to_ncfhw(const void* y, int F, int H, int W, int Co, void* out, int F
                        (T*)out, Ftot, f0))
     S2V_CHECK_HIP(hipGetLastError());
     return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// conv_out of the decoder (CogVideoXDecoder3D.forward :978-981: CogVideoXCausalConv3d(128 -> 3, k = 3)) as a DIRECT kernel (round 6).
+// As an implicit GEMM it has N = 3 output columns: the 256 x 128-column tile kernel stages A twenty-seven times (once per tap) and multiplies
+// 125 zero columns -- 2.3-2.6 ms per launch at 25 TFLOP/s, 3.7 % of a decode (profiles/r04_vae_conv_rates.txt).  Here a workgroup owns a
+// 4-row x 32-column patch of the output for ALL frames of the batch and walks the F + 2 planes of the padded operand [2 + F][H + 2][W + 2][Cin]
+// once: plane p is the dt = 0 / 1 / 2 tap of output frames p, p - 1, p - 2, so its 6 x 34-pixel halo is copied into LDS once (double-buffered:
+// the next plane's global loads are in flight in registers while this one is multiplied; pixel pitch Cin * 2 + 32 bytes: conflict-free fragment
+// reads, see the pitch note in the kernel) and feeds three rolling accumulators.  Every (dy, dx, 32-channel block) is one
+// v_mfma_f32_16x16x32 per 16-pixel run and output frame: A = 16 consecutive pixels x 32 channels as one ds_read_b128 (lane = pixel i, channel
+// octet g), shared by the three output frames; B = 32 channels x 16 output columns of which Cout are real (lanes j < Cout read their weights
+// from an LDS copy, the others hold zeros); D[i][j] accumulates in fp32.  Frame p - 2 is complete after plane p: bias, round to the model
+// dtype, written in the [C][Ftot][H][W] tile layout directly (the to_ncfhw pass disappears).  Per output element the sum runs over (dt, dy, dx,
+// channel) in ascending order, the order of the implicit GEMM's K index.
+// Lane maps of v_mfma_f32_16x16x32_{bf16,f16}: A[i][k]: i = lane & 15, k = 8 * (lane >> 4) + e; B[k][j]: j = lane & 15, same k;
+// D[i][j]: j = lane & 15, i = 4 * (lane >> 4) + reg (cdna_hip_programming.md, fragment layout).
+#define CO_TH 4
+#define CO_TW 32
+#define CO_PF 13   // 16-byte chunks of a halo plane per thread at Cin = 128: 6 * 34 * 16 / 256 = 12.75
+template <typename T16, int KB /* Cin / 32 */>
+__global__ __launch_bounds__(256, 1) void conv_out_direct_k(const unsigned short* __restrict__ pad, const unsigned short* __restrict__ w, int ldw,
+                                                            const unsigned short* __restrict__ bias, int F, int H, int W, int Cin, int Cout,
+                                                            unsigned short* __restrict__ out, int Ftot, int f0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // LDS pitches (MI355X_MICROARCH, LDS: a ds_read_b128 is served in four groups of sixteen lanes -- {0-3, 12-15, 20-27}, ... -- over 64 banks): with
+    // lane = pixel i + 16 * octet g a group mixes pixels {0-3, 12-15} of one octet with pixels {4-11} of the next; a pixel pitch of 32 bytes
+    // mod 256 (8 banks) puts the first set on the multiples of 8 banks and the second (+ 16 bytes) on the odd multiples of 4: conflict-free (a pitch
+    // of 16 mod 256 made lanes 11 and 12 collide in every group: 2 x).  Weight rows are Cout + 1 <= 4 distinct addresses per group: a row pitch of
+    // 64 bytes mod 256 spreads them over the banks (0 mod 256 was a 4-way conflict on 60 % of the reads).
+    const int pitch = Cin * 2 + 32;                               // bytes per halo pixel
+    const int wpitch = 27 * Cin + 32;                             // elements per weight row in LDS
+    const int halo_bytes = (CO_TH + 2) * (CO_TW + 2) * pitch;     // one plane: [CO_TH + 2][CO_TW + 2] pixels
+    unsigned short* wl = (unsigned short*)(smem + 2 * halo_bytes);  // [Cout + 1][wpitch]: the real output columns, then a row of zeros
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = (W + CO_TW - 1) / CO_TW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * CO_TH, x0 = tx * CO_TW;
+    const int Hp = H + 2, Wp = W + 2;
+    const int K = 27 * Cin;
+    for (int i = tid * 8; i < (Cout + 1) * K; i += 256 * 8) {     // K is a multiple of 8: a 16-byte chunk never straddles two rows
+        const int co = i / K, k = i - co * K;
+        u32x4 v = {0, 0, 0, 0};                                   // row Cout: what the lanes of the 16 - Cout padding columns, and taps of frames that do not exist, read
+        if (co < Cout) v = *(const u32x4*)(w + (size_t)co * ldw + k);
+        *(u32x4*)(wl + (size_t)co * wpitch + k) = v;
+    }
+    const int i16 = lane & 15, g = lane >> 4;
+    constexpr int chunks = KB * 4;                                // 16-byte chunks per pixel (compile-time: the index arithmetic below is shifts and constant divisions)
+    const int plane_chunks = (CO_TH + 2) * (CO_TW + 2) * chunks;
+    u32x4 pf[CO_PF];
+    auto gload = [&](int p) {                                     // plane p of the operand -> registers
+        const unsigned short* plane = pad + (size_t)p * Hp * Wp * Cin;
+#pragma unroll
+        for (int j = 0; j < CO_PF; ++j) {
+            const int i = tid + 256 * j;
+            const int c = i % chunks, px = (i / chunks) % (CO_TW + 2), py = i / (chunks * (CO_TW + 2));
+            const int yy = y0 + py, xx = x0 + px;                 // padded coordinates
+            pf[j] = u32x4{0, 0, 0, 0};
+            if (i < plane_chunks && yy < Hp && xx < Wp) pf[j] = *(const u32x4*)(plane + ((size_t)yy * Wp + xx) * Cin + c * 8);
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* halo = smem + buf * halo_bytes;
+#pragma unroll
+        for (int j = 0; j < CO_PF; ++j) {
+            const int i = tid + 256 * j;
+            const int c = i % chunks, pp = i / chunks;
+            if (i < plane_chunks) *(u32x4*)(halo + pp * pitch + c * 16) = pf[j];
+        }
+    };
+    f32x4 acc[3][2];                                              // [output frame mod 3][16-pixel run]
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) acc[s3][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float bv = i16 < Cout ? ET<T16>::ld((const T16*)bias + i16) : 0.f;
+    const int y = y0 + wave;
+
+    // plane p (p mod 3 == R at compile time: the accumulator slots are static): dt-th tap of output frame p - dt, slot (R - dt) mod 3
+    auto plane_step = [&](auto Rtag, int p) {
+        constexpr int R = decltype(Rtag)::value;
+        const char* halo = smem + (p & 1) * halo_bytes;
+        // output frames p, p - 1, p - 2 exist? (p <= F + 1)  A tap of a frame that does not exist, like the padding columns j >= Cout, reads its B
+        // fragment from the ROW OF ZEROS behind the weights: the loop body has no branch and no select (the compiler's code for a skipped MFMA
+        // shuffled every accumulator through VGPRs: 1.0 ms per launch; selects in the loop: 0.63 ms)
+        const bool live[3] = {p < F, p - 1 >= 0 && p - 1 < F, p - 2 >= 0};
+        const unsigned short* wrow[3];
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) wrow[dt] = wl + (size_t)((i16 < Cout && live[dt]) ? i16 : Cout) * wpitch + g * 8;
+        // One batch = one (dy, dx) tap position: 2 * KB A fragments + 3 * KB B fragments, then 6 * KB MFMAs.  The NEXT batch's twenty ds_read_b128
+        // are issued before this batch's MFMAs (two register sets, the nine batches fully unrolled): with one wave per SIMD nothing else hides the
+        // LDS latency -- the straightforward loop waited for every pair of reads and ran at 31 k cycles per plane instead of 6 k
+        struct Frags { u32x4 a[KB][2]; u32x4 b[KB][3]; };
+        auto load_batch = [&](Frags& fr, int dy, int dx) {
+            const char* arow = halo + ((wave + dy) * (CO_TW + 2) + dx + i16) * pitch + g * 16;
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb) {
+                fr.a[kb][0] = *(const u32x4*)(arow + kb * 64);
+                fr.a[kb][1] = *(const u32x4*)(arow + 16 * pitch + kb * 64);
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) fr.b[kb][dt] = *(const u32x4*)(wrow[dt] + ((dt * 3 + dy) * 3 + dx) * Cin + kb * 32);
+            }
+        };
+        auto mfma_batch = [&](const Frags& fr) {
+#pragma unroll
+            for (int kb = 0; kb < KB; ++kb)
+#pragma unroll
+                for (int dt = 0; dt < 3; ++dt) {
+                    f32x4* ac = acc[(R + 3 - dt) % 3];
+                    if constexpr (__is_same(T16, f16_t)) {
+                        ac[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fr.a[kb][0]), __builtin_bit_cast(f16x8, fr.b[kb][dt]), ac[0], 0, 0, 0);
+                        ac[1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fr.a[kb][1]), __builtin_bit_cast(f16x8, fr.b[kb][dt]), ac[1], 0, 0, 0);
+                    } else {
+                        ac[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr.a[kb][0]), __builtin_bit_cast(bf16x8, fr.b[kb][dt]), ac[0], 0, 0, 0);
+                        ac[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fr.a[kb][1]), __builtin_bit_cast(bf16x8, fr.b[kb][dt]), ac[1], 0, 0, 0);
+                    }
+                }
+        };
+        Frags f0_, f1_;
+        load_batch(f0_, 0, 0);
+#pragma unroll
+        for (int bt = 0; bt < 9; ++bt) {
+            Frags& cur = (bt & 1) ? f1_ : f0_;
+            Frags& nxt = (bt & 1) ? f0_ : f1_;
+            if (bt + 1 < 9) load_batch(nxt, (bt + 1) / 3, (bt + 1) % 3);
+            __builtin_amdgcn_sched_barrier(0);   // the scheduler otherwise sinks the reads back between the MFMAs that need them (fewer live registers, every read waited for)
+            mfma_batch(cur);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (p >= 2) {  // output frame p - 2 is complete: D[i][j]: this lane holds column j = i16 for pixels 4 g .. 4 g + 3 of each run
+            f32x4* ac = acc[(R + 1) % 3];
+            if (i16 < Cout && y < H) {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const int x = x0 + r * 16 + 4 * g;
+                    T16* o = (T16*)out + (((size_t)i16 * Ftot + f0 + (p - 2)) * H + y) * W + x;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (x + e < W) ET<T16>::st(o + e, ac[r][e] + bv);
+                }
+            }
+            ac[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            ac[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>; using R2 = std::integral_constant<int, 2>;
+    const int P = F + 2;
+    gload(0);
+    lstore(0);
+    __syncthreads();                                              // plane 0 and the weights are in LDS
+    for (int p = 0; p < P; ++p) {
+        if (p + 1 < P) gload(p + 1);                              // in flight while plane p is multiplied
+        switch (p % 3) {
+            case 0: plane_step(R0{}, p); break;
+            case 1: plane_step(R1{}, p); break;
+            default: plane_step(R2{}, p); break;
+        }
+        if (p + 1 < P) lstore((p + 1) & 1);                       // the other buffer: last read as plane p - 1, before the barrier below of step p - 1
+        __syncthreads();
+    }
+}
+// conv_out as the direct kernel when it qualifies (16-bit dtype, Cin % 32 == 0, Cout <= 16, the whole LDS image fits); returns 1 when launched, 0 when
+// the caller has to take the implicit-GEMM path, < 0 on error
+int launch_conv_out_direct(const void* pad, const void* w, int ldw, const void* bias, int F, int H, int W, int Cin, int Cout, void* out, int Ftot,
+                           int f0, int dtype, hipStream_t st) {
+    if ((dtype != S2V_BF16 && dtype != S2V_F16) || Cin % 32 != 0 || Cin > 128 || Cout > 16 || Cout < 1 || ldw % 8 != 0) return 0;
+    const size_t shmem = (size_t)2 * (CO_TH + 2) * (CO_TW + 2) * (Cin * 2 + 32) + (size_t)(Cout + 1) * (27 * Cin + 32) * 2;
+    if (shmem > 160 * 1024) return 0;
+    const int tiles = ((W + CO_TW - 1) / CO_TW) * ((H + CO_TH - 1) / CO_TH);
+#define S2V_CO_LAUNCH(T, KBV)                                                                                                               \
+    {                                                                                                                                        \
+        S2V_TRY(ensure_lds_attr((const void*)conv_out_direct_k<T, KBV>, 160 * 1024));                                                        \
+        hipLaunchKernelGGL((conv_out_direct_k<T, KBV>), dim3(tiles), dim3(256), shmem, st, (const unsigned short*)pad, (const unsigned short*)w, \
+                           ldw, (const unsigned short*)bias, F, H, W, Cin, Cout, (unsigned short*)out, Ftot, f0);                             \
+    }
+    const int kbv = Cin / 32;
+    if (dtype == S2V_F16) {
+        if (kbv == 4) S2V_CO_LAUNCH(f16_t, 4) else if (kbv == 2) S2V_CO_LAUNCH(f16_t, 2) else if (kbv == 1) S2V_CO_LAUNCH(f16_t, 1) else return 0;
+    } else {
+        if (kbv == 4) S2V_CO_LAUNCH(bf16_t, 4) else if (kbv == 2) S2V_CO_LAUNCH(bf16_t, 2) else if (kbv == 1) S2V_CO_LAUNCH(bf16_t, 1) else return 0;
+    }
+#undef S2V_CO_LAUNCH
+    S2V_CHECK_HIP(hipGetLastError());
+    return 1;
 }
 
 // blend_v / blend_h of tiled_decode, in place on tile b ([C][F][Hb][Wb]) from its already-blended neighbour a:

@@ -382,14 +382,21 @@ static int alloc_workspace_set(s2v_vae* v, int th, int tw, int fz_max) {
 // on the device and torch's caching allocator may move that figure: hence the retry-with-fewer path) and by a byte cap (a quarter of the
 // device's memory unless S2V_VAE_WORKSPACE_MAX_GB says otherwise).
 static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws = 1) {
-    if (v->th >= th && v->tw >= tw && v->fmax[0] >= fz_max && v->ws_req >= nws && !v->ws.empty()) return 0;
+    // Sets sized for a LARGER window than this request leave fewer tiles in flight than the byte cap allows: an untiled decode of 90 x 160 latents
+    // (one 57.7 GB set) followed by the tiled decode of the same latents (30 x 45 tiles: 21.7 GB sets, three fit the cap) used to keep the one big
+    // set and run the twenty tiles one after the other -- 1.9 s instead of ~1.4 (bench.py times untiled, then tiled).  A request
+    // for several sets that the present capacity cannot serve, while sets of the REQUESTED size could, rebuilds them at the requested size.
+    const bool oversized = !v->ws.empty() && (v->th > th || v->tw > tw) && nws > 1 && (int)v->ws.size() < nws;
+    if (!oversized && v->th >= th && v->tw >= tw && v->fmax[0] >= fz_max && v->ws_req >= nws && !v->ws.empty()) return 0;
     S2V_CHECK_HIP(hipDeviceSynchronize());
     for (void* p : v->geo_allocs) (void)hipFree(p);
     v->geo_allocs.clear();
-    th = th > v->th ? th : v->th;
-    tw = tw > v->tw ? tw : v->tw;
+    if (!oversized) {  // growing: never below what an earlier decode needed
+        th = th > v->th ? th : v->th;
+        tw = tw > v->tw ? tw : v->tw;
+        nws = std::max(nws, v->ws_req);
+    }
     fz_max = fz_max > v->fmax[0] ? fz_max : v->fmax[0];
-    nws = std::max(nws, v->ws_req);
     const int nws_req = nws;
     // from here until the commit below the context has NO capacity
     v->th = v->tw = 0; v->ws_req = 0; v->ws.clear(); v->ws_active = 0; v->cur_h = v->cur_w = 0;
@@ -489,14 +496,27 @@ static void vae_gemm_log(const GemmArgs& g, int epi, bool mfma, const char* kind
         if (FILE* f = fopen(lg, "a")) { fprintf(f, "%d %d %d %d %d %s\n", g.M, g.N, g.K, epi, (int)mfma, kind); fclose(f); }
 }
 #endif
+// direct_dst (conv_out only): the [C][Ftot][H][W] tile output -- when the direct small-N kernel qualifies (launch_conv_out_direct) it writes there
+// and *did_direct is set; otherwise the implicit GEMM writes `out` and the caller converts the layout
 static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int epi, const void* resid, void* out,
-                    hipStream_t st) {
+                    hipStream_t st, char* direct_dst = nullptr, int Ftot = 0, int f0 = 0, bool* did_direct = nullptr) {
     const int64_t fb = (int64_t)(H + 2) * (W + 2) * c.cin * v->esz;
     if (c.kt == 3 && first) {
         S2V_CHECK_HIP(hipMemcpyAsync(c.pad, c.pad + 2 * fb, fb, hipMemcpyDeviceToDevice, st));
         S2V_CHECK_HIP(hipMemcpyAsync(c.pad + fb, c.pad + 2 * fb, fb, hipMemcpyDeviceToDevice, st));
     }
     const int taps = c.kt == 3 ? 27 : 9;
+    bool direct = false;
+    bool want_direct = direct_dst && c.kt == 3 && epi == EPI_BIAS && !v->cfg.force_simple && (v->mfma || v->h16);
+#ifdef S2V_DIAG
+    if (getenv("S2V_VAE_NO_DIRECT_CONV_OUT")) want_direct = false;  // same-box A/B against the implicit-GEMM conv_out (diagnostics build only)
+#endif
+    if (want_direct) {
+        const int rc = launch_conv_out_direct(c.pad, c.w, taps * c.cin, c.b, F, H, W, c.cin, c.cout, direct_dst, Ftot, f0, v->dtype, st);
+        if (rc < 0) return rc;
+        direct = rc == 1;
+    }
+    if (did_direct) *did_direct = direct;
     GemmArgs g{};
     g.A = c.pad; g.W = c.w; g.ldw = taps * c.cin; g.bias = c.b; g.C = out; g.ldc = c.cout;
     g.M = F * H * W; g.N = c.cout; g.K = taps * c.cin;
@@ -508,9 +528,10 @@ static int run_conv(s2v_vae* v, ConvL& c, int F, int H, int W, bool first, int e
         if (epi == EPI_BIAS_ADD && atoi(e) == 1) { epi = EPI_BIAS; g.R = nullptr; }
         if (epi == EPI_BIAS_ADD && atoi(e) == 2) g.R = (const char*)c.pad;  // some other resident buffer of at least M x cout elements
     }
-    vae_gemm_log(g, epi, v->mfma && c.cin % 64 == 0, "conv");
+    if (!direct) vae_gemm_log(g, epi, v->mfma && c.cin % 64 == 0, "conv");
 #endif
-    if (v->mfma && c.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, epi, st));  // cout = 3 (conv_out) runs one padded 128-column tile
+    if (direct) {}  // conv_out ran as the direct kernel
+    else if (v->mfma && c.cin % 64 == 0) S2V_TRY(launch_gemm_bf16(g, epi, st));  // cout = 3 (conv_out) without the direct kernel: one padded 128-column tile
     else if (v->h16 && gemm_f16_ok(g, epi)) S2V_TRY(launch_gemm_f16(g, epi, st));
     else { g.valu_only = v->cfg.force_simple; S2V_TRY(launch_gemm_simple(g, epi, v->dtype, st)); }
     if (c.kt == 3) {  // conv cache: the last two frames of the operand become frames 0, 1 of the next batch (adjacent on both sides: one copy unless they overlap)
@@ -570,8 +591,9 @@ static int decode_batch(s2v_vae* v, int Fz, int h, int w, bool first, char* dst,
         }
     }
     S2V_TRY(run_snorm(v, v->norm_out, v->dense[cur], F, H, W, Fz, h, w, v->conv_out.pad, 2, st));
-    S2V_TRY(run_conv(v, v->conv_out, F, H, W, first, EPI_BIAS, nullptr, v->dense[t1], st));
-    S2V_TRY(launch_to_ncfhw(v->dense[t1], F, H, W, v->cfg.out_channels, dst, Ftot, f0, v->dtype, st));
+    bool direct = false;
+    S2V_TRY(run_conv(v, v->conv_out, F, H, W, first, EPI_BIAS, nullptr, v->dense[t1], st, dst, Ftot, f0, &direct));
+    if (!direct) S2V_TRY(launch_to_ncfhw(v->dense[t1], F, H, W, v->cfg.out_channels, dst, Ftot, f0, v->dtype, st));
     *frames_out = F;
     return 0;
 }

@@ -26,6 +26,8 @@ int launch_gn_stats(const void* x, int64_t P, int C, int G, double* sums, double
 int launch_snorm_apply(const SNormArgs& a, int dtype, hipStream_t st);
 int launch_upsample(const void* x, int F, int H, int W, int C, int compress_time, void* out, int dtype, hipStream_t st);
 int launch_to_ncfhw(const void* y, int F, int H, int W, int Co, void* out, int Ftot, int f0, int dtype, hipStream_t st);
+int launch_conv_out_direct(const void* pad, const void* w, int ldw, const void* bias, int F, int H, int W, int Cin, int Cout, void* out, int Ftot,
+                           int f0, int dtype, hipStream_t st);  // 1 = launched, 0 = does not qualify
 int launch_blend(const void* a, int Ha, int Wa, void* b, int Hb, int Wb, int CF, int E, int vertical, int dtype,
                  hipStream_t st);
 int launch_paste(const void* tile, int Ht, int Wt, int ch, int cw, void* out, int H, int W, int y0, int x0, int CF,
