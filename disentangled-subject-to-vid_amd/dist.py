@@ -210,12 +210,26 @@ class CfgPair:
             if p == self.pair:
                 self.group = g
         self.comm = RcclComm(group=self.group) if native else None
+        self._host = None   # pinned staging of the pair buffer for backends that do not move device memory themselves (exchange)
 
     def exchange(self, engine):
-        """after denoise_split_begin: fill the peer's half of the engine's pair buffer"""
+        """after denoise_split_begin: fill the peer's half of the engine's pair buffer.
+        native: s2v_rccl_allgather, stream-ordered.  Backend nccl (= RCCL): torch's all_gather on the device halves, stream-ordered.  Any other
+        backend (gloo: the tests, one-GPU boxes): the half travels through pinned host memory AFTER the stream has drained -- gloo's own handling of
+        device tensors waits for pending GPU work by polling and took 0.8-1.4 s per call behind a 6 ms forward (tools/cfgp_one_device_probe.py);
+        host-staged it is 1-2 ms."""
         pair = engine.cfg_pair()
         if self.comm is not None:
             self.comm.allgather(pair, pair[0].numel() * pair.element_size())
+            return
+        if pair.is_cuda and dist.get_backend(self.group) != "nccl":
+            if self._host is None or self._host.shape != pair.shape or self._host.dtype != pair.dtype:
+                self._host = torch.empty(pair.shape, dtype=pair.dtype).pin_memory()
+            host = self._host
+            host[self.slot].copy_(pair[self.slot], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            dist.all_gather([host[0], host[1]], host[self.slot].clone(), group=self.group)
+            pair[1 - self.slot].copy_(host[1 - self.slot], non_blocking=True)
             return
         mine = pair[self.slot].clone()
         dist.all_gather([pair[0], pair[1]], mine, group=self.group)

@@ -290,7 +290,12 @@ class S2VEngine:
         raw = torch.as_tensor(_ArenaView(p.value, 2 * n.value), device=self.device)
         return raw.view(self.dtype).view(2, F, self.cfg.out_channels, H, W)
 
+    def _no_auto_in_a_pair(self):
+        if self.cfg.attn_p_format == "auto":  # "auto" settles per engine from its own census: the two ranks of a pair could settle differently
+            raise _lib.S2VError("attn_p_format 'auto' is per-engine; the two ranks of a CFG-parallel pair must run the same arithmetic: use 'bf16' or 'f16'")
+
     def denoise_split_begin(self, latents, timestep, coef, slot, use_graph=False):
+        self._no_auto_in_a_pair()
         if latents.dtype != self.dtype or not latents.is_contiguous():
             raise _lib.S2VError("latents must be a contiguous model-dtype tensor")
         _lib.check(_lib.lib().s2v_denoise_split_begin(self._h, _lib.ptr(latents), float(timestep), ctypes.byref(coef), int(slot), int(use_graph),
@@ -301,6 +306,7 @@ class S2VEngine:
 
     def denoise_step_cfg_parallel(self, comm, slot, latents, timestep, coef, x0_hist=None, noise=None, use_graph=False):
         """begin + s2v_rccl_allgather + end in ONE library call over an RcclComm of the two ranks of the pair"""
+        self._no_auto_in_a_pair()
         if latents.dtype != self.dtype or not latents.is_contiguous():
             raise _lib.S2VError("latents must be a contiguous model-dtype tensor (it is updated in place)")
         _lib.check(_lib.lib().s2v_denoise_step_cfg_parallel(self._h, comm._h, int(slot), _lib.ptr(latents), float(timestep), ctypes.byref(coef),

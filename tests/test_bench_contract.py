@@ -88,3 +88,40 @@ def test_self_spawned_ranks_report_the_devices_they_ran_on():
     assert line["config"]["launcher"] == "self-spawned" and len(line["config"]["ranks"]) == 2
     assert abs(line["value"] - 2 * line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) <= 0.02 * line["value"]
     assert line["config"]["weight_broadcast_gb"] > 0 and line["config"]["outputs_finite"]
+
+
+def test_cfg_parallel_needs_an_even_number_of_ranks(bench):
+    """--cfg-parallel pairs the ranks up (dist.cfg_pair_layout): an odd or single-rank request is refused before anything is launched"""
+    for n in ("1", "3"):
+        with pytest.raises(SystemExit) as e:
+            bench.main(["--gpus", n, "--cfg-parallel"])
+        assert "even" in str(e.value.code)
+
+
+@pytest.mark.gpu
+def test_cfg_parallel_pair_on_one_device_reports_video_steps():
+    """two self-spawned ranks of ONE CFG-parallel pair sharing cuda:0 (gloo carries the all-gather): the line counts video steps -- each step
+    is done by BOTH ranks, so value = steps / time, not 2 x --, names the exchange, and the latents stayed finite on both ranks"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(S2V_BENCH_ONE_DEVICE="1", S2V_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cfg-parallel", "--steps", "3", "--warmup", "1", "--workload",
+                        "cogvideox-2b-9x256x256", "--no-roofline", "--single-mode"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and cfg["rccl_ranks"] == 2 and cfg["samples_per_gpu_per_step"] == 1
+    assert cfg["parallelism"] == "cfg-parallel pairs x1" and cfg["cfg_parallel"]["pairs"] == 1 and "all_gather" in cfg["cfg_parallel"]["exchange"]
+    assert abs(line["value"] - line["steps"] / (line["ms_per_step"] * line["steps"] / 1e3)) <= 0.02 * line["value"]
+    assert cfg["outputs_finite"] and line["scaling"] == "strong"
+
+
+@pytest.mark.gpu
+def test_batch_1_reports_the_half_step_as_the_projection():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "S2V_BENCH_ONE_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "1", "--steps", "3", "--warmup", "1", "--workload",
+                        "cogvideox-2b-9x256x256", "--no-roofline", "--single-mode"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["samples_per_gpu_per_step"] == 1 and line["config"]["projected_cfg_parallel_ms"] == line["ms_per_step"]
+    assert abs(line["value"] - 0.5e3 / line["ms_per_step"]) <= 0.02 * line["value"]   # half a step per GPU-step: two GPUs make one step
+    assert "cpu_baseline" not in line and line["wall_clock_per_video"] is None

@@ -32,3 +32,9 @@ fi
 for f in $E/r06_bench_*.json; do python -c "
 import json; d=json.loads(open('$f').read().strip().splitlines()[-1]); r=d.get('roofline') or {}; c=d.get('cpu_baseline') or {}; print('$f'.split('/')[-1], d['dtype'][:24], d['value'], d['ms_per_step'], r.get('kernel'), r.get('frac'), r.get('calibrated_peak'), 'cpu', c.get('value'), c.get('max_abs_vs_hip'), c.get('rel_l2_vs_hip'), (d.get('wall_clock_per_video') or {}).get('s_per_video_measured'))"; done
 cat $E/smoke.txt 2>/dev/null
+if [ $PART = d ] || [ $PART = all ]; then
+# the gemm_g4t (persistent, trickled bias epilogue) probe on the out-projection / FF2 shapes, as a file
+python tools/g4t_shapes_probe.py 2>/dev/null > $E/r06_g4t_out_ff2_probe.txt
+python tools/vae_decode_time.py 2>/dev/null > $E/r06_vae_decode_times.txt
+python tools/f32m_bench.py c1 2>/dev/null > $E/r06_f32m_c1_tiles.txt
+fi

@@ -19,6 +19,7 @@ res = {}
 st = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if st:
     rows = list(csv.DictReader(open(st[0])))
+    fields = list(rows[0].keys())
     keep = [r for r in rows][:40]
     # the 128 x 128 kernel's rows in a step trace are the ROW TAILS of split GEMMs (108 rows at M = 38 252, api.hip linear()): launched on the side
     # stream beside the 256-row kernel and scheduled behind it, so their "duration" is mostly queueing, not work -- say so in the file
@@ -27,7 +28,7 @@ if st:
         r["note"] = ("side-stream row tail of a split GEMM (the last partial 256-row tile): duration = queueing behind the main launch, not work; "
                      "exclude from shares") if "gemm_bf16_128<" in name else ""
     with open(f"{out}/summary/{tag}_kernel_stats.csv", "w") as f:
-        w = csv.DictWriter(f, fieldnames=list(rows[0].keys()) + ["note"]); w.writeheader(); w.writerows(keep)
+        w = csv.DictWriter(f, fieldnames=fields + ["note"]); w.writeheader(); w.writerows(keep)
     res["kernel_stats"] = f"{out}/summary/{tag}_kernel_stats.csv"
 for name, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE")):
     files = glob.glob(os.path.join(out, name, "**", "*counter_collection.csv"), recursive=True)
