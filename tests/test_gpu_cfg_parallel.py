@@ -207,3 +207,42 @@ def test_two_ranks_on_one_device_pipeline_bitwise(s2v):
             a, b = got[0][2][(sched, graph)], got[1][2][(sched, graph)]
             assert (a == b).all(), f"{sched} graph={graph}: the two ranks of the pair differ"
             assert (a == exp).all(), f"{sched} graph={graph}: CFG-parallel differs from the one-process pipeline"
+
+
+def test_split_entry_points_reject_what_they_cannot_run(s2v):
+    """argument validation of the CFG-parallel C ABI: a B = 2 geometry (the pair already lives on this GPU), a slot outside {0, 1}, null pointers,
+    and attn_p_format 'auto' (settled per engine from its own census: the two ranks of a pair could diverge) fail loudly with a message"""
+    import ctypes
+
+    L = s2v._lib
+    cfg = s2v.tiny(use_rope=True, heads=2, layers=1, text_dim=64, temb=64)
+    sd = s2v.weights.synthetic_state_dict(cfg, seed=71, parity=True)
+    T, F, H, W = 5, 2, 8, 12
+    text, ref, lat = _inputs(cfg, T, F, H, W, 72)
+    lat = lat.bfloat16().contiguous()
+    sch = s2v.CogVideoXDDIMScheduler(snr_shift_scale=1.0)
+    sch.set_timesteps(3)
+    coef = sch.coef(sch.timesteps[0], torch.bfloat16, 6.0)
+    m2, e2 = _engine(s2v, cfg, torch.bfloat16, sd, 2, text, ref, T, F, H, W)
+    with pytest.raises(L.S2VError, match="B = 1"):
+        e2.denoise_split_begin(lat, 999.0, coef, 0)
+    with pytest.raises(L.S2VError, match="B = 1"):
+        e2.denoise_split_end(lat)
+    e2.close()
+    m1, e1 = _engine(s2v, cfg, torch.bfloat16, sd, 1, text[1:2], ref, T, F, H, W)
+    with pytest.raises(L.S2VError, match="slot"):
+        e1.denoise_split_begin(lat, 999.0, coef, 2)
+    assert L.lib().s2v_denoise_split_begin(e1._h, None, 999.0, ctypes.byref(coef), 0, 0, L.stream_ptr()) != 0
+    assert L.lib().s2v_cfg_pair(e1._h, None, None) != 0
+    assert L.lib().s2v_rccl_allgather(None, None, None, 16, L.stream_ptr()) != 0 and b"s2v_rccl_allgather" in L.lib().s2v_last_error()
+    assert L.lib().s2v_denoise_step_cfg_parallel(e1._h, None, 0, L.ptr(lat), 999.0, ctypes.byref(coef), None, None, 0, L.stream_ptr()) != 0
+    pair = e1.cfg_pair()
+    assert tuple(pair.shape) == (2, F, 16, H, W) and pair.dtype == torch.bfloat16
+    e1.close()
+    import copy
+    ca = copy.copy(cfg)
+    ca.attn_p_format = "auto"
+    ma, ea = _engine(s2v, ca, torch.bfloat16, sd, 1, text[1:2], ref, T, F, H, W)
+    with pytest.raises(L.S2VError, match="auto"):
+        ea.denoise_split_begin(lat, 999.0, coef, 1)
+    ea.close()
