@@ -98,6 +98,7 @@ struct s2v_ctx {
     hipStream_t cap_stream = nullptr;
     hipGraphExec_t gexec = nullptr;
     GraphKey gkey{nullptr, nullptr, nullptr, -1};
+    int split_kind = -1;         // scheduler kind of the s2v_denoise_split_begin that has not met its s2v_denoise_split_end yet (-1: none pending)
     // optional per-kernel-class timing with HIP events on the launch stream (bench.py's live roofline figure)
     // + shader-clock stamps (s_memtime / s_memrealtime pairs written by a one-lane kernel right before and right after every profiled launch)
     long long* clk_buf = nullptr;                    // device: CLK_SLOTS x [memtime0, realtime0, memtime1, realtime1]
@@ -478,6 +479,7 @@ extern "C" int s2v_set_geometry(s2v_ctx* c, int32_t B, int32_t T, int32_t F, int
     c->M = (int64_t)B * c->Ntok;
     c->Mpad = rup(c->M, 256) + 256;
     c->have_rope = c->have_pos = c->have_cond = false;
+    c->split_kind = -1;
     const int64_t D = c->D, E = c->esz;
     const int64_t Cin4 = c->cfg.in_channels * 4, Cout4 = c->cfg.out_channels * 4;
     const int64_t BVp = rup((int64_t)B * c->V, 256) + 256;
@@ -1008,6 +1010,7 @@ extern "C" int s2v_denoise_step(s2v_ctx* c, void* latents, float timestep, const
 // only to fill the pair).  begin: the rank's forward into half `slot` of the context-owned pair buffer (a forward-only hipGraph);  the caller
 // exchanges the halves (s2v_rccl_allgather in place, or any transport -- the collective stays OUTSIDE the captured graph);  end: fp32 CFG +
 // scheduler step + round on the pair, run REDUNDANTLY by both ranks (:266-296): both hold bit-identical latents without a second collective.
+int s2v_rccl_pair_check(s2v_rccl_comm* comm, int slot);  // rccl.hip (not exported)
 static int64_t pair_half_bytes(const s2v_ctx* c) { return (int64_t)c->F * c->cfg.out_channels * c->H * c->W * c->esz; }
 
 extern "C" int s2v_denoise_split_begin(s2v_ctx* c, const void* latents, float timestep, const s2v_sched_coef* coef_host, int32_t slot,
@@ -1024,6 +1027,7 @@ extern "C" int s2v_denoise_split_begin(s2v_ctx* c, const void* latents, float ti
     S2V_CHECK_HIP(hipMemcpyAsync(c->t_dev, sg.t, sizeof(float) * 4, hipMemcpyHostToDevice, st));
     S2V_CHECK_HIP(hipMemcpyAsync(c->coef_dev, &sg.c, sizeof(SchedCoef), hipMemcpyHostToDevice, st));
     char* out = c->noise_pred + (int64_t)slot * pair_half_bytes(c);
+    c->split_kind = coef_host->kind;
     if (!use_graph) return forward_impl(c, latents, 0, c->t_dev, out, st);
     GraphKey key{(void*)latents, nullptr, nullptr, slot};
     if (!c->gexec || !(c->gkey == key)) {
@@ -1053,6 +1057,10 @@ extern "C" int s2v_cfg_pair(s2v_ctx* c, void** dev_ptr, int64_t* bytes_per_half)
 extern "C" int s2v_denoise_split_end(s2v_ctx* c, void* latents, float* x0_hist, const void* noise, s2v_stream stream) {
     S2V_REQUIRE(c && latents, "s2v_denoise_split_end: null argument");
     S2V_REQUIRE(c->ws && c->B == 1, "s2v_denoise_split_end: a geometry with B = 1 is required (s2v_denoise_split_begin ran before)");
+    // the step's coefficients live on the device since s2v_denoise_split_begin: one end per begin, and a DPM step brings its noise and x0 history
+    S2V_REQUIRE(c->split_kind >= 0, "s2v_denoise_split_end: no s2v_denoise_split_begin is pending (its coefficients are the step's)");
+    S2V_REQUIRE(c->split_kind == 0 || (noise && x0_hist), "s2v_denoise_split_end: DPM needs noise and x0_hist");
+    c->split_kind = -1;
     SchedArgs a{};
     a.noise_pred = c->noise_pred; a.latents_in = latents; a.latents_out = latents; a.x0_hist = x0_hist; a.noise = noise;
     a.n = (int64_t)c->F * c->cfg.out_channels * c->H * c->W; a.cfg = 1; a.coef = c->coef_dev;  // the coefficients s2v_denoise_split_begin uploaded
@@ -1064,6 +1072,7 @@ extern "C" int s2v_denoise_step_cfg_parallel(s2v_ctx* c, s2v_rccl_comm* comm, in
                                              s2v_stream stream) {
     S2V_REQUIRE(c && comm && latents && coef_host, "s2v_denoise_step_cfg_parallel: null argument");
     S2V_REQUIRE(coef_host->kind == 0 || (noise && x0_hist), "s2v_denoise_step_cfg_parallel: DPM needs noise and x0_hist");
+    S2V_TRY(s2v_rccl_pair_check(comm, slot));  // a two-rank communicator whose rank IS the slot: the in-place all-gather puts rank r's bytes into half r
     S2V_TRY(s2v_denoise_split_begin(c, latents, timestep, coef_host, slot, use_graph, stream));
     const int64_t half = pair_half_bytes(c);
     S2V_TRY(s2v_rccl_allgather(comm, c->noise_pred + (int64_t)slot * half, c->noise_pred, half, stream));  // in place: rank r owns half r

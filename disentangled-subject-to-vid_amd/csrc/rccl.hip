@@ -148,6 +148,13 @@ extern "C" int s2v_rccl_allgather(s2v_rccl_comm* c, const void* send, void* recv
     return 0;
 }
 
+// s2v_denoise_step_cfg_parallel's communicator: the two ranks of ONE pair, rank = the half of the CFG pair the caller computes
+int s2v_rccl_pair_check(s2v_rccl_comm* c, int slot) {
+    S2V_REQUIRE(c && c->comm, "s2v_denoise_step_cfg_parallel: null communicator");
+    S2V_REQUIRE(c->world == 2 && c->rank == slot, "s2v_denoise_step_cfg_parallel: the communicator must hold exactly the two ranks of the pair, and its rank must equal `slot`");
+    return 0;
+}
+
 // The transformer's merged weights (LoRA merged, QKV fused, fp8 copies and scales included) root -> all; a receiver's tensors are
 // marked loaded once the broadcast has been ENQUEUED -- like every entry point this is asynchronous: work submitted to `stream`
 // afterwards sees the weights, the host must not read them before the stream has passed.

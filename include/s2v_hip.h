@@ -225,7 +225,9 @@ S2V_API int s2v_denoise_split_begin(s2v_ctx* ctx, const void* latents, float tim
                                     int32_t use_graph, s2v_stream stream);
 /* the pair buffer [2][F,C,H,W] (model dtype, context-owned) and the bytes of one half */
 S2V_API int s2v_cfg_pair(s2v_ctx* ctx, void** dev_ptr, int64_t* bytes_per_half);
+/* one end per begin (the step's coefficients are the ones begin uploaded); x0_hist / noise as s2v_denoise_step (required for the DPM kinds) */
 S2V_API int s2v_denoise_split_end(s2v_ctx* ctx, void* latents, float* x0_hist, const void* noise, s2v_stream stream);
+/* comm: a communicator of exactly the pair's two ranks whose rank equals `slot` (the in-place all-gather puts rank r's bytes into half r) */
 S2V_API int s2v_denoise_step_cfg_parallel(s2v_ctx* ctx, s2v_rccl_comm* comm, int32_t slot, void* latents, float timestep,
                                           const s2v_sched_coef* coef_host, float* x0_hist, const void* noise, int32_t use_graph,
                                           s2v_stream stream);

@@ -232,6 +232,17 @@ def test_split_entry_points_reject_what_they_cannot_run(s2v):
     m1, e1 = _engine(s2v, cfg, torch.bfloat16, sd, 1, text[1:2], ref, T, F, H, W)
     with pytest.raises(L.S2VError, match="slot"):
         e1.denoise_split_begin(lat, 999.0, coef, 2)
+    with pytest.raises(L.S2VError, match="pending"):     # the step's coefficients are uploaded by begin: no end without its begin ...
+        e1.denoise_split_end(lat)
+    e1.denoise_split_begin(lat, 999.0, coef, 1)
+    e1.denoise_split_end(lat)
+    with pytest.raises(L.S2VError, match="pending"):     # ... and one end per begin
+        e1.denoise_split_end(lat)
+    dsch = s2v.CogVideoXDPMScheduler(snr_shift_scale=1.0)
+    dsch.set_timesteps(3)
+    e1.denoise_split_begin(lat, 999.0, dsch.coef(dsch.timesteps[0], None, True, torch.bfloat16, 6.0), 1)
+    with pytest.raises(L.S2VError, match="DPM"):         # a DPM step brings its noise and x0 history to the end
+        e1.denoise_split_end(lat)
     assert L.lib().s2v_denoise_split_begin(e1._h, None, 999.0, ctypes.byref(coef), 0, 0, L.stream_ptr()) != 0
     assert L.lib().s2v_cfg_pair(e1._h, None, None) != 0
     assert L.lib().s2v_rccl_allgather(None, None, None, 16, L.stream_ptr()) != 0 and b"s2v_rccl_allgather" in L.lib().s2v_last_error()
