@@ -383,9 +383,10 @@ static int alloc_workspace_set(s2v_vae* v, int th, int tw, int fz_max) {
 // device's memory unless S2V_VAE_WORKSPACE_MAX_GB says otherwise).
 static int prepare_tile_capacity(s2v_vae* v, int th, int tw, int fz_max, int nws = 1) {
     // Sets sized for a LARGER window than this request leave fewer tiles in flight than the byte cap allows: an untiled decode of 90 x 160 latents
-    // (one 57.7 GB set) followed by the tiled decode of the same latents (30 x 45 tiles: 21.7 GB sets, three fit the cap) used to keep the one big
-    // set and run the twenty tiles one after the other -- 1.9 s instead of ~1.4 (bench.py times untiled, then tiled).  A request
-    // for several sets that the present capacity cannot serve, while sets of the REQUESTED size could, rebuilds them at the requested size.
+    // (one 57.7 GB set) followed by the tiled decode of the same latents (30 x 45-latent tiles: 5.5 GB per set, six fit) used to keep the one big
+    // set and run the twenty tiles one after the other -- 1.9 s instead of 1.4 (bench.py times untiled, then tiled; at 480 x 720
+    // three 21.7 GB sets instead of six of 5.5 GB).  A request for several sets that the present capacity cannot serve is rebuilt at the REQUESTED
+    // size; the next untiled decode grows it again (a decoder that alternates the two modes re-allocates each time: the pipeline only tiles).
     const bool oversized = !v->ws.empty() && (v->th > th || v->tw > tw) && nws > 1 && (int)v->ws.size() < nws;
     if (!oversized && v->th >= th && v->tw >= tw && v->fmax[0] >= fz_max && v->ws_req >= nws && !v->ws.empty()) return 0;
     S2V_CHECK_HIP(hipDeviceSynchronize());
@@ -695,8 +696,9 @@ extern "C" int s2v_vae_decode(s2v_vae* v, const void* latents, int32_t F, int32_
     for (int i = 0; i < h; i += t.ov_h) is.push_back(i);
     for (int j = 0; j < w; j += t.ov_w) js.push_back(j);
     const size_t nt = is.size() * js.size();
-    // tiles in flight: 49 x 480 x 720 at the real widths measured 928 / 684 / 602 / 605 / 554 / 590 ms with 1 / 2 / 3 / 4 / 6 / 9 sets of
-    // ~20 GB each (profiles/r03_vae_tiles_in_flight.txt); up to six, as many as the byte cap of prepare_tile_capacity holds (three by default)
+    // tiles in flight: 49 x 480 x 720 at the real widths measured 928 / 684 / 602 / 605 / 554 / 590 ms with 1 / 2 / 3 / 4 / 6 / 9 sets
+    // (profiles/r03_vae_tiles_in_flight.txt; round 6: 505-510 ms with six); up to six, as many as the byte cap of prepare_tile_capacity holds (a set
+    // sized for a 30 x 45-latent tile is 5.5 GB: all six)
     int nws_cap = 6;
     if (const char* e = getenv("S2V_VAE_TILES_IN_FLIGHT")) nws_cap = std::max(1, atoi(e));
     int nws = (int)std::min<size_t>(nt, (size_t)nws_cap);
