@@ -253,3 +253,30 @@ def test_tiled_decode_survives_a_workspace_set_that_fails_part_way(s2v, monkeypa
             assert torch.equal(v.decode_latents(lat), y_free)  # and again on the surviving sets
     monkeypatch.delenv("S2V_VAE_FAULT_GEO_ALLOC")
     assert hit, "no injected failure landed inside a later set"
+
+
+@pytest.mark.parametrize("dt_name", ["bf16", "f16"])
+@pytest.mark.parametrize("frames,h,w", [(1, 5, 7), (2, 5, 7), (4, 3, 9)])
+def test_direct_conv_out_kernel_edge_shapes_vs_oracle(s2v, dt_name, frames, h, w):
+    """the direct conv_out kernel (round 6; csrc/vae.hip conv_out_direct_k: runs when the last block has a multiple of 32 channels) on what its
+    plane walk has to get right at the edges: ONE latent frame (three planes, a single output frame), two (8 frames), an even batch after an odd one
+    (4 latent frames = 3 + 1: the second batch is a single frame behind a conv cache), output sizes that are ragged against the 4 x 32 patch
+    (40 x 56, 24 x 72), 32 input channels (one 32-channel block per tap) -- against the CPU oracle"""
+    dt = DT[dt_name]
+    cfgd = dict(block_out_channels=(32, 32, 32, 32), layers_per_block=1, norm_num_groups=4, latent_channels=16,
+                sample_height=480, sample_width=720, scaling_factor=0.7, temporal_compression_ratio=4)
+    cfg = s2v.VAEConfig(**cfgd)
+    sd = {k: v.to(dt).float() for k, v in s2v.weights.synthetic_vae_state_dict(cfg, seed=81).items()}
+    lat = torch.randn(1, frames, 16, h, w, generator=torch.Generator().manual_seed(82)).to(dt).float()
+    with torch.no_grad():
+        exp = vae_ref.decode_latents(sd, cfgd, lat, False)
+    vae = make_vae(s2v, cfgd, dt, sd)
+    y = vae.decode_latents(lat.to(DEV, dt)).float().cpu()
+    torch.cuda.synchronize()
+    assert y.shape == exp.shape
+    assert torch.isfinite(y).all()
+    rel = ((y - exp).double().norm() / exp.double().norm()).item()
+    err = (y - exp).abs().max().item() / exp.abs().max().item()
+    print(f"MEASURED direct conv_out {dt_name} F={frames} {h}x{w}: rel-l2 {rel:.3e} max-abs/max|ref| {err:.3e}")
+    br, ba = (1.7e-2, 2.1e-2) if dt_name == "bf16" else (2.1e-3, 2.5e-3)   # the real-width decoder's bars above
+    assert rel <= br and err <= ba, (rel, err)
