@@ -597,7 +597,17 @@ static int linear(s2v_ctx* c, const GemmArgs& g0, int epi, hipStream_t st) {
         // against 100 for the two rounds on the same stream, slower (117) as a fork on the side stream.
         if (g.splitk == 0 && epi != EPI_BIAS_QKNORM && g.tile == 0 && tm * tn * 2 <= ncu) g.tile = 1;
         const int rem = (int)(g.M % 256);
-        if (rem > 0 && tm > 1 && g.N >= 256 && (tm * tn + ncu - 1) / ncu > ((tm - 1) * tn + ncu - 1) / ncu) {
+        bool split_tail = rem > 0 && tm > 1 && g.N >= 256 && (tm * tn + ncu - 1) / ncu > ((tm - 1) * tn + ncu - 1) / ncu;
+        // Round 6 (the B = 1 geometry of a CFG-parallel rank: M = 19 126): the persistent kernel with the trickled epilogue (gemm_g4t) takes whole
+        // 256-row tiles only, so a QKV projection whose row tail does NOT cost a round (75 x 36 = 2700 tiles = 10.5 rounds either way) used to run on
+        // gemm_g4 with the exposed q/k-norm epilogue: 0.90 ms where half the B = 2 launch is 0.80.  Split the tail off whenever that lets the whole
+        // tiles take gemm_g4t; the tail's 128 x 128 kernel returns the same bits (the B = 2 launch has mixed the two since round 5).
+        if (!split_tail && rem > 0 && tm > 1 && g.N >= 256 && c->mfma && g.splitk == 0 && g.tile == 0) {
+            GemmArgs gw = g;
+            gw.M = (int)((tm - 1) * 256);
+            split_tail = gemm_g4t_ok(gw, epi, (int)ncu);
+        }
+        if (split_tail) {
             GemmArgs gm = g, gt = g;
             gt.clk = nullptr;  // the row tail runs beside the main launch on the side stream: one stamp per profiled launch
             gm.M = (int)((tm - 1) * 256);
