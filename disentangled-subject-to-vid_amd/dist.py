@@ -249,6 +249,29 @@ class CfgPair:
             self.comm = None
 
 
+def run_cfg_parallel(make_engine, load_weights_rank0, prompts, run_prompt, native=False):
+    """run_replicas for CFG-parallel pairs: rank 0 ingests the checkpoints, every other rank receives the arenas; ranks 2p, 2p + 1
+    then run prompt q TOGETHER for every q with q mod pairs == p.  run_prompt(engine, pair: CfgPair, prompt_id, prompt) -> tensor is called on BOTH
+    ranks of the pair with the same arguments (it hands `pair` to S2VPipeline(cfg_parallel=pair) or drives pair.step itself) and returns the same
+    tensor on both; the slot-0 rank's copy is gathered on rank 0.  An odd world size is refused (cfg_pair_layout)."""
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    pair = CfgPair(native=native)
+    eng = make_engine()
+    if rank == 0:
+        load_weights_rank0(eng)
+    broadcast_components(eng if isinstance(eng, (tuple, list)) else [eng], 0)
+    mine = {}
+    for q in range(len(prompts)):
+        if q % pair.pairs == pair.pair:
+            out = run_prompt(eng, pair, q, prompts[q])
+            if pair.slot == 0:
+                mine[q] = out
+    res = gather_results(mine, 0)
+    pair.close()
+    return res
+
+
 def broadcast_components(components, src=0, comm=None):
     """replicate every component of the path -- transformer engine, VAE (decoder [+ encoder]), T5 encoder: anything with
     .weight_arenas() -> [uint8 tensors] and .mark_weights_loaded() -- rank `src` -> all.  Returns the bytes moved.

@@ -37,7 +37,11 @@ def inference(pipe, text_encoder, ref_image_uint8, prompt_ids, negative_prompt_i
     seed_everything (src/inference.py:28-35: torch.manual_seed + torch.cuda.manual_seed_all).  Here a private device generator seeded with
     `seed` produces the same two draws in the same order (a freshly seeded Philox stream is the same stream whichever generator object
     holds it: tests/test_gpu_end_to_end.py pins the equality) without touching the process-wide RNG state; seed=None draws from the global
-    device generator exactly as the reference does."""
+    device generator exactly as the reference does.
+
+    CFG-parallel (round 6): pass `cfg_parallel=dist.CfgPair(...)` through **pipe_kwargs on BOTH ranks of a pair with the same image, ids and seed: each
+    rank encodes the reference image and the prompts itself (42 ms + 10 ms, step-invariant), runs its half of every step, and both return the same
+    frames."""
     dev = pipe.transformer.device
     generator = None
     if seed is not None:

@@ -426,3 +426,56 @@ def test_cfg_pair_layout_rejects_odd_worlds():
             d.cfg_pair_layout(0, bad)
     with pytest.raises(ValueError):
         d.cfg_pair_layout(2, 2)
+
+
+def _cfgp_replica_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    d = importlib.import_module("disentangled-subject-to-vid_amd.dist")
+    d.init_from_env("gloo")
+
+    def run_prompt(eng, pair, pid, prompt):
+        assert eng.loaded
+        text = torch.randn(2, 5, 8, generator=torch.Generator().manual_seed(int(prompt)))
+        fe = FakeCfgEngine(text[pair.slot:pair.slot + 1] + eng.arena[:8].float().mean() / 255.0)
+        return _cfg_run(None, lambda x, t, coef: pair.step(fe, x, t, coef))
+
+    res = d.run_cfg_parallel(lambda: FakeEngine(1 << 16), _load_rank0, [11, 22, 33], run_prompt)
+    if rank == 0:
+        q.put({k: v.numpy() for k, v in res.items()})
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfg_parallel_pairs_compose_with_replicas():
+    """dist.run_cfg_parallel over four ranks = two pairs: three prompts (pair 0 runs prompts 0 and 2, pair 1 prompt 1), weights from rank 0 only, results
+    gathered from the slot-0 ranks; every result equals one process computing both halves"""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cfgp_replica_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(got) == [0, 1, 2]
+    eng = FakeEngine(1 << 16)
+    _load_rank0(eng)
+    shift = eng.arena[:8].float().mean() / 255.0
+    for pid, prompt in enumerate([11, 22, 33]):
+        text = torch.randn(2, 5, 8, generator=torch.Generator().manual_seed(prompt)) + shift
+        e0, e1 = FakeCfgEngine(text[0:1]), FakeCfgEngine(text[1:2])
+
+        def both(x, t, coef):
+            e0.denoise_split_begin(x, t, coef, 0)
+            e1.denoise_split_begin(x, t, coef, 1)
+            e0.pair[1] = e1.pair[1]
+            e0.denoise_split_end(x)
+
+        assert (got[pid] == _cfg_run(None, both).numpy()).all(), pid
