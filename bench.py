@@ -262,12 +262,17 @@ def cpu_baseline_vae(s2v, dev, cores, vae_scaling=0.7, F=13, H=60, W=90):
 # kernel names as rocprofv3 prints them (template arguments included)
 KERNEL_OF_CLASS = {"attention": "attn_qx_persist_k<2>", "gemm_qkv": "gemm_g4t<4>", "gemm_ff1_gelu": "gemm_g4t<1>",
                    "gemm_out": "gemm_g4<2>", "gemm_ff2": "gemm_g4<2>"}  # <4>: QKV with the fused q/k norm + rotary epilogue; g4t: trickled epilogue
+# what the same classes run on at other geometries / widths (the first name present in the PMC pass counts): short sequences take attn_pp_k, few-tile
+# and non-256-multiple shapes the eight-wave / four-wave non-persistent kernels
+KERNEL_ALTERNATIVES = {"attention": ["attn_pp_k<false>", "attn_pp_k<true>"], "gemm_qkv": ["gemm_g4<4>", "gemm_bf16_pp64<4>"],
+                       "gemm_ff1_gelu": ["gemm_g4<1>", "gemm_bf16_pp64<1>"], "gemm_out": ["gemm_bf16_stag<2>"], "gemm_ff2": ["gemm_bf16_stag<2>"]}
 
 
 # which committed rocprofv3 PMC passes belong to which workload (profiles/README.md): rNN_ = the default workload,
 # rNNfp8_ = the fp8 engine at the same geometry, rNN_c1_ = the C1 geometry; the other workloads have no PMC pass
 PMC_PREFIX = {"cogvideox-5b-49x480x720": r"r\d+_pmc", "cogvideox-5b-fp8-49x480x720": r"r\d+fp8_pmc", "cogvideox-2b-9x256x256": r"r\d+_c1_pmc",
-              "cogvideox-5b-fp8-49x720x1280": r"r\d+_c5fp8_pmc"}  # rNN_c5fp8_ = BASELINE configs[4]
+              "cogvideox-5b-fp8-49x720x1280": r"r\d+_c5fp8_pmc",   # rNN_c5fp8_ = BASELINE configs[4]
+              "cogvideox-2b-49x480x720": r"r\d+_c2_pmc"}          # rNN_c2_ = BASELINE configs[1] (round 6)
 
 
 def pmc_traffic_bytes(kernel_class, workload):
@@ -288,16 +293,25 @@ def pmc_traffic_bytes(kernel_class, workload):
     if not fetch or not write:
         return None, []
 
+    def norm(n):
+        """rocprofv3 prints the return type and every template argument, defaults included"""
+        n = n.replace("void ", "").replace(", unsigned short>", ">").replace(", 0, false>", ">").replace(", 0>", ">")
+        return n.replace(" ", "")
+
     def mean_kb(path):
-        tot = cnt = 0.0
-        for row in csv.reader(open(path)):
-            got = row[0].replace("void ", "").replace(", 0, false>", ">").replace(", 0>", ">").replace(", unsigned short>", ">").replace(" ", "") if row else ""
-            # default template arguments and the return type are printed too; the attention kernel's name carries its format flags
-            # (<2, false, false> bf16 P, <2, false, true> fp16 P, <2, true, ...> fp8 QK^T): any four-wave form of the pass counts
-            if got == name.replace(" ", "") or (name.startswith("attn_qx_persist_k<2") and got.startswith("attn_qx_persist_k<2")):
-                tot += float(row[2]) * float(row[1])
-                cnt += float(row[1])
-        return tot / cnt if cnt else None
+        rows = [r for r in csv.reader(open(path)) if r and r[0] != "kernel"]
+        for cand in [name] + KERNEL_ALTERNATIVES.get(kernel_class, []):
+            tot = cnt = 0.0
+            for row in rows:
+                got = norm(row[0])
+                # the attention kernel's name carries its format flags (<2, false, false> bf16 P, <2, false, true> fp16 P, <2, true, ...> fp8 QK^T):
+                # any four-wave form of the pass counts
+                if got == cand.replace(" ", "") or (cand.startswith("attn_qx_persist_k<2") and got.startswith("attn_qx_persist_k<2")):
+                    tot += float(row[2]) * float(row[1])
+                    cnt += float(row[1])
+            if cnt:
+                return tot / cnt
+        return None
 
     f, w = mean_kb(os.path.join(pdir, fetch[-1])), mean_kb(os.path.join(pdir, write[-1]))
     if f is None or w is None:

@@ -38,3 +38,9 @@ python tools/g4t_shapes_probe.py 2>/dev/null > $E/r06_g4t_out_ff2_probe.txt
 python tools/vae_decode_time.py 2>/dev/null > $E/r06_vae_decode_times.txt
 python tools/f32m_bench.py c1 2>/dev/null > $E/r06_f32m_c1_tiles.txt
 fi
+if [ $PART = e ]; then
+# FETCH_SIZE / WRITE_SIZE passes of the other BASELINE configurations (roofline.traffic of their lines reads them from profiles/): configs[1], configs[0], configs[4]
+for t in "r06_c2 cogvideox-2b-49x480x720" "r06_c1 cogvideox-2b-9x256x256" "r06_c5fp8 cogvideox-5b-fp8-49x720x1280"; do
+  set -- $t; bash tools/profile.sh $1 --workload $2 > $E/profile_$1.log 2>&1; cp gpurun_out/prof_$1/summary/* $E/; rm -rf gpurun_out/prof_$1
+done
+fi
