@@ -210,6 +210,7 @@ class CfgPair:
             if p == self.pair:
                 self.group = g
         self.comm = RcclComm(group=self.group) if native else None
+        self._dev = None    # torch-allocated all-gather target (nccl / CPU path of exchange)
         self._host = None   # pinned staging of the pair buffer for backends that do not move device memory themselves (exchange)
 
     def exchange(self, engine):
@@ -231,8 +232,14 @@ class CfgPair:
             dist.all_gather([host[0], host[1]], host[self.slot].clone(), group=self.group)
             pair[1 - self.slot].copy_(host[1 - self.slot], non_blocking=True)
             return
+        # nccl (= RCCL), or CPU tensors on any backend: one all-gather into a torch-allocated buffer, then one copy into the context-owned pair
+        # (the pair buffer is library memory wrapped through __cuda_array_interface__: it is kept out of c10d's allocator bookkeeping -- two 2.2 MB
+        # device copies per step are the price, stream-ordered like the collective)
         mine = pair[self.slot].clone()
-        dist.all_gather([pair[0], pair[1]], mine, group=self.group)
+        if self._dev is None or self._dev.shape != pair.shape or self._dev.dtype != pair.dtype or self._dev.device != pair.device:
+            self._dev = torch.empty(pair.shape, dtype=pair.dtype, device=pair.device)
+        dist.all_gather_into_tensor(self._dev.view(-1), mine.view(-1), group=self.group)
+        pair[1 - self.slot].copy_(self._dev[1 - self.slot], non_blocking=True)
 
     def step(self, engine, latents, timestep, coef, x0_hist=None, noise=None, use_graph=False):
         """one denoise step of the pair's video; latents (identical on both ranks) updated in place on both"""
