@@ -241,6 +241,25 @@ class CfgPair:
         dist.all_gather_into_tensor(self._dev.view(-1), mine.view(-1), group=self.group)
         pair[1 - self.slot].copy_(self._dev[1 - self.slot], non_blocking=True)
 
+    def assert_same(self, **tensors):
+        """once per video: the two ranks of a pair must hold the SAME start latents, reference latent and embeddings (each computes its half of every
+        step from them and both apply the scheduler step): a rank that drew its own latents would diverge silently.  Compares a checksum of every
+        named tensor across the pair (one small object all-gather) and raises on BOTH ranks when they differ."""
+        sums = {}
+        for k, t in tensors.items():
+            if t is None:
+                sums[k] = None
+                continue
+            b = t.detach().contiguous().view(torch.uint8).to(torch.int64)
+            w = torch.arange(1, b.numel() + 1, device=b.device, dtype=torch.int64) % 65521
+            sums[k] = (tuple(t.shape), str(t.dtype), int((b.view(-1) * w).sum().item()))
+        both = [None, None]
+        dist.all_gather_object(both, sums, group=self.group)
+        bad = [k for k in sums if both[0][k] != both[1][k]]
+        if bad:
+            raise RuntimeError(f"CFG-parallel pair {self.pair}: the two ranks were given different {bad} (slot 0: {[both[0][k] for k in bad]}, "
+                               f"slot 1: {[both[1][k] for k in bad]}); pass the same tensors, or generators seeded alike, to both ranks")
+
     def step(self, engine, latents, timestep, coef, x0_hist=None, noise=None, use_graph=False):
         """one denoise step of the pair's video; latents (identical on both ranks) updated in place on both"""
         if self.comm is not None:

@@ -97,6 +97,8 @@ class S2VPipeline:
 
         if cfg_parallel is not None and not fused:
             raise ValueError("cfg_parallel runs the fused step (one sample of the CFG pair per rank); fused=False is the reference's seam sequence")
+        if cfg_parallel is not None:  # both ranks compute from the same inputs or the video is garbage: checked once, collectively
+            cfg_parallel.assert_same(latents=latents, ref_img_states=ref, text=text)
         if fused:
             # CFG-parallel: B = 1 with this rank's half of [negative | positive] (custom_cogvideox_pipe.py:196) and the un-duplicated reference tokens
             my_text = text if cfg_parallel is None else text[cfg_parallel.slot:cfg_parallel.slot + 1]

@@ -479,3 +479,38 @@ def test_cfg_parallel_pairs_compose_with_replicas():
             e0.denoise_split_end(x)
 
         assert (got[pid] == _cfg_run(None, both).numpy()).all(), pid
+
+
+def _same_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    d = importlib.import_module("disentangled-subject-to-vid_amd.dist")
+    d.init_from_env("gloo")
+    cp = d.CfgPair(native=False)
+    lat = torch.randn(1, 2, 4, 6, 6, generator=torch.Generator().manual_seed(3))
+    cp.assert_same(latents=lat, ref=None, text=torch.ones(2, 3))          # identical: passes
+    verdict = "no error"
+    try:
+        cp.assert_same(latents=lat + (1e-3 if rank == 1 else 0.0), text=torch.ones(2, 3))   # rank 1 drew its own latents
+    except RuntimeError as e:
+        verdict = str(e)
+    q.put((rank, verdict))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cfg_pair_refuses_ranks_that_start_from_different_latents():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_same_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):   # BOTH ranks raise, naming what differs
+        assert "different ['latents']" in got[r], got[r]
