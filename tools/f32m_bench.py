@@ -27,9 +27,24 @@ if "c1" in sys.argv:  # configs[0] (2B, 9 x 256 x 256: M = 2500 rows, D = 1920):
         W = torch.randn(N, K, device=DEV) * 0.02
         b = torch.randn(N, device=DEV)
         C = torch.empty(M, N, device=DEV)
-        for impl, tag in ((30, "128x128"), (31, "128x64"), (32, "64x128"), (33, "64x64"), (3, "launcher")):
-            ms = timed(lambda: L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, epi, L.DTYPE_F32, impl, L.stream_ptr())), n=20)
+        best = {}
+        for rnd in range(3):  # three interleaved rounds, the minimum per tile: the first launches of a process run at a lower clock
+            for impl, tag in ((30, "128x128"), (31, "128x64"), (32, "64x128"), (33, "64x64"), (3, "launcher")):
+                ms = timed(lambda: L.check(L.lib().s2v_op_linear(L.ptr(A), L.ptr(W), L.ptr(b), L.ptr(C), M, N, K, epi, L.DTYPE_F32, impl, L.stream_ptr())), n=20)
+                best[tag] = min(best.get(tag, 1e9), ms)
+        for tag, ms in best.items():
             print(f"gemm_c1 {name:9s} {tag:9s}: M {M} N {N} K {K}: {ms * 1e3:8.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s", flush=True)
+    for B, H, N in ((2, 30, 1250),):  # configs[0]'s attention: four waves per workgroup (600 workgroups), two (1200), the launcher's pick
+        D = H * 64
+        qkv = torch.randn(B * N + 64, 3 * D, device=DEV)
+        out = torch.empty(B * N, D, device=DEV)
+        best = {}
+        for rnd in range(3):
+            for impl, tag in ((54, "4 waves"), (52, "2 waves"), (5, "launcher")):
+                ms = timed(lambda: L.check(L.lib().s2v_op_attention(L.ptr(qkv), None, L.ptr(out), B, H, N, L.DTYPE_F32, impl, L.stream_ptr())), n=20)
+                best[tag] = min(best.get(tag, 1e9), ms)
+        for tag, ms in best.items():
+            print(f"attention_c1 {tag:9s}: B {B} H {H} N {N}: {ms * 1e3:8.1f} us  {4.0 * B * H * N * N * 64 / ms / 1e9:7.1f} TFLOP/s", flush=True)
     sys.exit(0)
 M = 38252
 for name, N, K, epi in (("qkv", 9216, 3072, 0), ("out", 3072, 3072, 0), ("ff1+gelu", 12288, 3072, 1), ("ff2", 3072, 12288, 0)):
