@@ -34,13 +34,13 @@ if "c1" in sys.argv:  # configs[0] (2B, 9 x 256 x 256: M = 2500 rows, D = 1920):
                 best[tag] = min(best.get(tag, 1e9), ms)
         for tag, ms in best.items():
             print(f"gemm_c1 {name:9s} {tag:9s}: M {M} N {N} K {K}: {ms * 1e3:8.1f} us  {2.0 * M * N * K / ms / 1e9:7.1f} TFLOP/s", flush=True)
-    for B, H, N in ((2, 30, 1250),):  # configs[0]'s attention: four waves per workgroup (600 workgroups), two (1200), the launcher's pick
+    for B, H, N in ((2, 30, 1250),):  # configs[0]'s attention (a two-wave workgroup form was tried in round 6 and dropped: profiles/r06_f32m_c1_tiles.txt)
         D = H * 64
         qkv = torch.randn(B * N + 64, 3 * D, device=DEV)
         out = torch.empty(B * N, D, device=DEV)
         best = {}
         for rnd in range(3):
-            for impl, tag in ((54, "4 waves"), (52, "2 waves"), (5, "launcher")):
+            for impl, tag in ((5, "attn_f32m"),):
                 ms = timed(lambda: L.check(L.lib().s2v_op_attention(L.ptr(qkv), None, L.ptr(out), B, H, N, L.DTYPE_F32, impl, L.stream_ptr())), n=20)
                 best[tag] = min(best.get(tag, 1e9), ms)
         for tag, ms in best.items():
