@@ -439,7 +439,7 @@ def main(argv=None):
                     "(s2v_bcast_weights) instead of torch.distributed.broadcast")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16"], help="model dtype of the engine, VAE and T5: bf16 = the headline (and every "
                     "5B configuration); f32 = configs[0] as BASELINE names it (the CPU-reference-parity mode, on the fp32 matrix pipe); f16 = what the "
-                    "reference loads non-5B checkpoints in (src/inference.py:191).  Non-bf16 lines skip the format A/B passes and the CPU baseline")
+                    "reference loads non-5B checkpoints in (src/inference.py:191).  Non-bf16 lines skip the attention format A/B passes; every dtype times the CPU oracle beside it")
     ap.add_argument("--batch", type=int, default=2, choices=[1, 2], help="2 = the CFG pair on one GPU (the metric); 1 = ONE sample of the pair: what each of the two "
                     "GPUs of a CFG-parallel pair runs per step (s2v_denoise_split_begin + the CFG / scheduler step; the peer's half is a local copy) -- "
                     "reported as projected_cfg_parallel_ms, the step time of one video on two GPUs less the 2.2 MB all-gather")
