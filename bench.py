@@ -5,6 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W             (the driver's form: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the env)
 
+    python bench.py --batch 1                              (ONE sample of the CFG pair per step: the half step a GPU of a CFG-parallel pair runs)
+    python bench.py --gpus 2 --cfg-parallel                (one video on two GPUs: dist.CfgPair; N even: N / 2 videos in flight)
+
 --gpus N is a CLAIM the run has to earn: with no torchrun environment the script launches N rank processes itself and refuses
 (non-zero exit) when fewer than N GPUs are visible; with a torchrun environment WORLD_SIZE must equal N.  `value` is computed from
 what the ranks report (sum of their timed steps / max elapsed over ranks), never from the flag.
