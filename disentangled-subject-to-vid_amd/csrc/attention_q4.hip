@@ -352,8 +352,11 @@ __global__ __launch_bounds__(64 * (8 / JB), 1) void attn_qx_persist_k(const Attn
                 if (__hip_atomic_load(&queue[y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cnt) continue;
                 const int i = atomicAdd(&queue[y], 1);
                 if (i < cnt) {
+#ifdef S2V_DIAG
                     if (dealt) { const int bh = i / per, j = i - bh * per; wg = bh * nqb + y + 8 * j; }
-                    else wg = first + i;
+                    else
+#endif
+                        wg = first + i;
                 }
             }
             s_item = wg;
